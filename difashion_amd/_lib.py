@@ -1,0 +1,145 @@
+"""ctypes binding of libdifashion_hip.so (C ABI: include/difashion_hip.h).
+
+There is NO fallback: if the HIP library is missing, import of the compute path raises.  PyTorch is
+used on the host side only for device memory, streams and torch.distributed (plumbing).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libdifashion_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "difashion_hip.h")
+
+DFH_MAX_BLOCKS = 4
+
+
+class DfhError(RuntimeError):
+    pass
+
+
+class UNetConfigC(C.Structure):
+    _fields_ = [
+        ("sample_size", C.c_int), ("in_channels", C.c_int), ("out_channels", C.c_int), ("num_blocks", C.c_int),
+        ("block_out_channels", C.c_int * DFH_MAX_BLOCKS), ("layers_per_block", C.c_int),
+        ("cross_attention_dim", C.c_int), ("num_heads", C.c_int * DFH_MAX_BLOCKS),
+        ("down_attn", C.c_int * DFH_MAX_BLOCKS), ("use_linear_projection", C.c_int),
+        ("norm_num_groups", C.c_int), ("norm_eps", C.c_float), ("text_len", C.c_int),
+    ]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("conv_src", C.c_void_p), ("conv_c", C.c_int), ("conv", C.c_int),
+        ("batch", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("stride", C.c_int), ("upsample", C.c_int),
+        ("a0", C.c_void_p), ("a0_c", C.c_int), ("a1", C.c_void_p), ("a1_c", C.c_int),
+        ("W", C.c_void_p), ("ldw", C.c_int),
+        ("M", C.c_int), ("N", C.c_int),
+        ("bias", C.c_void_p),
+        ("rowvec", C.c_void_p), ("rv_ld", C.c_int), ("rv_off", C.c_int), ("rows_per_b", C.c_int),
+        ("resid", C.c_void_p), ("ld_res", C.c_int),
+        ("act", C.c_int),
+        ("out", C.c_void_p), ("ld_out", C.c_int), ("out_mode", C.c_int),
+        ("partial", C.c_void_p), ("partial_floats", C.c_size_t),
+        ("zero_page", C.c_void_p),
+        ("force_tile", C.c_int), ("force_split", C.c_int), ("force_glds", C.c_int),
+    ]
+
+
+class StepCoef(C.Structure):
+    _fields_ = [("kind", C.c_int), ("vpred", C.c_int), ("sqrt_a_t", C.c_float), ("sqrt_b_t", C.c_float),
+                ("sqrt_a_prev", C.c_float), ("dir_coef", C.c_float), ("std_dev", C.c_float)]
+
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); status-returning functions are wrapped to raise DfhError
+SIGNATURES = {
+    "dfh_abi_version": (_i, []),
+    "dfh_last_error": (C.c_char_p, []),
+    "dfh_build_info": (C.c_char_p, []),
+    "dfh_unet_create": (_i, [C.POINTER(UNetConfigC), C.POINTER(_vp)]),
+    "dfh_unet_destroy": (None, [_vp]),
+    "dfh_unet_num_params": (_i, [_vp]),
+    "dfh_unet_param_name": (C.c_char_p, [_vp, _i]),
+    "dfh_unet_param_ndim": (_i, [_vp, _i]),
+    "dfh_unet_param_dim": (_i, [_vp, _i, _i]),
+    "dfh_unet_arena16_bytes": (_sz, [_vp]),
+    "dfh_unet_arena32_bytes": (_sz, [_vp]),
+    "dfh_unet_workspace_bytes": (_sz, [_vp, _i]),
+    "dfh_unet_bind": (_i, [_vp, _vp, _vp, _vp, _sz, _i]),
+    "dfh_unet_pack": (_i, [_vp, C.POINTER(_vp), _i, _vp]),
+    "dfh_unet_forward": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "dfh_unet_debug_tap": (_i, [_vp, C.c_char_p, _vp, _sz, _vp]),
+    "dfh_gemm_partial_floats": (_sz, [C.POINTER(GemmDesc)]),
+    "dfh_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
+    "dfh_groupnorm": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    "dfh_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "dfh_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "dfh_timestep_embedding": (_i, [_vp, _vp, _i, _i, _vp]),
+    "dfh_nchw_to_nhwc_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    "dfh_cast_f32_to_bf16": (_i, [_vp, _vp, _sz, _vp]),
+    "dfh_pack_conv3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "dfh_pack_matrix": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "dfh_pack_vector": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "dfh_mutual_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "dfh_assemble_input": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp]),
+    "dfh_cfg_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, C.POINTER(StepCoef), _vp]),
+    "dfh_noise_mix": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "dfh_mse_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+}
+_NO_STATUS = {"dfh_abi_version", "dfh_unet_num_params", "dfh_unet_param_ndim", "dfh_unet_param_dim"}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j", str(min(8, os.cpu_count() or 1))]
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=True)
+    r = subprocess.run(args, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise DfhError("building libdifashion_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+def raw():
+    """The ctypes CDLL with prototypes set.  Raises if the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DfhError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU / PyTorch fallback for the compute path)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)       # AttributeError here = header/library drift
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return raw().dfh_last_error().decode()
+
+
+def call(name: str, *args):
+    """Call a status-returning entry point; raise DfhError with the library's message on failure."""
+    rc = getattr(raw(), name)(*args)
+    if name not in _NO_STATUS and SIGNATURES[name][0] is _i and rc != 0:
+        raise DfhError(f"{name} failed ({rc}): {last_error()}")
+    return rc
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())

@@ -1,0 +1,141 @@
+// extern "C" surface of libdifashion_hip.so (declared in include/difashion_hip.h): error plumbing and
+// the op-level entry points.  The U-Net context entry points live in unet.hip.
+#include <cstring>
+#include <string>
+
+#include "../../include/difashion_hip.h"
+#include "attention.h"
+#include "dfh_common.h"
+#include "elementwise.h"
+#include "gemm.h"
+#include "norm.h"
+
+namespace dfh {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return -2;
+  }
+  return 0;
+}
+}  // namespace dfh
+
+static int fill_gemm(const dfh_gemm_desc* d, GemmArgs* g) {
+  DFH_REQUIRE(d != nullptr, "null descriptor");
+  std::memset(g, 0, sizeof(*g));
+  if (d->conv) {
+    DFH_REQUIRE(d->stride == 1 || d->stride == 2, "stride must be 1 or 2");
+    DFH_REQUIRE(!(d->upsample && d->stride != 1), "upsample only with stride 1");
+    g->conv_src = (const bf16_t*)d->conv_src; g->conv_c = d->conv_c; g->ntaps = 9;
+    g->Hin = d->Hin; g->Win = d->Win; g->stride = d->stride; g->ups = d->upsample;
+    g->Hout = d->upsample ? d->Hin * 2 : (d->stride == 2 ? d->Hin / 2 : d->Hin);
+    g->Wout = d->upsample ? d->Win * 2 : (d->stride == 2 ? d->Win / 2 : d->Win);
+    DFH_REQUIRE(d->M == d->batch * g->Hout * g->Wout, "M must equal batch * Hout * Wout");
+  }
+  if (d->a0) { g->p_src[g->nplain] = (const bf16_t*)d->a0; g->p_c[g->nplain] = d->a0_c; ++g->nplain; }
+  if (d->a1) { DFH_REQUIRE(d->a0 != nullptr, "a1 without a0"); g->p_src[g->nplain] = (const bf16_t*)d->a1; g->p_c[g->nplain] = d->a1_c; ++g->nplain; }
+  g->W = (const bf16_t*)d->W; g->ldw = d->ldw; g->zero = (const bf16_t*)d->zero_page;
+  g->M = d->M; g->N = d->N;
+  g->bias = d->bias; g->rowvec = d->rowvec; g->rv_ld = d->rv_ld; g->rv_off = d->rv_off;
+  g->rows_per_b = d->rows_per_b > 0 ? d->rows_per_b : d->M;
+  g->resid = (const bf16_t*)d->resid; g->ld_res = d->ld_res;
+  g->act = d->act; g->out = d->out; g->ld_out = d->ld_out; g->out_mode = d->out_mode;
+  g->partial = d->partial;
+  DFH_REQUIRE(g->W && g->out, "null W / out");
+  return 0;
+}
+
+extern "C" {
+
+int dfh_abi_version(void) { return DFH_ABI_VERSION; }
+const char* dfh_last_error(void) { return dfh::g_err.c_str(); }
+const char* dfh_build_info(void) { return "libdifashion_hip gfx950 (CDNA4) bf16-MFMA abi=1"; }
+
+size_t dfh_gemm_partial_floats(const dfh_gemm_desc* d) {
+  GemmArgs g;
+  if (fill_gemm(d, &g)) return 0;
+  if (d->force_split > 1) return (size_t)d->force_split * g.M * g.N;
+  return dfh::gemm_partial_floats(g);
+}
+
+int dfh_gemm(const dfh_gemm_desc* d, void* stream) {
+  GemmArgs g;
+  if (int rc = fill_gemm(d, &g)) return rc;
+  const size_t need = d->force_split > 1 ? (size_t)d->force_split * g.M * g.N : dfh::gemm_partial_floats(g);
+  DFH_REQUIRE(need == 0 || (d->partial && d->partial_floats >= need), "partial buffer too small for split-K");
+  return dfh::gemm_launch(g, (hipStream_t)stream, d->force_tile, d->force_split, d->force_glds);
+}
+
+int dfh_groupnorm(const void* src0, int c0, const void* src1, int c1, int batch, int hw, int groups, const float* gamma,
+                  const float* beta, float eps, int silu, void* out, float* partial, void* stream) {
+  GnArgs a; std::memset(&a, 0, sizeof(a));
+  a.src0 = (const bf16_t*)src0; a.C0 = c0; a.src1 = (const bf16_t*)src1; a.C1 = src1 ? c1 : 0;
+  a.B = batch; a.HW = hw; a.G = groups; a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu;
+  a.out = (bf16_t*)out; a.partial = partial;
+  return dfh::groupnorm_launch(a, (hipStream_t)stream);
+}
+
+int dfh_layernorm(const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps, void* stream) {
+  return dfh::layernorm_launch((const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps, (hipStream_t)stream);
+}
+
+int dfh_attention(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo, int batch,
+                  int heads, int head_dim, int Nq, int Nk, float scale, void* stream) {
+  AttnArgs a; std::memset(&a, 0, sizeof(a));
+  a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.Vt = (const bf16_t*)Vt; a.ldvt = ldvt;
+  a.O = (bf16_t*)O; a.ldo = ldo; a.B = batch; a.H = heads; a.D = head_dim; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+  return dfh::attention_launch(a, (hipStream_t)stream);
+}
+
+int dfh_timestep_embedding(const float* t, void* out, int batch, int dim, void* stream) {
+  return dfh::timestep_embed_launch(t, (bf16_t*)out, batch, dim, (hipStream_t)stream);
+}
+int dfh_nchw_to_nhwc_bf16(const void* x, int x_bf16, void* out, int batch, int C, int HW, void* stream) {
+  return dfh::nchw_to_nhwc_launch(x, x_bf16, (bf16_t*)out, batch, C, HW, (hipStream_t)stream);
+}
+int dfh_cast_f32_to_bf16(const float* x, void* y, size_t n, void* stream) {
+  return dfh::cast_f32_to_bf16_launch(x, (bf16_t*)y, (long)n, (hipStream_t)stream);
+}
+int dfh_pack_conv3x3(const float* w, void* out, int Cout, int Cin, int ldw, int col_off, void* stream) {
+  return dfh::pack_conv3x3_launch(w, (bf16_t*)out, Cout, Cin, ldw, col_off, (hipStream_t)stream);
+}
+int dfh_pack_matrix(const float* w, void* out, int N, int K, int ldw, int row_off, int col_off, int geglu, void* stream) {
+  return dfh::pack_matrix_launch(w, (bf16_t*)out, N, K, ldw, row_off, col_off, geglu, (hipStream_t)stream);
+}
+int dfh_pack_vector(const float* v, float* out, int N, int off, int geglu, int accumulate, void* stream) {
+  return dfh::pack_vector_launch(v, out, N, off, geglu, accumulate, (hipStream_t)stream);
+}
+
+int dfh_mutual_reduce(const float* gen, const float* given, const int32_t* table, const float* wtab, void* out_bf16,
+                      float* out_f32, int rows, int olen, int L, void* stream) {
+  DFH_REQUIRE(gen && table && wtab && out_bf16, "null argument");
+  return dfh::mutual_reduce_launch(gen, given, table, wtab, (bf16_t*)out_bf16, out_f32, rows, olen, L, (hipStream_t)stream);
+}
+int dfh_assemble_input(const float* latents, const float* mutual, const float* hist, const float* null_latent,
+                       const uint8_t* mutual_real, const uint8_t* hist_real, float* x, int R, int F, int CL,
+                       float one_minus_eta, float eta, int per_row_flags, void* stream) {
+  DFH_REQUIRE(latents && mutual && hist && null_latent && mutual_real && hist_real && x, "null argument");
+  return dfh::assemble_input_launch(latents, mutual, hist, null_latent, mutual_real, hist_real, x, R, F, CL, one_minus_eta,
+                                    eta, per_row_flags, (hipStream_t)stream);
+}
+int dfh_cfg_step(const float* eps_all, float* latents, float* eps_out, const float* noise, size_t n, int mode,
+                 float cate_scale, float hist_scale, float mutual_scale, const dfh_step_coef* k, void* stream) {
+  DFH_REQUIRE(eps_all && k, "null argument");
+  DFH_REQUIRE(k->kind == STEP_NONE || latents != nullptr, "latents required for a scheduler step");
+  StepCoef c; c.kind = k->kind; c.vpred = k->vpred; c.sqrt_a_t = k->sqrt_a_t; c.sqrt_b_t = k->sqrt_b_t;
+  c.sqrt_a_prev = k->sqrt_a_prev; c.dir_coef = k->dir_coef; c.std_dev = k->std_dev;
+  return dfh::cfg_step_launch(eps_all, latents, eps_out, noise, (long)n, mode, cate_scale, hist_scale, mutual_scale, c,
+                              (hipStream_t)stream);
+}
+int dfh_noise_mix(const float* x0, const float* noise, const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp,
+                  float* noisy, float* velocity, int rows, int L, void* stream) {
+  return dfh::noise_mix_launch(x0, noise, (const long*)t, sqrt_acp, sqrt_1m_acp, noisy, velocity, rows, L, (hipStream_t)stream);
+}
+int dfh_mse_rows(const float* pred, const float* target, float* out, int rows, int L, void* stream) {
+  return dfh::mse_rows_launch(pred, target, out, rows, L, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,240 @@
+// Fused softmax(Q K^T / sqrt(d)) V for the U-Net's self- and cross-attention on gfx950.
+// Reference call sites: diffusers Attention (attn1 / attn2 of BasicTransformerBlock) reached via
+// DiFashion/models/difashion.py:249-253,518-523; the reference runs it through xformers
+// memory_efficient_attention (difashion.py:118).  SURVEY.md A.3: heads split C, scale d^-0.5,
+// (N, d) = (4096,40) (1024,80) (256,160) (64,160) self; Nk = 77 cross.
+//
+// Structure (DESIGN.md "Kernels/attention"), all 16x16x32 bf16 MFMA, 64-wide waves:
+//   * workgroup = 4 waves = 128 queries of one (batch, head); a wave owns 32 queries (two 16-wide
+//     column tiles) so every K / V^T fragment read from LDS feeds two MFMAs.
+//   * scores are computed TRANSPOSED, S^T = K . Q^T: a lane then holds, for ONE query (lane&15),
+//     4 keys per 16-key tile -> running max / sum are lane-local plus two xor-shuffles (16, 32).
+//   * the K rows of each 16-key tile are chosen as key = (rho>>2)*8 + u*4 + (rho&3), so after two
+//     tiles a lane holds 8 CONSECUTIVE keys = exactly the B fragment of the P.V MFMA: the
+//     probabilities never leave registers (no LDS round trip, no permutes).
+//   * O is accumulated transposed, O^T = V^T . P^T, with V^T read from a [d][key] tile; V^T is
+//     produced directly by the V projection GEMM's transposed epilogue (gemm.hip OUT_BF16_T), so
+//     nothing is transposed here.  The accumulator column is the lane's own query -> the softmax
+//     rescale and the final 1/l need no cross-lane traffic either; output is 8-byte bf16x4 stores.
+//   * LDS tiles are XOR-swizzled on the 16-byte slot so ds_read_b128 fragment reads are
+//     conflict-free; the N x N score matrix never touches HBM.
+#include "dfh_common.h"
+#include "attention.h"
+
+namespace {
+
+constexpr int KV_TILE = 64;
+
+template <int D> struct AttnGeom {
+  static constexpr int KS = (D + 31) / 32;                       // 32-deep k-steps over the head dim
+  static constexpr int DF = (D + 15) / 16;                       // 16-row fragments of O^T
+  static constexpr int KSTR = D <= 64 ? 128 : (D <= 128 ? 256 : 512);  // K tile row stride (bytes)
+  static constexpr int K_BYTES = KV_TILE * KSTR;
+  static constexpr int V_BYTES = DF * 16 * 128;
+};
+
+// rho = position of a key inside its 16-row MFMA tile (see header); swizzle bits derive from it
+DFH_DEVICE int key_rho(int key) { return (((key >> 3) & 3) << 2) | (key & 3); }
+
+template <int D>
+__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
+  using G = AttnGeom<D>;
+  constexpr int KS = G::KS, DF = G::DF, KSTR = G::KSTR;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[G::K_BYTES + G::V_BYTES];
+  unsigned char* Ks = smem;
+  unsigned char* Vs = smem + G::K_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+
+  const bf16_t* Qb = a.Q + (long)b * a.Nq * a.ldq + h * D;
+  const bf16_t* Kb = a.K + (long)b * a.Nk * a.ldk + h * D;
+  const bf16_t* Vb = a.Vt + ((long)b * a.H * D + (long)h * D) * a.ldvt;
+
+  // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q = fr][d = ks*32 + fg*8 ..+8]
+  bf16x8_t qf[2][KS];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = q0 + qt * 16 + fr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = ks * 32 + fg * 8;
+      uint4 v = uint4{0, 0, 0, 0};
+      if (q < a.Nq && d0 < D) v = *(const uint4*)(Qb + (long)q * a.ldq + d0);
+      qf[qt][ks] = __builtin_bit_cast(bf16x8_t, v);
+    }
+  }
+
+  f32x4_t oacc[2][DF];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int f = 0; f < DF; ++f) oacc[qt][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY};
+  float l_run[2] = {0.f, 0.f};
+  const float c = a.scale * 1.44269504088896340736f;   // fold log2(e): p = 2^(s*c - m*c)
+
+  for (int kv0 = 0; kv0 < a.Nk; kv0 += KV_TILE) {
+    __syncthreads();   // every wave finished reading the previous tile
+    // ---- stage K tile: 64 keys x KS*4 16-byte slots (zero beyond D / beyond Nk)
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int idx = tid + i * 256;
+      const int key = idx / (KS * 4), slot = idx - key * (KS * 4);
+      uint4 v = uint4{0, 0, 0, 0};
+      if (kv0 + key < a.Nk && slot * 8 < D) v = *(const uint4*)(Kb + (long)(kv0 + key) * a.ldk + slot * 8);
+      const int rho = key_rho(key);
+      const int sw = (KSTR == 128) ? ((rho >> 1) & 7) : rho;
+      *(uint4*)(Ks + key * KSTR + ((slot ^ sw) << 4)) = v;
+    }
+    // ---- stage V^T tile: DF*16 rows (head-dim) x 8 slots (64 keys)
+#pragma unroll
+    for (int i = 0; i < (DF * 128 + 255) / 256; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < DF * 128) {
+        const int row = idx >> 3, slot = idx & 7;
+        const int k0 = kv0 + slot * 8;
+        uint4 v = uint4{0, 0, 0, 0};
+        if (row < D && k0 < a.Nk) {
+          v = *(const uint4*)(Vb + (long)row * a.ldvt + k0);
+          if (k0 + 8 > a.Nk) {   // ragged tail (cross-attention, Nk = 77): zero the padding keys
+            const int valid = a.Nk - k0;
+            uint32_t* w = (uint32_t*)&v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (e >= valid) w[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+          }
+        }
+        *(uint4*)(Vs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) = v;
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T tiles: 4 x (16 keys) for each of the wave's two query tiles
+    f32x4_t s[2][4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      s[0][tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      s[1][tt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const int key = (tt >> 1) * 32 + (fr >> 2) * 8 + (tt & 1) * 4 + (fr & 3);
+      const int sw = (KSTR == 128) ? ((fr >> 1) & 7) : fr;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t kf = *(const bf16x8_t*)(Ks + key * KSTR + (((ks * 4 + fg) ^ sw) << 4));
+        s[0][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[0][tt], 0, 0, 0);
+        s[1][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[1][tt], 0, 0, 0);
+      }
+    }
+    // lane (fr = query, fg) holds for tile tt, reg r: key kv0 + (tt>>1)*32 + fg*8 + (tt&1)*4 + r
+    const bool ragged = kv0 + KV_TILE > a.Nk;
+    bf16x8_t pf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (ragged) {
+            const int key = kv0 + (tt >> 1) * 32 + fg * 8 + (tt & 1) * 4 + r;
+            if (key >= a.Nk) s[qt][tt][r] = -INFINITY;
+          }
+          mx = fmaxf(mx, s[qt][tt][r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[qt], mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * c);
+      m_run[qt] = m_new;
+      const float mc = m_new * c;
+      float psum = 0.f;
+      float p[4][4];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[tt][r] = __builtin_amdgcn_exp2f(s[qt][tt][r] * c - mc);
+          psum += p[tt][r];
+        }
+      l_run[qt] = l_run[qt] * alpha + psum;
+#pragma unroll
+      for (int f = 0; f < DF; ++f) {
+        oacc[qt][f][0] *= alpha; oacc[qt][f][1] *= alpha; oacc[qt][f][2] *= alpha; oacc[qt][f][3] *= alpha;
+      }
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        uint4 w;
+        w.x = pack2bf(p[2 * ch][0], p[2 * ch][1]);
+        w.y = pack2bf(p[2 * ch][2], p[2 * ch][3]);
+        w.z = pack2bf(p[2 * ch + 1][0], p[2 * ch + 1][1]);
+        w.w = pack2bf(p[2 * ch + 1][2], p[2 * ch + 1][3]);
+        pf[qt][ch] = __builtin_bit_cast(bf16x8_t, w);
+      }
+    }
+    // ---- O^T += V^T . P^T
+#pragma unroll
+    for (int f = 0; f < DF; ++f) {
+      const int row = f * 16 + fr;
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        const bf16x8_t vf = *(const bf16x8_t*)(Vs + row * 128 + (((ch * 4 + fg) ^ ((row >> 1) & 7)) << 4));
+        oacc[0][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0][ch], oacc[0][f], 0, 0, 0);
+        oacc[1][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][ch], oacc[1][f], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise and store: lane holds O[q = fr][d = f*16 + fg*4 + r]
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = l_run[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int q = q0 + qt * 16 + fr;
+    if (q >= a.Nq) continue;
+    bf16_t* orow = a.O + ((long)b * a.Nq + q) * a.ldo + h * D;
+#pragma unroll
+    for (int f = 0; f < DF; ++f) {
+      const int d0 = f * 16 + fg * 4;
+      if (d0 < D) {
+        uint2 o;
+        o.x = pack2bf(oacc[qt][f][0] * inv, oacc[qt][f][1] * inv);
+        o.y = pack2bf(oacc[qt][f][2] * inv, oacc[qt][f][3] * inv);
+        *(uint2*)(orow + d0) = o;
+      }
+    }
+  }
+}
+
+template <int D>
+int launch(const AttnArgs& a, hipStream_t stream) {
+  dim3 grid((a.Nq + 127) / 128, a.H, a.B);
+  hipLaunchKernelGGL(attention_kernel<D>, grid, dim3(256), 0, stream, a);
+  return dfh::check_launch("attention_kernel");
+}
+
+}  // namespace
+
+namespace dfh {
+
+int attention_launch(const AttnArgs& a, hipStream_t stream) {
+  DFH_REQUIRE(a.Nq > 0 && a.Nk > 0 && a.B > 0 && a.H > 0, "empty attention");
+  DFH_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 4 == 0, "leading dims must be 16-byte aligned");
+  DFH_REQUIRE(a.ldvt >= ((a.Nk + 7) / 8) * 8, "V^T rows must be padded to a multiple of 8 keys");
+  switch (a.D) {
+    case 32: return launch<32>(a, stream);
+    case 40: return launch<40>(a, stream);
+    case 64: return launch<64>(a, stream);
+    case 80: return launch<80>(a, stream);
+    case 128: return launch<128>(a, stream);
+    case 160: return launch<160>(a, stream);
+    default: break;
+  }
+  set_error("attention_launch: unsupported head dim " + std::to_string(a.D) + " (have 32,40,64,80,128,160)");
+  return -1;
+}
+
+}  // namespace dfh

@@ -1,0 +1,75 @@
+// Shared device/host helpers for the DiFashion gfx950 kernels.
+// Layout conventions (DESIGN.md "Data layout in HBM"):
+//   activations  : bf16, NHWC == [B][H*W][C] token-major (so convs, 1x1 convs and the
+//                  transformer linears all see the same row-major [M][K] A operand)
+//   GEMM weights : bf16, [N][K] row-major (K contiguous); conv3x3 K index = (ky*3+kx)*Cin + c
+//   bias / temb  : fp32
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define DFH_DEVICE __device__ __forceinline__
+
+DFH_DEVICE float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
+DFH_DEVICE bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+DFH_DEVICE uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+DFH_DEVICE void unpack8(const uint4& v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+DFH_DEVICE uint4 pack8(const float* f) {
+  uint4 v;
+  v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
+  v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+  return v;
+}
+
+DFH_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+DFH_DEVICE float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+DFH_DEVICE float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- host side ------------------------------------------------------------------------------
+#include <string>
+namespace dfh {
+void set_error(const std::string& msg);  // api.cpp
+int check_launch(const char* what);     // returns 0 or negative and records the message
+}  // namespace dfh
+#define DFH_REQUIRE(cond, msg)                                   \
+  do {                                                           \
+    if (!(cond)) {                                               \
+      dfh::set_error(std::string(__func__) + ": " + (msg));      \
+      return -1;                                                 \
+    }                                                            \
+  } while (0)
+
+// Bijective XCD-aware remap of a linear block id (guide T1): consecutive logical tiles land on
+// the same XCD (= same L2), so neighbouring tiles that share an A row panel or a W column panel
+// hit in L2.  Placement only affects speed, never results.
+DFH_DEVICE int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

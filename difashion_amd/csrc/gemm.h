@@ -1,0 +1,48 @@
+// Implicit-GEMM descriptor shared by gemm.hip (device) and the host orchestration.
+//   out[M][N] = epilogue( sum over K-segments of A_seg[M][len] . W[N][seg_off : seg_off+len]^T )
+// K is a concatenation of segments; each is padded (virtually, through a zero page) to a
+// multiple of 64 so that a 64-deep k-step never straddles two segments:
+//   * ntaps == 9 : the nine taps of a 3x3 / pad-1 convolution over ``conv_src`` (NHWC, conv_c
+//                  channels, optional stride 2, optional fused nearest-2x upsample of the input)
+//   * then up to two "plain" segments: row m of p_src[i] ([M][p_c[i]]) -- a linear / 1x1 conv
+//                  operand, the second half of a channel concat, or a resnet's 1x1 shortcut
+//                  accumulated into its conv2.
+#pragma once
+#include <stdint.h>
+#include "dfh_common.h"
+
+enum GemmAct { ACT_NONE = 0, ACT_SILU = 1, ACT_LEAKY = 2, ACT_TANH = 3, ACT_GEGLU = 4 };
+enum GemmOut {
+  OUT_BF16 = 0,    // bf16 [M][ld_out]
+  OUT_BF16_T = 1,  // bf16 transposed per batch: out[b][n][ld_out], m = b*rows_per_b + mm (attention V^T)
+  OUT_F32 = 2,     // fp32 [M][ld_out]
+  OUT_F32_T = 3,   // fp32 transposed per batch (conv_out -> NCHW noise prediction)
+};
+
+struct GemmArgs {
+  // --- K segments
+  const bf16_t* conv_src; int conv_c; int ntaps;
+  int Hin, Win, Hout, Wout, stride, ups;
+  const bf16_t* p_src[2]; int p_c[2]; int nplain;
+  const bf16_t* W; int ldw;
+  const bf16_t* zero;  // >= 16 bytes of zeros in device memory
+  int M, N;
+  int ksteps;      // total 64-deep k-steps over all segments
+  int ksplit;      // grid.z; each z handles a contiguous range of k-steps
+  // --- epilogue:  v = acc + bias[n] + rowvec[m / rows_per_b][rv_off + n];  v = act(v);  v += resid[m][n]
+  const float* bias;
+  const float* rowvec; int rv_ld; int rv_off; int rows_per_b;
+  const bf16_t* resid; int ld_res;
+  int act;
+  void* out; int ld_out; int out_mode;
+  float* partial;  // [ksplit][M][N] fp32 when ksplit > 1
+};
+
+namespace dfh {
+// Picks a tile shape + split-K factor, launches, and (if split) launches the reduce.  ``partial``
+// must hold gemm_partial_floats(...) floats when the heuristic splits.
+int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile = 0, int force_split = 0, int force_glds = -1);
+int gemm_pick_split(const GemmArgs& a, int* tile_out);
+size_t gemm_partial_floats(const GemmArgs& a);
+int gemm_count_ksteps(const GemmArgs& a);
+}  // namespace dfh

@@ -1,0 +1,209 @@
+// GroupNorm(32)(+SiLU) and LayerNorm for NHWC bf16 activations on gfx950.
+// Reference call sites: diffusers ResnetBlock2D norm1/norm2 + SiLU, conv_norm_out, Transformer2DModel.norm
+// (eps 1e-6, no activation) and BasicTransformerBlock norm1/2/3 reached through
+// DiFashion/models/difashion.py:249-253,518-523.
+//
+// HBM-bound kernels (DESIGN.md "Kernels/norm"): every access is a 16-byte bf16x8 vector, each
+// thread owns a fixed channel octet so per-channel scale/shift live in registers, statistics are
+// reduced deterministically (fixed order, no float atomics): per-thread registers -> LDS ->
+// 32 group lanes -> [B][chunk][32][2] partials -> summed in chunk order by the apply kernel.
+// The channel concat of the up-path (torch.cat([h, skip], dim=1)) is fused into the read: an
+// octet below C0/8 comes from src0, the rest from src1.
+#include "dfh_common.h"
+#include "norm.h"
+
+namespace {
+
+struct GnGeom {
+  int C, C0, C1, HW, cpg, C8, PL, chunks, pix_per_chunk;
+};
+
+DFH_DEVICE const uint4* gn_src(const GnArgs& a, int b, int p, int o) {
+  const int o0 = a.C0 >> 3;
+  if (o < o0) return (const uint4*)(a.src0 + ((long)(b * a.HW + p) * a.C0 + o * 8));
+  return (const uint4*)(a.src1 + ((long)(b * a.HW + p) * a.C1 + (o - o0) * 8));
+}
+
+// grid (chunks, B); block = roundup64(C8 * PL) threads; thread -> (pixel lane pl, octet o)
+__global__ void gn_stats_kernel(const GnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [PL][C][2]
+  const int C8 = a.C >> 3;
+  const int tid = threadIdx.x;
+  const int o = tid % C8, pl = tid / C8;
+  const int b = blockIdx.y;
+  const int p_begin = blockIdx.x * a.pix_per_chunk;
+  const int p_end = min(a.HW, p_begin + a.pix_per_chunk);
+  float s[8], q[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s[k] = 0.f; q[k] = 0.f; }
+  if (pl < a.PL) {
+    for (int p = p_begin + pl; p < p_end; p += a.PL) {
+      float f[8];
+      unpack8(*gn_src(a, b, p, o), f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s[k] += f[k]; q[k] += f[k] * f[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      red[((pl * a.C) + o * 8 + k) * 2 + 0] = s[k];
+      red[((pl * a.C) + o * 8 + k) * 2 + 1] = q[k];
+    }
+  }
+  __syncthreads();
+  if (tid < a.G) {
+    const int cpg = a.C / a.G;
+    float ss = 0.f, qq = 0.f;
+    for (int l = 0; l < a.PL; ++l)
+      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+        ss += red[(l * a.C + c) * 2 + 0];
+        qq += red[(l * a.C + c) * 2 + 1];
+      }
+    float* dst = a.partial + (((long)b * gridDim.x + blockIdx.x) * a.G + tid) * 2;
+    dst[0] = ss; dst[1] = qq;
+  }
+}
+
+// grid (achunks, B); same thread mapping; normalise (+SiLU) and write bf16 [B][HW][C]
+__global__ void gn_apply_kernel(const GnArgs a) {
+  __shared__ float mean_s[64], rstd_s[64];
+  const int C8 = a.C >> 3;
+  const int tid = threadIdx.x;
+  const int o = tid % C8, pl = tid / C8;
+  const int b = blockIdx.y;
+  const int cpg = a.C / a.G;
+  if (tid < a.G) {
+    float ss = 0.f, qq = 0.f;
+    for (int c = 0; c < a.chunks; ++c) {
+      const float* src = a.partial + (((long)b * a.chunks + c) * a.G + tid) * 2;
+      ss += src[0]; qq += src[1];
+    }
+    const float n = (float)a.HW * (float)cpg;
+    const float mean = ss / n;
+    const float var = fmaxf(qq / n - mean * mean, 0.f);
+    mean_s[tid] = mean;
+    rstd_s[tid] = rsqrtf(var + a.eps);
+  }
+  __syncthreads();
+  if (pl >= a.PL) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = o * 8 + k;
+    const int g = c / cpg;
+    const float w = a.gamma[c] * rstd_s[g];
+    sc[k] = w;
+    sh[k] = a.beta[c] - mean_s[g] * w;
+  }
+  const int p_begin = blockIdx.x * a.apix_per_chunk;
+  const int p_end = min(a.HW, p_begin + a.apix_per_chunk);
+  for (int p = p_begin + pl; p < p_end; p += a.PL) {
+    float f[8];
+    unpack8(*gn_src(a, b, p, o), f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float y = f[k] * sc[k] + sh[k];
+      f[k] = a.silu ? silu_f(y) : y;
+    }
+    *(uint4*)(a.out + ((long)(b * a.HW + p) * a.C + o * 8)) = pack8(f);
+  }
+}
+
+// one wave per token row; exact two-pass variance in registers (C <= 8*64*MAXO)
+template <int MAXO>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                        int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int C8 = C >> 3;
+  float v[MAXO][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXO; ++i) {
+    const int o = lane + i * 64;
+    if (o < C8) {
+      unpack8(*(const uint4*)(x + (long)row * C + o * 8), v[i]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[i][k];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXO; ++i) {
+    const int o = lane + i * 64;
+    if (o < C8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < MAXO; ++i) {
+    const int o = lane + i * 64;
+    if (o < C8) {
+      float f[8];
+      const float4 g0 = *(const float4*)(gamma + o * 8), g1 = *(const float4*)(gamma + o * 8 + 4);
+      const float4 b0 = *(const float4*)(beta + o * 8), b1 = *(const float4*)(beta + o * 8 + 4);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = (v[i][k] - mean) * rstd * gg[k] + bb[k];
+      *(uint4*)(y + (long)row * C + o * 8) = pack8(f);
+    }
+  }
+}
+
+}  // namespace
+
+namespace dfh {
+
+static void gn_geometry(GnArgs& a, int* block, int* achunks) {
+  const int C8 = a.C / 8;
+  int PL = 256 / C8;
+  if (PL < 1) PL = 1;
+  if (PL > a.HW) PL = a.HW;
+  a.PL = PL;
+  *block = ((C8 * PL + 63) / 64) * 64;
+  // statistics: enough chunks to fill the chip, at most GN_MAX_CHUNKS (partial buffer size)
+  int chunks = (512 + a.B - 1) / a.B;
+  const int max_by_pix = (a.HW + PL - 1) / PL;
+  chunks = std::max(1, std::min({chunks, max_by_pix, (int)GN_MAX_CHUNKS}));
+  a.pix_per_chunk = (a.HW + chunks - 1) / chunks;
+  a.chunks = (a.HW + a.pix_per_chunk - 1) / a.pix_per_chunk;
+  int ac = (2048 + a.B - 1) / a.B;
+  ac = std::max(1, std::min(ac, max_by_pix));
+  a.apix_per_chunk = (a.HW + ac - 1) / ac;
+  *achunks = (a.HW + a.apix_per_chunk - 1) / a.apix_per_chunk;
+}
+
+int groupnorm_launch(GnArgs a, hipStream_t stream) {
+  a.C = a.C0 + a.C1;
+  DFH_REQUIRE(a.C % 8 == 0 && a.C0 % 8 == 0 && a.C1 % 8 == 0, "channels must be multiples of 8");
+  DFH_REQUIRE(a.G > 0 && a.G <= 64 && a.C % a.G == 0, "bad group count");
+  DFH_REQUIRE(a.C / 8 <= 1024, "too many channels");
+  DFH_REQUIRE(a.partial != nullptr && a.out != nullptr && a.src0 != nullptr, "null pointer");
+  DFH_REQUIRE(a.C1 == 0 || a.src1 != nullptr, "second source missing");
+  int block, achunks;
+  gn_geometry(a, &block, &achunks);
+  DFH_REQUIRE(block <= 1024, "block too large");
+  const size_t lds = (size_t)a.PL * a.C * 2 * sizeof(float);
+  DFH_REQUIRE(lds <= 64 * 1024, "GroupNorm LDS reduction too large");
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(a.chunks, a.B), dim3(block), lds, stream, a);
+  if (int rc = check_launch("gn_stats_kernel")) return rc;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(achunks, a.B), dim3(block), 0, stream, a);
+  return check_launch("gn_apply_kernel");
+}
+
+int layernorm_launch(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int M, int C, float eps,
+                     hipStream_t stream) {
+  DFH_REQUIRE(C % 8 == 0 && C <= 8 * 64 * 4, "LayerNorm width must be a multiple of 8 and <= 2048");
+  const dim3 grid((M + 3) / 4), block(256);
+  if (C <= 512) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, stream, x, gamma, beta, y, M, C, eps);
+  else if (C <= 1024) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, x, gamma, beta, y, M, C, eps);
+  else hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, stream, x, gamma, beta, y, M, C, eps);
+  return check_launch("layernorm_kernel");
+}
+
+}  // namespace dfh

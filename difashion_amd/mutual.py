@@ -1,0 +1,96 @@
+"""MutualEncoder (reference: DiFashion/models/difashion.py:21-46) on the HIP GEMM path.
+
+``tanh(W2 . dropout(leaky_relu(W1 . flat(x) + b1)) + b2)`` with W1 (hid, C*S*S), W2 (C*S*S, hid).
+State-dict keys match the reference (``category_embedding.weight`` -- unused in forward, kept so
+checkpoints round-trip -- ``mlp.0.*``, ``mlp.3.*``).  At N = 4 items the layer is a weight-streaming
+GEMV-like problem (16.8 MB of bf16 weights): both linears go through dfh_gemm (split-K for the
+16384-deep first layer), activations fused in the epilogues.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+ACT_LEAKY, ACT_TANH = 2, 3
+OUT_BF16, OUT_F32 = 0, 2
+
+
+class MutualEncoder(nn.Module):
+    def __init__(self, cate_num: int, cate_emb_size: int, latent_channels: int, latent_size: int, hid_dim: int):
+        super().__init__()
+        self.config = dict(cate_num=cate_num, cate_emb_size=cate_emb_size, latent_channels=latent_channels,
+                           latent_size=latent_size, hid_dim=hid_dim)
+        self.category_embedding = nn.Embedding(cate_num, cate_emb_size)  # unused in forward (difashion.py:28)
+        self.latent_channels = latent_channels
+        self.latent_size = latent_size
+        flat = latent_channels * latent_size * latent_size
+        if flat % 8 or hid_dim % 8:
+            raise ValueError("latent and hidden widths must be multiples of 8")
+        self.mlp = nn.Sequential(nn.Linear(flat, hid_dim), nn.LeakyReLU(), nn.Dropout(0.1),
+                                 nn.Linear(hid_dim, flat), nn.Tanh())
+        self._packed = None
+        self._sig = None
+
+    def _pack(self):
+        w1, b1, w2, b2 = self.mlp[0].weight, self.mlp[0].bias, self.mlp[3].weight, self.mlp[3].bias
+        if w1.device.type != "cuda":
+            raise _lib.DfhError("MutualEncoder runs on the HIP path only: move it to 'cuda'")
+        sig = tuple((p.data_ptr(), p._version) for p in (w1, b1, w2, b2))
+        if sig == self._sig:
+            return self._packed
+        dev = w1.device
+        hid, flat = w1.shape
+        p1 = torch.empty((hid, flat), dtype=torch.bfloat16, device=dev)
+        p2 = torch.empty((flat, hid), dtype=torch.bfloat16, device=dev)
+        s = _lib.stream_ptr()
+        _lib.call("dfh_pack_matrix", _lib.ptr(w1.detach().float().contiguous()), _lib.ptr(p1), hid, flat, flat, 0, 0, 0, s)
+        _lib.call("dfh_pack_matrix", _lib.ptr(w2.detach().float().contiguous()), _lib.ptr(p2), flat, hid, hid, 0, 0, 0, s)
+        zero = torch.zeros(256, dtype=torch.uint8, device=dev)
+        self._packed = (p1, p2, b1.detach().float().contiguous(), b2.detach().float().contiguous(), zero)
+        self._sig = sig
+        return self._packed
+
+    def _gemm(self, x, K, W, bias, N, act, out, out_mode, zero, M):
+        d = _lib.GemmDesc()
+        d.a0, d.a0_c = x.data_ptr(), K
+        d.W, d.ldw = W.data_ptr(), K
+        d.M, d.N = M, N
+        d.bias = bias.data_ptr()
+        d.act = act
+        d.out, d.ld_out, d.out_mode = out.data_ptr(), N, out_mode
+        d.zero_page = zero.data_ptr()
+        d.force_glds = -1
+        need = _lib.raw().dfh_gemm_partial_floats(C.byref(d))
+        part = None
+        if need:
+            part = torch.empty(need, dtype=torch.float32, device=out.device)
+            d.partial, d.partial_floats = part.data_ptr(), need
+        _lib.call("dfh_gemm", C.byref(d), _lib.stream_ptr())
+        return part
+
+    def forward_bf16(self, x_bf16: torch.Tensor, dropout_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x_bf16: (N, C*S*S) bf16 rows (the sibling-reduce kernel's output) -> fp32 (N, C, S, S)."""
+        p1, p2, b1, b2, zero = self._pack()
+        n = x_bf16.shape[0]
+        hid, flat = p1.shape
+        h = torch.empty((n, hid), dtype=torch.bfloat16, device=x_bf16.device)
+        keep = [self._gemm(x_bf16, flat, p1, b1, hid, ACT_LEAKY, h, OUT_BF16, zero, n)]
+        if dropout_mask is not None:      # train-mode nn.Dropout(0.1) with a caller-supplied mask
+            h = (h.float() * dropout_mask).to(torch.bfloat16)
+        y = torch.empty((n, flat), dtype=torch.float32, device=x_bf16.device)
+        keep.append(self._gemm(h, hid, p2, b2, flat, ACT_TANH, y, OUT_F32, zero, n))
+        return y.view(n, self.latent_channels, self.latent_size, self.latent_size)
+
+    def forward(self, mutual_emb: torch.Tensor) -> torch.Tensor:
+        bsz = mutual_emb.shape[0]
+        x = mutual_emb.reshape(bsz, -1).float().contiguous()
+        xb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        _lib.call("dfh_cast_f32_to_bf16", _lib.ptr(x), _lib.ptr(xb), x.numel(), _lib.stream_ptr())
+        if self.training:
+            raise NotImplementedError("train-mode dropout needs an explicit mask: use forward_bf16(x, dropout_mask)")
+        return self.forward_bf16(xb)

@@ -1,0 +1,241 @@
+"""Host-side counterparts of the reference's two callers of the U-Net, on explicit tensors:
+
+  * ``sample_outfits``  <- DiFashion.fashion_generation, denoising loop difashion.py:356-577
+  * ``train_forward``   <- DiFashion.forward from the point the latents exist, difashion.py:147-267
+
+VAE / CLIP / tokenizer are out of scope: callers pass what those models would
+have produced (clean latents, null latent, prompt states) and the history rows already selected
+(lookup policy is the caller's).  Every tensor op on the path is a HIP kernel from
+libdifashion_hip.so: sibling reduce, MutualEncoder GEMMs, input assembly with CFG replica stacking,
+the U-Net, guidance combine fused with the scheduler update.  Torch only allocates and indexes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from .mutual import MutualEncoder
+from .schedulers import DDIMScheduler, PNDMScheduler, STEP_NONE
+
+# guidance modes, replica order and which conditions are real per replica (hist, mutual, prompt):
+# fashion_generation difashion.py:309-325 (mode), :388-427 and :494-512 (stacking), :525-566 (combine)
+CFG_NONE, CFG_FULL, CFG_CATE_HIST, CFG_CATE_MUTUAL, CFG_CATE, CFG_HIST, CFG_MUTUAL = range(7)
+_BRANCHES = {
+    "full": (CFG_FULL, [(1, 1, 1), (0, 1, 1), (0, 0, 1), (0, 0, 0)]),
+    "cate_hist": (CFG_CATE_HIST, [(1, 1, 1), (0, 1, 1), (0, 1, 0)]),
+    "cate_mutual": (CFG_CATE_MUTUAL, [(1, 1, 1), (1, 0, 1), (1, 0, 0)]),
+    "cate": (CFG_CATE, [(1, 1, 1), (1, 1, 0)]),
+    "hist_mutual": (CFG_HIST, [(1, 1, 1), (0, 0, 1)]),
+    "hist": (CFG_HIST, [(1, 1, 1), (0, 1, 1)]),
+    "mutual": (CFG_MUTUAL, [(1, 1, 1), (1, 0, 1)]),
+    "none": (CFG_NONE, [(1, 1, 1)]),
+}
+
+
+def guidance_plan(cate_scale: float, hist_scale: float, mutual_scale: float, use_history: bool = True,
+                  use_mutual_guidance: bool = True) -> str:
+    h = use_history and hist_scale > 1.0
+    m = use_mutual_guidance and mutual_scale > 1.0
+    c = cate_scale > 1.0
+    if h and m and c:
+        return "full"
+    if c:
+        return "cate_hist" if h else ("cate_mutual" if m else "cate")
+    if h and m:
+        return "hist_mutual"
+    return "hist" if h else ("mutual" if m else "none")
+
+
+def sampling_tables(olists: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Index/weight tables for dfh_mutual_reduce in sampling (difashion.py:439-450,475-489): for each
+    blank slot (outfit-major order) and each slot k of its outfit: >= 0 -> row of the generated
+    latents, < 0 -> -(row+1) of the given items' clean latents; own slot gets weight 0."""
+    ol = olists.cpu()
+    bsz, olen = ol.shape
+    gen = ol == 0
+    gidx = torch.cumsum(gen.reshape(-1).long(), 0).reshape(bsz, olen) - 1
+    tab, wt = [], []
+    for o in range(bsz):
+        for i in range(olen):
+            if not gen[o, i]:
+                continue
+            tab.append([int(gidx[o, k]) if gen[o, k] else -(o * olen + k + 1) for k in range(olen)])
+            wt.append([0.0 if k == i else 1.0 for k in range(olen)])
+    return torch.tensor(tab, dtype=torch.int32), torch.tensor(wt, dtype=torch.float32)
+
+
+def training_tables(n_items: int, olen: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Training (difashion.py:162-169): row j = mean of the other olen-1 noisy siblings; weights are
+    the reference's ones/sum(ones) = fp32(1/(olen-1)), own slot 0."""
+    w = torch.ones(olen, olen).masked_fill(torch.eye(olen) > 0, 0.0)
+    w = w / torch.sum(w, dim=1)
+    tab = [[(j // olen) * olen + k for k in range(olen)] for j in range(n_items)]
+    wt = [w[j % olen].tolist() for j in range(n_items)]
+    return torch.tensor(tab, dtype=torch.int32), torch.tensor(wt, dtype=torch.float32)
+
+
+def _u8(flags, dev):
+    return torch.tensor(flags, dtype=torch.uint8, device=dev)
+
+
+@torch.no_grad()
+def sample_outfits(unet, fashion_encoder: MutualEncoder, scheduler, *, olists: torch.Tensor,
+                   all_latents: torch.Tensor, init_latents: torch.Tensor, hist_latents: torch.Tensor,
+                   null_latent: torch.Tensor, category_prompts: torch.Tensor, null_prompt: torch.Tensor,
+                   num_inference_steps: int = 50, cate_scale: float = 12.0, hist_scale: float = 4.0,
+                   mutual_scale: float = 5.0, eta: float = 0.1, ddim_eta: float = 0.0,
+                   use_history: bool = True, use_mutual_guidance: bool = True, generator=None,
+                   taps: Optional[dict] = None, callback: Optional[Callable] = None) -> torch.Tensor:
+    """CFG sampler for the F blank slots of ``olists`` (0 = generate).  Returns final latents (F,4,S,S).
+
+    ``all_latents`` (bsz*olen,4,S,S): clean latents of every slot (blank slots unused);
+    ``hist_latents`` (F,4,S,S): history rows selected for the blank slots; ``category_prompts``
+    (F,77,D); ``null_prompt`` (1,77,D).  ``eta`` is the mutual mix weight (args.eta), ``ddim_eta`` the
+    scheduler's stochasticity (fashion_generation's ``eta``)."""
+    dev = init_latents.device
+    if dev.type != "cuda":
+        raise _lib.DfhError("sample_outfits runs on the HIP path only (device tensors required)")
+    mode_name = guidance_plan(cate_scale, hist_scale, mutual_scale, use_history, use_mutual_guidance)
+    mode, br = _BRANCHES[mode_name]
+    R = len(br)
+    F_ = init_latents.shape[0]
+    CL = init_latents[0].numel()
+    S = init_latents.shape[-1]
+    f32 = dict(dtype=torch.float32, device=dev)
+    latents = init_latents.to(**f32).clone().contiguous()
+    all_lat = all_latents.to(**f32).contiguous()
+    hist = hist_latents.to(**f32).contiguous()
+    null_lat = null_latent.to(**f32).contiguous()
+    # prompt stack per replica (constant across steps)
+    null_prompts = null_prompt.to(dev).expand(F_, -1, -1)
+    ehs = torch.cat([category_prompts.to(dev) if b[2] else null_prompts for b in br], dim=0).contiguous()
+    hist_real = _u8([b[0] for b in br], dev)
+    mutual_real = _u8([b[1] if use_mutual_guidance else 0 for b in br], dev)
+    tab, wt = sampling_tables(olists)
+    tab, wt = tab.to(dev), wt.to(dev)
+    olen = olists.shape[1]
+
+    scheduler.set_timesteps(num_inference_steps, device=dev)
+    ts_host = list(scheduler._timesteps_host)
+    is_ddim = isinstance(scheduler, DDIMScheduler)
+    x_in = torch.empty((R * F_, 2 * init_latents.shape[1], S, S), **f32)
+    mutual_bf = torch.empty((F_, CL), dtype=torch.bfloat16, device=dev)
+    eps_comb = torch.empty_like(latents) if (taps is not None or not is_ddim) else None
+    mutual = null_lat.expand(F_, -1, -1, -1).contiguous()     # used only when mutual guidance is off
+    one_minus_eta, eta_f = float(1 - eta), float(eta)
+    sp = _lib.stream_ptr
+    unet_static = getattr(unet, "assume_static_weights", None)
+    if unet_static is not None:
+        unet.pack() if hasattr(unet, "pack") else None
+        unet.assume_static_weights = True
+    try:
+        for i, t in enumerate(ts_host):
+            if use_mutual_guidance:
+                _lib.call("dfh_mutual_reduce", _lib.ptr(latents), _lib.ptr(all_lat), _lib.ptr(tab), _lib.ptr(wt),
+                          _lib.ptr(mutual_bf), None, F_, olen, CL, sp())
+                mutual = fashion_encoder.forward_bf16(mutual_bf)
+            _lib.call("dfh_assemble_input", _lib.ptr(latents), _lib.ptr(mutual), _lib.ptr(hist), _lib.ptr(null_lat),
+                      _lib.ptr(mutual_real), _lib.ptr(hist_real), _lib.ptr(x_in), R, F_, CL, one_minus_eta, eta_f, 0, sp())
+            eps_all = unet(x_in, t, ehs, return_dict=False)[0]
+            if is_ddim:
+                k = scheduler.step_coef(t, ddim_eta)
+                noise = None
+                if ddim_eta > 0:
+                    noise = torch.randn(latents.shape, generator=generator, device=dev, dtype=torch.float32)
+                _lib.call("dfh_cfg_step", _lib.ptr(eps_all), _lib.ptr(latents), _lib.ptr(eps_comb), _lib.ptr(noise),
+                          latents.numel(), mode, float(cate_scale), float(hist_scale), float(mutual_scale),
+                          C.byref(k), sp())
+            else:
+                k = _lib.StepCoef()
+                k.kind = STEP_NONE
+                _lib.call("dfh_cfg_step", _lib.ptr(eps_all), None, _lib.ptr(eps_comb), None, latents.numel(), mode,
+                          float(cate_scale), float(hist_scale), float(mutual_scale), C.byref(k), sp())
+                latents = scheduler.step(eps_comb.clone(), t, latents, return_dict=False)[0]
+            if taps is not None:
+                taps[f"x_in_{i}"] = x_in.clone()
+                taps[f"eps_{i}"] = eps_comb.clone()
+                taps[f"unet_out_{i}"] = eps_all.clone()
+            if callback is not None:
+                callback(i, t, latents)
+    finally:
+        if unet_static is not None:
+            unet.assume_static_weights = unet_static
+    return latents
+
+
+@torch.no_grad()
+def train_forward(unet, fashion_encoder: MutualEncoder, scheduler, *, latents: torch.Tensor, noise: torch.Tensor,
+                  timesteps_outfit: torch.Tensor, null_latent: torch.Tensor, hist_latents: torch.Tensor,
+                  ehs: torch.Tensor, null_prompt: torch.Tensor, random_p: Optional[torch.Tensor],
+                  random_p_cate: Optional[torch.Tensor], olen: int = 4, eta: float = 0.1,
+                  mask_ratio: Optional[float] = 0.2, coupling_mask_ratio: float = 0.3,
+                  cate_mask_ratio: Optional[float] = 0.2, snr_gamma: Optional[float] = None,
+                  use_history: bool = True, use_mutual_guidance: bool = True,
+                  dropout_mask: Optional[torch.Tensor] = None, taps: Optional[dict] = None) -> torch.Tensor:
+    """Forward half of one training step: the loss of DiFashion.forward (difashion.py:147-267).
+
+    ``timesteps_outfit`` (bsz,): the draw of :154; ``random_p`` / ``random_p_cate``: the torch.rand draws
+    of :188 / :236 (masks are derived from them on the host, as plain index bookkeeping);
+    ``hist_latents``: rows chosen at :177-184 before masking.  Backward / optimizer are round-2 work."""
+    dev = latents.device
+    if dev.type != "cuda":
+        raise _lib.DfhError("train_forward runs on the HIP path only (device tensors required)")
+    f32 = dict(dtype=torch.float32, device=dev)
+    n = latents.shape[0]
+    CL = latents[0].numel()
+    S = latents.shape[-1]
+    lat = latents.to(**f32).contiguous()
+    noi = noise.to(**f32).contiguous()
+    t = timesteps_outfit.to(dev).repeat_interleave(olen).long()
+    noisy = scheduler.add_noise(lat, noi, t)
+    null_lat = null_latent.to(**f32).contiguous()
+    sp = _lib.stream_ptr
+    if use_mutual_guidance:
+        tab, wt = training_tables(n, olen)
+        mb = torch.empty((n, CL), dtype=torch.bfloat16, device=dev)
+        _lib.call("dfh_mutual_reduce", _lib.ptr(noisy), None, _lib.ptr(tab.to(dev)), _lib.ptr(wt.to(dev)),
+                  _lib.ptr(mb), None, n, olen, CL, sp())
+        mutual = fashion_encoder.forward_bf16(mb, dropout_mask)
+    else:
+        mutual = null_lat.expand(n, -1, -1, -1).contiguous()
+    # condition dropout (difashion.py:186-213): per-row "is real" flags
+    hist_real = torch.ones(n, dtype=torch.bool, device=dev)
+    mutual_real = torch.ones(n, dtype=torch.bool, device=dev)
+    if mask_ratio is not None:
+        rp = random_p.to(dev)
+        if use_history and use_mutual_guidance:
+            hist_real = ~(rp < mask_ratio + coupling_mask_ratio)
+            mutual_real = ~((rp >= mask_ratio) & (rp < 2 * mask_ratio + coupling_mask_ratio))
+        elif use_history:
+            hist_real = ~(rp < mask_ratio)
+        elif use_mutual_guidance:
+            mutual_real = ~(rp < mask_ratio)
+    x_in = torch.empty((n, 2 * latents.shape[1], S, S), **f32)
+    _lib.call("dfh_assemble_input", _lib.ptr(noisy), _lib.ptr(mutual), _lib.ptr(hist_latents.to(**f32).contiguous()),
+              _lib.ptr(null_lat), _lib.ptr(mutual_real.to(torch.uint8)), _lib.ptr(hist_real.to(torch.uint8)),
+              _lib.ptr(x_in), 1, n, CL, float(1 - eta), float(eta), 1, sp())
+    states = ehs.to(dev).clone()
+    if cate_mask_ratio is not None:
+        states[random_p_cate.to(dev) < cate_mask_ratio] = null_prompt.to(dev)[0]
+    ptype = scheduler.config.prediction_type
+    if ptype == "epsilon":
+        target = noi
+    elif ptype == "v_prediction":
+        target = scheduler.get_velocity(lat, noi, t)
+    else:
+        raise ValueError(f"Unknown prediction type {ptype}")
+    pred = unet(x_in, t, states, return_dict=False)[0]
+    rows = torch.empty(n, **f32)
+    _lib.call("dfh_mse_rows", _lib.ptr(pred.contiguous()), _lib.ptr(target.contiguous()), _lib.ptr(rows), n, CL, sp())
+    if taps is not None:
+        taps.update(x_in=x_in, timesteps=t, ehs=states, target=target, pred=pred)
+    if snr_gamma is None:
+        return rows.mean()
+    ac = scheduler.alphas_cumprod
+    snr = ((ac ** 0.5)[t.cpu()] / ((1.0 - ac) ** 0.5)[t.cpu()]) ** 2
+    w = (torch.minimum(snr, torch.full_like(snr, snr_gamma)) / snr).to(dev)
+    return (rows * w).mean()

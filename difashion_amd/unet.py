@@ -1,0 +1,325 @@
+"""UNet2DConditionModel on the MI355X HIP path, behind the diffusers call signature.
+
+Mirrors what the reference glue requires of ``self.unet``:
+  * ``unet(sample, timestep, encoder_hidden_states[, return_dict])`` -> ``.sample`` / tuple
+    (DiFashion/models/difashion.py:249-253, :518-523); ``timestep`` int, 0-d tensor or (B,) tensor;
+  * ``.config.sample_size`` / ``.config.in_channels`` and ``register_to_config(in_channels=8)`` (:85,:99,:327);
+  * a replaceable ``.conv_in`` nn.Conv2d with ``out_channels/kernel_size/stride/padding/weight`` (:84-93);
+  * ``parameters()/state_dict()/load_state_dict()`` with diffusers key names (train.py:508,545-547,586);
+  * ``save_pretrained(dir)`` / ``from_pretrained(dir, subfolder=)`` (train.py:524,545; difashion.py:77-79);
+  * ``enable_gradient_checkpointing()`` / ``enable_xformers_memory_efficient_attention()`` (train.py:560,
+    difashion.py:118) -- accepted; attention here is always the fused flash-style HIP kernel.
+
+All arithmetic runs in libdifashion_hip.so (include/difashion_hip.h).  The fp32 ``nn.Parameter``s are
+the master weights (optimizers / EMA / checkpoints keep working on them); ``pack()`` converts them to
+the bf16 kernel layouts whenever they change.  There is no PyTorch/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import Dict, Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class UNet2DConditionOutput:
+    def __init__(self, sample: torch.Tensor):
+        self.sample = sample
+
+
+class FrozenDict(dict):
+    """diffusers-style config: attribute and mapping access."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+class _Node(nn.Module):
+    """Bare container used to rebuild the diffusers module tree from dotted parameter names."""
+
+
+_DEFAULT_DOWN = ("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D")
+_DEFAULT_UP = ("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D")
+
+
+class UNet2DConditionModel(nn.Module):
+    config_name = "config.json"
+    weights_name = "diffusion_pytorch_model.safetensors"
+
+    def __init__(self, sample_size: int = 64, in_channels: int = 4, out_channels: int = 4,
+                 down_block_types: Sequence[str] = _DEFAULT_DOWN, up_block_types: Sequence[str] = _DEFAULT_UP,
+                 block_out_channels: Sequence[int] = (320, 640, 1280, 1280), layers_per_block: int = 2,
+                 cross_attention_dim: int = 768, attention_head_dim: Union[int, Sequence[int]] = 8,
+                 use_linear_projection: bool = False, norm_num_groups: int = 32, norm_eps: float = 1e-5,
+                 text_len: int = 77, max_batch: int = 16, init_seed: Optional[int] = 0, init_std: float = 0.02,
+                 **unused):
+        super().__init__()
+        nb = len(block_out_channels)
+        if isinstance(attention_head_dim, int):
+            attention_head_dim = (attention_head_dim,) * nb
+        if nb > _lib.DFH_MAX_BLOCKS:
+            raise ValueError(f"at most {_lib.DFH_MAX_BLOCKS} blocks supported")
+        expected_up = tuple("CrossAttnUpBlock2D" if "CrossAttn" in d else "UpBlock2D" for d in reversed(tuple(down_block_types)))
+        if tuple(up_block_types) != expected_up:
+            raise ValueError("up_block_types must mirror down_block_types")
+        self.config = FrozenDict(
+            sample_size=sample_size, in_channels=in_channels, out_channels=out_channels,
+            down_block_types=tuple(down_block_types), up_block_types=tuple(up_block_types),
+            block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
+            cross_attention_dim=cross_attention_dim, attention_head_dim=tuple(attention_head_dim),
+            use_linear_projection=bool(use_linear_projection), norm_num_groups=norm_num_groups,
+            norm_eps=norm_eps, text_len=text_len)
+        self.max_batch = int(max_batch)
+        self.assume_static_weights = False   # set by the sampler inside its loop: skip the dirty check
+        self._ctx = None
+        self._ctx_key = None
+        self._names = None
+        self._buffers_dev = None
+        self._packed_sig = None
+        # parameter tree straight from the C table (single source of truth for names and shapes)
+        ctx = self._make_ctx()
+        try:
+            table = self._table(ctx)
+        finally:
+            _lib.raw().dfh_unet_destroy(ctx)
+        g = torch.Generator(device="cpu")
+        if init_seed is not None:
+            g.manual_seed(init_seed)
+        self.conv_in = nn.Conv2d(in_channels, block_out_channels[0], 3, 1, 1)
+        for name, shape in table:
+            is_norm = ".norm" in name or name.startswith("conv_norm_out")
+            if name.endswith(".weight") and not is_norm:
+                t = torch.randn(shape, generator=g) * init_std
+            elif name.endswith(".weight"):
+                t = torch.ones(shape)
+            else:
+                t = torch.zeros(shape)
+            if name.startswith("conv_in."):
+                getattr(self.conv_in, name.split(".")[1]).data.copy_(t)
+                continue
+            parts = name.split(".")
+            m = self
+            for p in parts[:-1]:
+                if p not in m._modules:
+                    m.add_module(p, _Node())
+                m = m._modules[p]
+            m.register_parameter(parts[-1], nn.Parameter(t))
+
+    # ------------------------------------------------------------------ config plumbing
+    def register_to_config(self, **kwargs):
+        self.config.update(kwargs)
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return next(self.parameters()).dtype
+
+    def enable_gradient_checkpointing(self):
+        return None
+
+    def enable_xformers_memory_efficient_attention(self, *a, **k):
+        return None
+
+    def _c_config(self) -> _lib.UNetConfigC:
+        cfg = self.config
+        in_ch = self.conv_in.weight.shape[1] if hasattr(self, "conv_in") else cfg["in_channels"]
+        c = _lib.UNetConfigC()
+        c.sample_size = cfg["sample_size"]
+        c.in_channels = int(in_ch)
+        c.out_channels = cfg["out_channels"]
+        c.num_blocks = len(cfg["block_out_channels"])
+        for i, v in enumerate(cfg["block_out_channels"]):
+            c.block_out_channels[i] = v
+            c.num_heads[i] = cfg["attention_head_dim"][i]
+            c.down_attn[i] = 1 if "CrossAttn" in cfg["down_block_types"][i] else 0
+        c.layers_per_block = cfg["layers_per_block"]
+        c.cross_attention_dim = cfg["cross_attention_dim"]
+        c.use_linear_projection = int(cfg["use_linear_projection"])
+        c.norm_num_groups = cfg["norm_num_groups"]
+        c.norm_eps = cfg["norm_eps"]
+        c.text_len = cfg["text_len"]
+        return c
+
+    def _make_ctx(self):
+        c = self._c_config()
+        h = C.c_void_p()
+        _lib.call("dfh_unet_create", C.byref(c), C.byref(h))
+        return h
+
+    @staticmethod
+    def _table(ctx):
+        lib = _lib.raw()
+        out = []
+        for i in range(lib.dfh_unet_num_params(ctx)):
+            name = lib.dfh_unet_param_name(ctx, i).decode()
+            shape = tuple(lib.dfh_unet_param_dim(ctx, i, d) for d in range(lib.dfh_unet_param_ndim(ctx, i)))
+            out.append((name, shape))
+        return out
+
+    def param_table(self):
+        """[(diffusers key, shape)] as the native library enumerates them."""
+        ctx = self._make_ctx()
+        try:
+            return self._table(ctx)
+        finally:
+            _lib.raw().dfh_unet_destroy(ctx)
+
+    def __del__(self):
+        try:
+            if self._ctx is not None:
+                _lib.raw().dfh_unet_destroy(self._ctx)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ device state
+    def _ensure_ctx(self, batch: int):
+        dev = self.device
+        if dev.type != "cuda":
+            raise _lib.DfhError("UNet2DConditionModel runs only on the MI355X HIP path: move it to 'cuda' (no CPU fallback)")
+        if self.dtype != torch.float32:
+            raise _lib.DfhError("master parameters must stay fp32 (the kernels pack their own bf16 copies)")
+        in_ch = int(self.conv_in.weight.shape[1])
+        if tuple(self.conv_in.kernel_size) != (3, 3) or tuple(self.conv_in.padding) != (1, 1) or tuple(self.conv_in.stride) != (1, 1):
+            raise _lib.DfhError("conv_in must be a 3x3 / stride 1 / padding 1 convolution")
+        if batch > self.max_batch:
+            self.max_batch = batch
+        key = (in_ch, self.max_batch, dev.index, tuple(sorted((k, str(v)) for k, v in self.config.items())))
+        if self._ctx is not None and key == self._ctx_key:
+            return
+        if self._ctx is not None:
+            _lib.raw().dfh_unet_destroy(self._ctx)
+            self._ctx = None
+        ctx = self._make_ctx()
+        lib = _lib.raw()
+        table = self._table(ctx)
+        params = dict(self.named_parameters())
+        for name, shape in table:
+            if name not in params or tuple(params[name].shape) != shape:
+                lib.dfh_unet_destroy(ctx)
+                raise _lib.DfhError(f"parameter {name}: expected shape {shape}, module has "
+                                    f"{tuple(params[name].shape) if name in params else None}")
+        a16 = torch.empty(lib.dfh_unet_arena16_bytes(ctx), dtype=torch.uint8, device=dev)
+        a32 = torch.empty(lib.dfh_unet_arena32_bytes(ctx), dtype=torch.uint8, device=dev)
+        wsb = lib.dfh_unet_workspace_bytes(ctx, self.max_batch)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _lib.call("dfh_unet_bind", ctx, _lib.ptr(a16), _lib.ptr(a32), _lib.ptr(ws), wsb, self.max_batch)
+        self._ctx, self._ctx_key = ctx, key
+        self._names = [n for n, _ in table]
+        self._buffers_dev = (a16, a32, ws)
+        self._packed_sig = None
+
+    def _signature(self, params):
+        return tuple((p.data_ptr(), p._version) for p in params)
+
+    def pack(self, force: bool = False):
+        """fp32 master parameters -> bf16 kernel layouts (call happens automatically when they change)."""
+        self._ensure_ctx(1)
+        named = dict(self.named_parameters())
+        plist = [named[n] for n in self._names]
+        sig = self._signature(plist)
+        if not force and sig == self._packed_sig:
+            return
+        arr = (C.c_void_p * len(plist))(*[p.data_ptr() for p in plist])
+        _lib.call("dfh_unet_pack", self._ctx, arr, len(plist), _lib.stream_ptr())
+        self._packed_sig = sig
+
+    def workspace_bytes(self) -> int:
+        return 0 if self._buffers_dev is None else sum(b.numel() for b in self._buffers_dev)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor,
+                return_dict: bool = True, **unused):
+        if sample.dim() != 4:
+            raise ValueError("sample must be (B, C, H, W)")
+        B, Cin, H, W = sample.shape
+        cfg = self.config
+        if H != cfg["sample_size"] or W != cfg["sample_size"]:
+            raise ValueError(f"sample must be {cfg['sample_size']}x{cfg['sample_size']}, got {H}x{W}")
+        if Cin != self.conv_in.weight.shape[1]:
+            raise ValueError(f"sample has {Cin} channels, conv_in expects {self.conv_in.weight.shape[1]}")
+        if tuple(encoder_hidden_states.shape) != (B, cfg["text_len"], cfg["cross_attention_dim"]):
+            raise ValueError(f"encoder_hidden_states must be {(B, cfg['text_len'], cfg['cross_attention_dim'])}, "
+                             f"got {tuple(encoder_hidden_states.shape)}")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in (sample, encoder_hidden_states)):
+            raise NotImplementedError("the HIP U-Net backward is not built yet (round 2): call under torch.no_grad()")
+        self._ensure_ctx(B)
+        if not (self.assume_static_weights and self._packed_sig is not None):
+            self.pack()
+        dev = sample.device
+        # timestep forms of difashion.py:251 ((B,) int64) and :520 (0-d tensor) / python numbers
+        if not torch.is_tensor(timestep):
+            t = torch.full((B,), float(timestep), dtype=torch.float32, device=dev)
+        else:
+            t = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
+            if t.numel() == 1:
+                t = t.expand(B)
+            t = t.contiguous()
+        if t.numel() != B:
+            raise ValueError("timestep must be a scalar or have one entry per batch row")
+        dt = {torch.float32: 0, torch.bfloat16: 1}
+        if sample.dtype not in dt or encoder_hidden_states.dtype not in dt:
+            raise TypeError("sample / encoder_hidden_states must be float32 or bfloat16")
+        sample = sample.contiguous()
+        ehs = encoder_hidden_states.contiguous()
+        out = torch.empty((B, cfg["out_channels"], H, W), dtype=torch.float32, device=dev)
+        _lib.call("dfh_unet_forward", self._ctx, _lib.ptr(sample), dt[sample.dtype], _lib.ptr(t), _lib.ptr(ehs),
+                  dt[ehs.dtype], _lib.ptr(out), B, _lib.stream_ptr())
+        if sample.dtype != torch.float32:
+            out = out.to(sample.dtype)
+        return UNet2DConditionOutput(out) if return_dict else (out,)
+
+    def debug_tap(self, name: str) -> torch.Tensor:
+        """fp32 NCHW copy of a named intermediate of the last forward (parity tests)."""
+        cfg = self.config
+        boc = cfg["block_out_channels"]
+        nb = len(boc)
+        S = cfg["sample_size"]
+        shapes = {"conv_in": (boc[0], S), "mid": (boc[-1], S >> (nb - 1))}
+        for i in range(nb):
+            shapes[f"down{i}"] = (boc[i], S >> min(i + 1, nb - 1))
+            shapes[f"up{i}"] = (boc[nb - 1 - i], S >> max(nb - 2 - i, 0))
+        c, s = shapes[name]
+        B = self._last_batch
+        out = torch.empty((B, c, s, s), dtype=torch.float32, device=self.device)
+        _lib.call("dfh_unet_debug_tap", self._ctx, name.encode(), _lib.ptr(out), out.numel(), _lib.stream_ptr())
+        return out
+
+    def __call__(self, *a, **k):
+        out = super().__call__(*a, **k)
+        self._last_batch = a[0].shape[0] if a else k["sample"].shape[0]
+        return out
+
+    # ------------------------------------------------------------------ checkpoints (diffusers directory layout)
+    def save_pretrained(self, save_directory: str, **unused):
+        from safetensors.torch import save_file
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = dict(self.config)
+        cfg["in_channels"] = int(self.conv_in.weight.shape[1])
+        cfg["_class_name"] = "UNet2DConditionModel"
+        with open(os.path.join(save_directory, self.config_name), "w") as f:
+            json.dump(cfg, f, indent=2)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
+                  os.path.join(save_directory, self.weights_name))
+
+    @classmethod
+    def from_pretrained(cls, path: str, subfolder: Optional[str] = None, **kwargs):
+        from safetensors.torch import load_file
+        d = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(d, cls.config_name)) as f:
+            cfg = json.load(f)
+        cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
+        cfg.update({k: v for k, v in kwargs.items() if k in ("max_batch",)})
+        model = cls(init_seed=None, **cfg)
+        model.load_state_dict(load_file(os.path.join(d, cls.weights_name)))
+        return model

@@ -1,0 +1,158 @@
+/* libdifashion_hip.so -- C ABI of the MI355X (gfx950) DiFashion denoising path.
+ *
+ * The reference has no C ABI / FFI: its boundary is Python duck-typing on two objects held by
+ * DiFashion (``self.unet``, ``self.noise_scheduler``).  This header is what the
+ * Python host side (difashion_amd/, mirroring the diffusers call signatures) binds through ctypes;
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.  Every entry point
+ * names the reference interface it replaces (DiFashion/models/difashion.py = "df.py"; diffusers
+ * 0.18.2 classes are external, pinned by the reference README.md:27).
+ *
+ * Conventions: plain pointers and sizes only (no torch types); all pointers are DEVICE pointers
+ * unless marked host; ``stream`` is a hipStream_t passed as void*; every function returns 0 on
+ * success or a negative status, with the message available from dfh_last_error(); nothing
+ * throws; nothing allocates device memory (callers own arenas / workspaces); a context is
+ * re-entrant per instance and not thread-safe when shared.
+ *
+ * dtypes: "bf16" = raw uint16 bfloat16 bits.  Activations inside the library are NHWC bf16; the
+ * public tensors keep the reference's layouts (NCHW latents, [B][77][D] text states).
+ */
+#ifndef DIFASHION_HIP_H
+#define DIFASHION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFH_ABI_VERSION 1
+#define DFH_MAX_BLOCKS 4
+
+/* ------------------------------------------------------------------ library */
+int dfh_abi_version(void);
+const char* dfh_last_error(void);          /* message of the last failing call on this thread */
+const char* dfh_build_info(void);          /* "gfx950 ..." */
+
+/* ------------------------------------------------------------------ U-Net context
+ * Replaces: diffusers UNet2DConditionModel as constructed at df.py:77-93 (in_channels widened to
+ * 8) and called at df.py:249-253 (training) and df.py:518-523 (sampling). */
+typedef struct dfh_unet_config {
+  int sample_size;                  /* latent H = W (64) */
+  int in_channels;                  /* 8: [latent | history latent], df.py:83-85 */
+  int out_channels;                 /* 4 */
+  int num_blocks;                   /* 4 */
+  int block_out_channels[DFH_MAX_BLOCKS]; /* 320,640,1280,1280 */
+  int layers_per_block;             /* 2 */
+  int cross_attention_dim;          /* 768 (SD-1.5) / 1024 (SD-2) */
+  int num_heads[DFH_MAX_BLOCKS];    /* diffusers "attention_head_dim": 8,8,8,8 / 5,10,20,20 */
+  int down_attn[DFH_MAX_BLOCKS];    /* 1,1,1,0 */
+  int use_linear_projection;        /* only changes parameter shapes (1x1 conv == linear in NHWC) */
+  int norm_num_groups;              /* 32 */
+  float norm_eps;                   /* 1e-5 */
+  int text_len;                     /* 77 */
+} dfh_unet_config;
+
+typedef struct dfh_unet dfh_unet;
+
+int dfh_unet_create(const dfh_unet_config* cfg, dfh_unet** out);   /* host-only work */
+void dfh_unet_destroy(dfh_unet* u);
+
+/* Parameter table, in diffusers state-dict order/names: the single source of truth
+ * the Python module builds its nn.Parameters from (checkpoint drop-in, df.py:77-79, train.py:524-547). */
+int dfh_unet_num_params(const dfh_unet* u);
+const char* dfh_unet_param_name(const dfh_unet* u, int i);
+int dfh_unet_param_ndim(const dfh_unet* u, int i);
+int dfh_unet_param_dim(const dfh_unet* u, int i, int d);
+
+/* Packed-weight arenas (bf16 GEMM operands in kernel layout, fp32 vectors) and activation workspace.
+ * Sizes are bytes; buffers are caller-allocated device memory, 256-byte aligned. */
+size_t dfh_unet_arena16_bytes(const dfh_unet* u);
+size_t dfh_unet_arena32_bytes(const dfh_unet* u);
+size_t dfh_unet_workspace_bytes(dfh_unet* u, int batch);
+int dfh_unet_bind(dfh_unet* u, void* arena16, void* arena32, void* workspace, size_t workspace_bytes, int max_batch);
+
+/* fp32 master parameters (device pointers, table order) -> packed arenas.  Call after every
+ * weight update (optimizer step / load_state_dict). */
+int dfh_unet_pack(dfh_unet* u, const float* const* master_params, int count, void* stream);
+
+/* noise_pred = unet(sample, timestep, encoder_hidden_states).sample
+ *   sample   : [B][in_channels][H][W]  fp32 (sample_bf16=0) or bf16 (1), NCHW as in df.py:216/:515
+ *   timestep : [B] fp32 (the host side expands the 0-d / int / (B,) forms, df.py:251,:520)
+ *   ehs      : [B][text_len][cross_attention_dim] fp32 (ehs_bf16=0) or bf16 (1)
+ *   out      : [B][out_channels][H][W] fp32, NCHW */
+int dfh_unet_forward(dfh_unet* u, const void* sample, int sample_bf16, const float* timestep,
+                     const void* ehs, int ehs_bf16, float* out, int batch, void* stream);
+
+/* Copies a named NHWC bf16 intermediate of the LAST forward into ``dst`` as fp32 NCHW (layer-level
+ * parity tests).  Names: "conv_in", "down0".."down3", "mid", "up0".."up3". */
+int dfh_unet_debug_tap(dfh_unet* u, const char* name, float* dst, size_t dst_floats, void* stream);
+
+/* ------------------------------------------------------------------ op-level entry points (tests, profiling)
+ * ResnetBlock2D conv3x3 / Downsample2D / Upsample2D / 1x1 conv / Linear, as one implicit GEMM:
+ *   out[M][N] = act( conv3x3(x) (+ a0 . W[:, k0:] + a1 . W[:, k1:]) + bias + rowvec[b] ) + resid */
+typedef struct dfh_gemm_desc {
+  const void* conv_src; int conv_c; int conv;   /* conv != 0: 3x3 pad 1 over NHWC bf16 [B][Hin][Win][conv_c] */
+  int batch, Hin, Win, stride, upsample;        /* stride 1|2; upsample: nearest 2x before the conv */
+  const void* a0; int a0_c; const void* a1; int a1_c; /* plain K segments, rows [M][c] bf16 */
+  const void* W; int ldw;                       /* bf16 [N][ldw], K-contiguous, segments in the order above */
+  int M, N;
+  const float* bias;                            /* [N] or NULL */
+  const float* rowvec; int rv_ld, rv_off, rows_per_b;  /* + rowvec[m / rows_per_b][rv_off + n] (time embedding) */
+  const void* resid; int ld_res;                /* + resid[m][n] bf16 */
+  int act;                                      /* 0 none 1 silu 2 leaky_relu(0.01) 3 tanh 4 GEGLU (W/bias pre-interleaved) */
+  void* out; int ld_out; int out_mode;          /* 0 bf16 [M][ld] 1 bf16 [b][N][ld] 2 fp32 [M][ld] 3 fp32 [b][N][ld] */
+  float* partial; size_t partial_floats;        /* split-K slabs (dfh_gemm_partial_floats) */
+  const void* zero_page;                        /* >= 256 zero bytes */
+  int force_tile, force_split, force_glds;      /* 0,0,-1 = heuristics */
+} dfh_gemm_desc;
+size_t dfh_gemm_partial_floats(const dfh_gemm_desc* d);
+int dfh_gemm(const dfh_gemm_desc* d, void* stream);
+
+/* GroupNorm(32, C, eps)(+SiLU) over NHWC bf16, optional fused channel concat of two sources
+ * (ResnetBlock2D.norm1/norm2, conv_norm_out, Transformer2DModel.norm).  partial: >= B*64*G*2 floats */
+int dfh_groupnorm(const void* src0, int c0, const void* src1, int c1, int batch, int hw, int groups,
+                  const float* gamma, const float* beta, float eps, int silu, void* out, float* partial, void* stream);
+/* LayerNorm over the last dim of [M][C] bf16 (BasicTransformerBlock.norm1/2/3) */
+int dfh_layernorm(const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps, void* stream);
+/* softmax(Q K^T * scale) V; Q [B][Nq][ldq], K [B][Nk][ldk], Vt [B][H*D][ldvt] (V transposed), O [B][Nq][ldo]; bf16 */
+int dfh_attention(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
+                  int batch, int heads, int head_dim, int Nq, int Nk, float scale, void* stream);
+/* Timesteps(flip_sin_to_cos=True, freq_shift=0): t [B] fp32 -> [B][dim] bf16 */
+int dfh_timestep_embedding(const float* t, void* out, int batch, int dim, void* stream);
+int dfh_nchw_to_nhwc_bf16(const void* x, int x_bf16, void* out, int batch, int C, int HW, void* stream);
+int dfh_cast_f32_to_bf16(const float* x, void* y, size_t n, void* stream);
+
+/* weight packing (fp32 master -> bf16 kernel layout) */
+int dfh_pack_conv3x3(const float* w_oihw, void* out, int Cout, int Cin, int ldw, int col_off, void* stream);
+int dfh_pack_matrix(const float* w, void* out, int N, int K, int ldw, int row_off, int col_off, int geglu, void* stream);
+int dfh_pack_vector(const float* v, float* out, int N, int off, int geglu, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ DiFashion glue (reference-owned arithmetic)
+ * Sibling reduce feeding MutualEncoder: df.py:160-170 (training mean) / df.py:475-489 (sampling sum).
+ *   out[j] = sum_k wtab[j][k] * (table[j][k] >= 0 ? gen[table] : given[-(table+1)])   (slot order)
+ *   gen/given: fp32 rows of L = 4*H*W; out bf16 [rows][L] (MLP operand), out_f32 optional. */
+int dfh_mutual_reduce(const float* gen, const float* given, const int32_t* table, const float* wtab,
+                      void* out_bf16, float* out_f32, int rows, int olen, int L, void* stream);
+/* Input assembly df.py:215-216 / :514-515 incl. CFG replica stacking: x [R*F][8][H][W] fp32 NCHW */
+int dfh_assemble_input(const float* latents, const float* mutual, const float* hist, const float* null_latent,
+                       const uint8_t* mutual_real, const uint8_t* hist_real, float* x, int R, int F, int CL,
+                       float one_minus_eta, float eta, int per_row_flags, void* stream);
+/* Guidance combine df.py:525-566 fused with scheduler.step df.py:569 (DDIMScheduler.step / PNDM transfer) */
+typedef struct dfh_step_coef {
+  int kind;            /* -1 combine only, 0 DDIM, 1 linear (x' = a*x - b*eps) */
+  int vpred;
+  float sqrt_a_t, sqrt_b_t, sqrt_a_prev, dir_coef, std_dev;
+} dfh_step_coef;
+int dfh_cfg_step(const float* eps_all, float* latents, float* eps_out, const float* noise, size_t n, int mode,
+                 float cate_scale, float hist_scale, float mutual_scale, const dfh_step_coef* k, void* stream);
+/* DDIMScheduler.add_noise / get_velocity df.py:158,:244 */
+int dfh_noise_mix(const float* x0, const float* noise, const int64_t* t, const float* sqrt_acp, const float* sqrt_1m_acp,
+                  float* noisy, float* velocity, int rows, int L, void* stream);
+/* per-row MSE of df.py:256-264 (fp32) */
+int dfh_mse_rows(const float* pred, const float* target, float* out, int rows, int L, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFASHION_HIP_H */

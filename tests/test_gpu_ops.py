@@ -1,0 +1,356 @@
+"""-m gpu: op-level parity of the HIP kernels, called through the C ABI, against torch fp32
+references on identical (bf16-rounded) operands.  Tolerances are stated per test."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from difashion_amd import _lib
+from oracle import glue_ref, sched_ref, unet_ref
+from tests import gpu_util as gu
+from tests.gpu_util import DEV, bf, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+# ----------------------------------------------------------------------------- GEMM (linear / 1x1 conv)
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("glds", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (128, 160, 64), (77 * 3, 64, 768), (16, 1280, 200), (4, 256, 2048)])
+def test_gemm_plain(tile, glds, M, N, K):
+    a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05))
+    bias = rnd(N, seed=3)
+    res = bf(rnd(M, N, seed=4))
+    out = gu.gemm(M=M, N=N, W=w, ldw=K, a0=a, a0_c=K, bias=bias, resid=res, force_tile=tile, force_glds=glds)
+    ref = a.float() @ w.float().T + bias + res.float()
+    gu.assert_close_bf16(out, ref, f"gemm {M}x{N}x{K} tile{tile} glds{glds}")
+
+
+@pytest.mark.parametrize("split", [2, 5])
+def test_gemm_splitk_matches_single_pass(split):
+    M, N, K = 200, 320, 1280
+    a, w = bf(rnd(M, K, seed=5)), bf(rnd(N, K, seed=6, scale=0.05))
+    bias = rnd(N, seed=7)
+    ref = a.float() @ w.float().T + bias
+    out = gu.gemm(M=M, N=N, W=w, ldw=K, a0=a, a0_c=K, bias=bias, force_split=split)
+    gu.assert_close_bf16(out, ref, f"split{split}")
+    out32 = gu.gemm(M=M, N=N, W=w, ldw=K, a0=a, a0_c=K, bias=bias, force_split=split, out_mode=2)
+    assert gu.rel_err(out32, ref) < 2e-5      # fp32 output: only accumulation order differs
+
+
+def test_gemm_two_sources_is_channel_concat():
+    """K segments = torch.cat([h, skip], dim=1) feeding a 1x1 conv (up-path resnet shortcut)."""
+    M, N, C0, C1 = 256, 160, 192, 96
+    a0, a1 = bf(rnd(M, C0, seed=8)), bf(rnd(M, C1, seed=9))
+    w = bf(rnd(N, C0 + C1, seed=10, scale=0.05))
+    out = gu.gemm(M=M, N=N, W=w, ldw=C0 + C1, a0=a0, a0_c=C0, a1=a1, a1_c=C1)
+    ref = torch.cat([a0, a1], 1).float() @ w.float().T
+    gu.assert_close_bf16(out, ref, "concat")
+
+
+@pytest.mark.parametrize("act,fn", [(1, F.silu), (2, lambda x: F.leaky_relu(x, 0.01)), (3, torch.tanh)])
+def test_gemm_activations_and_rowvec(act, fn):
+    B, rows, N, K = 3, 40, 128, 96
+    M = B * rows
+    a, w = bf(rnd(M, K, seed=11)), bf(rnd(N, K, seed=12, scale=0.1))
+    bias = rnd(N, seed=13)
+    rv = rnd(B, 3 * N, seed=14)
+    out = gu.gemm(M=M, N=N, W=w, ldw=K, a0=a, a0_c=K, bias=bias, rowvec=rv, rv_ld=3 * N, rv_off=N, rows_per_b=rows, act=act)
+    ref = fn(a.float() @ w.float().T + bias + rv[:, N:2 * N].repeat_interleave(rows, 0))
+    gu.assert_close_bf16(out, ref, f"act{act}")
+
+
+def test_gemm_geglu_epilogue():
+    """FeedForward GEGLU: proj -> chunk(2) -> a * gelu(gate); weights/bias interleaved by dfh_pack_*."""
+    M, C = 200, 64
+    x = bf(rnd(M, C, seed=15))
+    w = rnd(8 * C, C, seed=16, scale=0.1)
+    b = rnd(8 * C, seed=17, scale=0.5)
+    wp = torch.empty((8 * C, C), dtype=torch.bfloat16, device=DEV)
+    bp = torch.empty(8 * C, dtype=torch.float32, device=DEV)
+    _lib.call("dfh_pack_matrix", _lib.ptr(w), _lib.ptr(wp), 8 * C, C, C, 0, 0, 1, gu.stream())
+    _lib.call("dfh_pack_vector", _lib.ptr(b), _lib.ptr(bp), 8 * C, 0, 1, 0, gu.stream())
+    out = gu.gemm(M=M, N=8 * C, W=wp, ldw=C, a0=x, a0_c=C, bias=bp, act=4)
+    h = x.float() @ bf(w).float().T + b
+    a, gate = h.chunk(2, -1)
+    gu.assert_close_bf16(out, a * F.gelu(gate), "geglu")
+
+
+def test_gemm_transposed_outputs():
+    """OUT_BF16_T feeds attention's V^T (ragged 77 keys padded to 80); OUT_F32_T is conv_out's NCHW."""
+    B, T, N, K = 3, 77, 64, 128
+    a, w = bf(rnd(B * T, K, seed=18)), bf(rnd(N, K, seed=19, scale=0.1))
+    out = torch.zeros((B, N, 80), dtype=torch.bfloat16, device=DEV)
+    gu.gemm(M=B * T, N=N, W=w, ldw=K, a0=a, a0_c=K, out=out, ld_out=80, out_mode=1, rows_per_b=T)
+    ref = (a.float() @ w.float().T).view(B, T, N).transpose(1, 2)
+    gu.assert_close_bf16(out[:, :, :T], ref, "bf16_T")
+    assert float(out[:, :, T:].abs().max()) == 0.0
+    out32 = torch.zeros((B, N, T), dtype=torch.float32, device=DEV)
+    gu.gemm(M=B * T, N=N, W=w, ldw=K, a0=a, a0_c=K, out=out32, ld_out=T, out_mode=3, rows_per_b=T)
+    assert gu.rel_err(out32, ref) < 2e-5
+
+
+# ----------------------------------------------------------------------------- conv3x3 as implicit GEMM
+@pytest.mark.parametrize("cin,cout,H,stride,ups", [
+    (64, 160, 16, 1, 0), (32, 64, 8, 1, 0), (320, 320, 16, 1, 0), (64, 64, 16, 2, 0), (64, 128, 8, 1, 1),
+    (8, 64, 16, 1, 0),      # conv_in shape class (8 input channels, difashion.py:83-93)
+    (64, 4, 16, 1, 0),      # conv_out shape class
+    (128, 128, 2, 1, 0),    # 2x2 level of the tiny configs: every tap hits padding somewhere
+])
+@pytest.mark.parametrize("glds", [1, 0])
+def test_conv3x3(cin, cout, H, stride, ups, glds):
+    B = 2
+    x = bf(rnd(B, cin, H, H, seed=20))
+    w = rnd(cout, cin, 3, 3, seed=21, scale=0.05)
+    bias = rnd(cout, seed=22)
+    Ho = H * 2 if ups else H // stride
+    out = gu.gemm(M=B * Ho * Ho, N=cout, W=gu.pack_conv(w), ldw=9 * cin, conv_src=gu.nhwc(x), conv_c=cin, batch=B,
+                  Hin=H, Win=H, stride=stride, upsample=ups, bias=bias, force_glds=glds)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, bf(w).float(), bias, stride=stride, padding=1)
+    gu.assert_close_bf16(gu.nchw(out.view(B, Ho, Ho, cout)), ref, f"conv {cin}->{cout}@{H} s{stride} u{ups}")
+
+
+def test_conv3x3_with_fused_shortcut_and_temb():
+    """ResnetBlock2D tail: conv2(h) + conv_shortcut(cat(x, skip)) + biases, and conv1 + time embedding."""
+    B, H, c0, c1, cout = 2, 8, 64, 32, 96
+    h = bf(rnd(B, cout, H, H, seed=23))
+    x0, x1 = bf(rnd(B, c0, H, H, seed=24)), bf(rnd(B, c1, H, H, seed=25))
+    w2 = rnd(cout, cout, 3, 3, seed=26, scale=0.05)
+    ws = rnd(cout, c0 + c1, 1, 1, seed=27, scale=0.1)
+    b2, bs = rnd(cout, seed=28), rnd(cout, seed=29)
+    K = 9 * cout + c0 + c1
+    W = torch.empty((cout, K), dtype=torch.bfloat16, device=DEV)
+    _lib.call("dfh_pack_conv3x3", _lib.ptr(w2), _lib.ptr(W), cout, cout, K, 0, gu.stream())
+    _lib.call("dfh_pack_matrix", _lib.ptr(ws.reshape(cout, -1).contiguous()), _lib.ptr(W), cout, c0 + c1, K, 0, 9 * cout, 0, gu.stream())
+    bias = torch.empty(cout, device=DEV)
+    _lib.call("dfh_pack_vector", _lib.ptr(b2), _lib.ptr(bias), cout, 0, 0, 0, gu.stream())
+    _lib.call("dfh_pack_vector", _lib.ptr(bs), _lib.ptr(bias), cout, 0, 0, 1, gu.stream())
+    M = B * H * H
+    out = gu.gemm(M=M, N=cout, W=W, ldw=K, conv_src=gu.nhwc(h), conv_c=cout, batch=B, Hin=H, Win=H,
+                  a0=gu.nhwc(x0).view(M, c0), a0_c=c0, a1=gu.nhwc(x1).view(M, c1), a1_c=c1, bias=bias)
+    ref = F.conv2d(h.float(), bf(w2).float(), b2, padding=1) + F.conv2d(torch.cat([x0, x1], 1).float(), bf(ws).float(), bs)
+    gu.assert_close_bf16(gu.nchw(out.view(B, H, H, cout)), ref, "conv2+shortcut")
+    temb = rnd(B, 2 * cout, seed=30)
+    out = gu.gemm(M=M, N=cout, W=gu.pack_conv(w2), ldw=9 * cout, conv_src=gu.nhwc(h), conv_c=cout, batch=B, Hin=H, Win=H,
+                  bias=b2, rowvec=temb, rv_ld=2 * cout, rv_off=cout, rows_per_b=H * H)
+    ref = F.conv2d(h.float(), bf(w2).float(), b2, padding=1) + temb[:, cout:, None, None]
+    gu.assert_close_bf16(gu.nchw(out.view(B, H, H, cout)), ref, "conv1+temb")
+
+
+# ----------------------------------------------------------------------------- normalisation
+@pytest.mark.parametrize("C0,C1,HW,silu,eps", [(320, 0, 256, 1, 1e-5), (640, 320, 64, 1, 1e-5), (1280, 1280, 16, 1, 1e-5),
+                                               (64, 0, 4, 0, 1e-6), (32, 32, 256, 1, 1e-5), (1280, 640, 64, 0, 1e-6)])
+def test_groupnorm_silu(C0, C1, HW, silu, eps):
+    B, G = 3, 32
+    C = C0 + C1
+    H = int(math.isqrt(HW))
+    x0 = bf(rnd(B, C0, H, H, seed=31) * 2 + 0.7)
+    x1 = bf(rnd(B, C1, H, H, seed=32) - 0.4) if C1 else None
+    gamma, beta = rnd(C, seed=33) * 0.3 + 1, rnd(C, seed=34) * 0.2
+    out = torch.empty((B, HW, C), dtype=torch.bfloat16, device=DEV)
+    part = torch.empty(B * 64 * G * 2, device=DEV)
+    _lib.call("dfh_groupnorm", _lib.ptr(gu.nhwc(x0)), C0, _lib.ptr(gu.nhwc(x1)) if C1 else None, C1, B, HW, G,
+              _lib.ptr(gamma), _lib.ptr(beta), eps, silu, _lib.ptr(out), _lib.ptr(part), gu.stream())
+    torch.cuda.synchronize()
+    xin = torch.cat([x0, x1], 1).float() if C1 else x0.float()
+    ref = F.group_norm(xin, G, gamma, beta, eps)
+    ref = F.silu(ref) if silu else ref
+    gu.assert_close_bf16(gu.nchw(out.view(B, H, H, C)), ref, f"groupnorm C={C} HW={HW}", rel=5e-3, max_rel=2e-2)
+
+
+@pytest.mark.parametrize("M,C", [(300, 320), (64, 1280), (37, 32), (128, 640)])
+def test_layernorm(M, C):
+    x = bf(rnd(M, C, seed=35) * 3 + 1.5)
+    gamma, beta = rnd(C, seed=36) * 0.3 + 1, rnd(C, seed=37) * 0.2
+    y = torch.empty_like(x)
+    _lib.call("dfh_layernorm", _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), M, C, 1e-5, gu.stream())
+    torch.cuda.synchronize()
+    gu.assert_close_bf16(y, F.layer_norm(x.float(), (C,), gamma, beta, 1e-5), "layernorm", rel=5e-3, max_rel=2e-2)
+
+
+# ----------------------------------------------------------------------------- attention
+def _attention(q, k, v, heads):
+    """q [B][Nq][C], k/v [B][Nk][C] bf16 -> O via the HIP kernel (V handed over transposed + padded)."""
+    B, Nq, Cc = q.shape
+    Nk = k.shape[1]
+    ld = (Nk + 7) // 8 * 8
+    vt = torch.full((B, Cc, ld), float("nan"), dtype=torch.bfloat16, device=DEV)   # padding must be ignored
+    vt[:, :, :Nk] = v.transpose(1, 2)
+    o = torch.empty_like(q)
+    d = Cc // heads
+    _lib.call("dfh_attention", _lib.ptr(q), Cc, _lib.ptr(k), Cc, _lib.ptr(vt), ld, _lib.ptr(o), Cc, B, heads, d, Nq, Nk,
+              d ** -0.5, gu.stream())
+    torch.cuda.synchronize()
+    return o
+
+
+@pytest.mark.parametrize("d,heads", [(40, 8), (80, 8), (160, 8), (32, 2), (64, 5), (128, 2)])
+@pytest.mark.parametrize("Nq,Nk", [(256, 256), (64, 64), (200, 77), (4, 4), (1024, 1024)])
+def test_attention(d, heads, Nq, Nk):
+    B, Cc = 2, d * heads
+    q, k, v = bf(rnd(B, Nq, Cc, seed=40)), bf(rnd(B, Nk, Cc, seed=41)), bf(rnd(B, Nk, Cc, seed=42))
+    o = _attention(q, k, v, heads)
+    qh, kh, vh = (t.float().view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Nq, Cc)
+    # P is rounded to bf16 before the PV MFMA: rel error budget ~2^-8 on top of the output rounding
+    gu.assert_close_bf16(o, ref, f"attention d={d} {Nq}x{Nk}", rel=1e-2, max_rel=4e-2)
+
+
+def test_attention_online_softmax_rescale_is_exercised():
+    """A late key tile carries a much larger score than the first: the running max must jump and the
+    accumulated O / l be rescaled (guide rule 26: force the rare branch)."""
+    B, heads, d, N = 1, 1, 64, 256
+    q, k, v = bf(rnd(B, N, d, seed=43)), bf(rnd(B, N, d, seed=44)), bf(rnd(B, N, d, seed=45))
+    k[:, 200] = q[:, 7] * 6.0      # spike: key 200 (4th tile) aligned with query 7
+    o = _attention(q, k, v, heads)
+    ref = F.scaled_dot_product_attention(q.float()[:, None], k.float()[:, None], v.float()[:, None])[:, 0]
+    gu.assert_close_bf16(o, ref, "rescale", rel=1e-2, max_rel=4e-2)
+
+
+# ----------------------------------------------------------------------------- small kernels
+def test_timestep_embedding():
+    t = torch.tensor([0.0, 1.0, 481.0, 999.0], device=DEV)
+    out = torch.empty((4, 320), dtype=torch.bfloat16, device=DEV)
+    _lib.call("dfh_timestep_embedding", _lib.ptr(t), _lib.ptr(out), 4, 320, gu.stream())
+    torch.cuda.synchronize()
+    ref = unet_ref.timestep_embedding(t.cpu(), 320)
+    assert gu.max_err(out.cpu(), ref) <= 2 ** -8     # bf16 rounding of values in [-1, 1]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_nchw_to_nhwc(dtype):
+    x = rnd(3, 8, 16, 16, seed=50).to(dtype)
+    out = torch.empty((3, 256, 8), dtype=torch.bfloat16, device=DEV)
+    _lib.call("dfh_nchw_to_nhwc_bf16", _lib.ptr(x), int(dtype == torch.bfloat16), _lib.ptr(out), 3, 8, 256, gu.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(3, 16, 16, 8), gu.nhwc(bf(x)))
+
+
+def test_weight_packers_are_exact():
+    w = rnd(24, 16, 3, 3, seed=51)
+    assert torch.equal(gu.pack_conv(w), bf(w.permute(0, 2, 3, 1).reshape(24, -1)))
+
+
+# ----------------------------------------------------------------------------- DiFashion glue kernels (bit-exact fp32)
+def test_mutual_reduce_sampling_and_training_bit_exact():
+    from difashion_amd.pipeline import sampling_tables, training_tables
+    olists = torch.tensor([[0, 0, 5, 6], [7, 0, 0, 0], [1, 2, 3, 0]])
+    L = 4 * 16 * 16
+    given = rnd(12, 4, 16, 16, seed=52)
+    gen = rnd(6, 4, 16, 16, seed=53)
+    tab, wt = sampling_tables(olists)
+    out = torch.empty((6, L), dtype=torch.bfloat16, device=DEV)
+    out32 = torch.empty((6, L), device=DEV)
+    _lib.call("dfh_mutual_reduce", _lib.ptr(gen), _lib.ptr(given), _lib.ptr(tab.to(DEV)), _lib.ptr(wt.to(DEV)),
+              _lib.ptr(out), _lib.ptr(out32), 6, 4, L, gu.stream())
+    torch.cuda.synchronize()
+    ref = glue_ref.mutual_sum(olists, given.cpu(), gen.cpu())
+    assert torch.equal(out32.cpu().view_as(ref), ref)
+    assert torch.equal(out.cpu().view_as(ref), bf(ref))
+    tab, wt = training_tables(8, 4)
+    noisy = rnd(8, 4, 16, 16, seed=54)
+    o32 = torch.empty((8, L), device=DEV)
+    o16 = torch.empty((8, L), dtype=torch.bfloat16, device=DEV)
+    _lib.call("dfh_mutual_reduce", _lib.ptr(noisy), None, _lib.ptr(tab.to(DEV)), _lib.ptr(wt.to(DEV)), _lib.ptr(o16),
+              _lib.ptr(o32), 8, 4, L, gu.stream())
+    torch.cuda.synchronize()
+    ref = glue_ref.mutual_mean(noisy.cpu(), 4)
+    assert torch.equal(o32.cpu().view_as(ref), ref)
+
+
+def test_assemble_input_bit_exact():
+    Fn, CL = 3, 4 * 8 * 8
+    lat, mut, hist = rnd(Fn, 4, 8, 8, seed=55), rnd(Fn, 4, 8, 8, seed=56), rnd(Fn, 4, 8, 8, seed=57)
+    null = rnd(4, 8, 8, seed=58)
+    mreal = torch.tensor([1, 1, 0, 0], dtype=torch.uint8, device=DEV)
+    hreal = torch.tensor([1, 0, 0, 0], dtype=torch.uint8, device=DEV)
+    x = torch.empty((4 * Fn, 8, 8, 8), device=DEV)
+    _lib.call("dfh_assemble_input", _lib.ptr(lat), _lib.ptr(mut), _lib.ptr(hist), _lib.ptr(null), _lib.ptr(mreal),
+              _lib.ptr(hreal), _lib.ptr(x), 4, Fn, CL, float(1 - 0.1), 0.1, 0, gu.stream())
+    torch.cuda.synchronize()
+    nulls = null[None].expand(Fn, -1, -1, -1)
+    mstack = torch.cat([mut, mut, nulls, nulls])
+    hstack = torch.cat([hist, nulls, nulls, nulls])
+    ref = torch.cat([(1 - 0.1) * torch.cat([lat] * 4) + 0.1 * mstack, hstack], dim=1)   # difashion.py:514-515
+    assert torch.equal(x, ref)
+
+
+@pytest.mark.parametrize("mode,name,R", [(1, "full", 4), (2, "cate_hist", 3), (3, "cate_mutual", 3), (4, "cate", 2),
+                                         (5, "hist", 2), (6, "mutual", 2), (0, "none", 1)])
+@pytest.mark.parametrize("pred", ["epsilon", "v_prediction"])
+def test_cfg_combine_and_ddim_step_match_oracle(mode, name, R, pred):
+    from difashion_amd.schedulers import DDIMScheduler
+    Fn = 3
+    eps_all = rnd(R * Fn, 4, 8, 8, seed=59)
+    lat = rnd(Fn, 4, 8, 8, seed=60)
+    sc, sh, sm = 12.0, 4.0, 5.0
+    ref_s = sched_ref.DDIMRef(prediction_type=pred)
+    ref_s.set_timesteps(50)
+    s = DDIMScheduler(prediction_type=pred)
+    s.set_timesteps(50)
+    for t in (981, 501, 21, 1):
+        eps_ref = glue_ref.cfg_combine(name, eps_all.cpu(), sc, sh, sm)
+        prev_ref = ref_s.step(eps_ref, t, lat.cpu(), eta=0.0, return_dict=False)[0]
+        x = lat.clone()
+        eps_out = torch.empty_like(lat)
+        k = s.step_coef(t, 0.0)
+        _lib.call("dfh_cfg_step", _lib.ptr(eps_all), _lib.ptr(x), _lib.ptr(eps_out), None, x.numel(), mode, sc, sh, sm,
+                  C.byref(k), gu.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(eps_out.cpu(), eps_ref)                       # guidance combine: bit-exact
+        torch.testing.assert_close(x.cpu(), prev_ref, rtol=2e-6, atol=2e-6)   # fp32 update, <= 2 ulp-ish
+        torch.testing.assert_close(s.step(eps_ref.to(DEV), t, lat, return_dict=False)[0].cpu(), prev_ref, rtol=2e-6, atol=2e-6)
+
+
+def test_ddim_eta_noise_and_scheduler_api():
+    import inspect
+    from difashion_amd.schedulers import DDIMScheduler, PNDMScheduler
+    s, r = DDIMScheduler(), sched_ref.DDIMRef()
+    s.set_timesteps(50, device=DEV)
+    r.set_timesteps(50)
+    assert s.timesteps.tolist() == r.timesteps.tolist() and s.timesteps.device.type == "cuda"
+    assert {"eta", "generator"} <= set(inspect.signature(s.step).parameters)          # difashion.py:665-673
+    assert not ({"eta", "generator"} & set(inspect.signature(PNDMScheduler().step).parameters))
+    eps, x, z = rnd(2, 4, 8, 8, seed=61), rnd(2, 4, 8, 8, seed=62), rnd(2, 4, 8, 8, seed=63)
+    got = s.step(eps, s.timesteps[3], x, eta=0.7, variance_noise=z).prev_sample
+    ref = r.step(eps.cpu(), 921, x.cpu(), eta=0.7, variance_noise=z.cpu())["prev_sample"]
+    torch.testing.assert_close(got.cpu(), ref, rtol=3e-6, atol=3e-6)
+
+
+def test_add_noise_velocity_and_pndm_match_oracle():
+    from difashion_amd.schedulers import DDIMScheduler, PNDMScheduler
+    s, r = DDIMScheduler(), sched_ref.DDIMRef()
+    x0, n = rnd(6, 4, 8, 8, seed=64), rnd(6, 4, 8, 8, seed=65)
+    t = torch.tensor([0, 1, 500, 999, 37, 640], device=DEV)
+    assert torch.equal(s.add_noise(x0, n, t).cpu(), r.add_noise(x0.cpu(), n.cpu(), t.cpu()))
+    assert torch.equal(s.get_velocity(x0, n, t).cpu(), r.get_velocity(x0.cpu(), n.cpu(), t.cpu()))
+    p, pr = PNDMScheduler(), sched_ref.PNDMRef()
+    p.set_timesteps(10, device=DEV)
+    pr.set_timesteps(10)
+    assert p.timesteps.tolist() == pr.timesteps.tolist()
+    x, xr = rnd(2, 4, 8, 8, seed=66), None
+    xr = x.cpu().clone()
+    for i, tt in enumerate(pr.timesteps.tolist()):
+        e = rnd(2, 4, 8, 8, seed=70 + i)
+        x = p.step(e, tt, x, return_dict=False)[0]
+        xr = pr.step(e.cpu(), tt, xr, return_dict=False)[0]
+        torch.testing.assert_close(x.cpu(), xr, rtol=2e-5, atol=2e-5)
+
+
+def test_mse_rows():
+    a, b = rnd(5, 4, 16, 16, seed=67), rnd(5, 4, 16, 16, seed=68)
+    out = torch.empty(5, device=DEV)
+    _lib.call("dfh_mse_rows", _lib.ptr(a), _lib.ptr(b), _lib.ptr(out), 5, 1024, gu.stream())
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out, ((a - b) ** 2).mean(dim=(1, 2, 3)), rtol=1e-5, atol=1e-7)
+
+
+def test_error_reporting_is_loud():
+    with pytest.raises(_lib.DfhError, match="multiple of 4"):
+        gu.gemm(M=8, N=6, W=bf(rnd(6, 64)), ldw=64, a0=bf(rnd(8, 64)), a0_c=64)
+    with pytest.raises(_lib.DfhError, match="unsupported head dim"):
+        q = bf(rnd(1, 16, 48))
+        _lib.call("dfh_attention", _lib.ptr(q), 48, _lib.ptr(q), 48, _lib.ptr(q), 16, _lib.ptr(q), 48, 1, 1, 48, 16, 16, 1.0, gu.stream())

@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): U-Net denoise steps/sec for a 4-item outfit at 64x64x4 latents.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = everything one iteration of DiFashion.fashion_generation's loop does for one outfit
+(DiFashion/models/difashion.py:456-577) at BASELINE.json configs[1]: sibling reduce + MutualEncoder MLP
++ input assembly + ONE U-Net forward at batch 16 (4 items x 4 guidance branches, SD-1.5 shape,
+in_channels 8) + guidance combine + DDIM update.  Inputs are resident in HBM before the timed region.
+Multi-GPU: one process per GPU, each denoising its own outfit (outfits are independent; no data-path
+collective) -> weak scaling; value = N*K / max-over-ranks(elapsed).
+
+Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit/..., plus
+  "roofline"     : dominant kernel (gemm_bf16_kernel: every conv3x3 / 1x1 / linear) -- ALGORITHMIC flops
+                   per launch / average launch duration from HIP events recorded on the launch stream
+                   (a second, profiled pass of the same K steps; the timed pass carries no events);
+  "cpu_baseline" : the fp32 oracle (stand-in for the reference diffusers path) timed on
+                   this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_BF16_PEAK = 2500.0   # TFLOP/s dense, MI355X_MICROARCH.md
+HBM_PEAK = 8000.0         # GB/s
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_models(dev, cfg_name):
+    import difashion_amd as da
+    kw = dict(sample_size=64, in_channels=8, max_batch=16, init_seed=None)
+    if cfg_name == "sd2base":
+        kw.update(cross_attention_dim=1024, attention_head_dim=(5, 10, 20, 20), use_linear_projection=True)
+    t0 = time.time()
+    unet = da.UNet2DConditionModel(**kw).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(0)
+    with torch.no_grad():                      # synthetic weights: N(0, 0.02), norm gamma 1 / beta 0, biases 0
+        for n, p in unet.named_parameters():
+            is_norm = ".norm" in n or n.startswith("conv_norm_out")
+            if n.endswith(".weight") and not is_norm:
+                p.normal_(0.0, 0.02, generator=g)
+            elif n.endswith(".weight"):
+                p.fill_(1.0)
+            else:
+                p.zero_()
+    enc = da.MutualEncoder(cate_num=50, cate_emb_size=64, latent_channels=4, latent_size=64, hid_dim=256).to(dev).eval()
+    with torch.no_grad():
+        for i in (0, 3):
+            torch.nn.init.xavier_normal_(enc.mlp[i].weight)
+            enc.mlp[i].bias.zero_()
+    unet.pack()
+    torch.cuda.synchronize()
+    log(f"[bench] models ready in {time.time() - t0:.1f}s; workspace+arenas {unet.workspace_bytes() / 2**30:.2f} GiB")
+    return unet, enc
+
+
+def outfit_inputs(dev, cross_dim, rank):
+    """Synthetic iFashion-shaped inputs: one 4-item outfit, every slot generated (GOR)."""
+    def rn(seed, *shape):
+        return torch.randn(*shape, generator=torch.Generator().manual_seed(seed + 1000 * rank)).to(dev)
+    return dict(olists=torch.zeros(1, 4, dtype=torch.long), all_latents=rn(122, 4, 4, 64, 64) * 0.18215,
+                init_latents=rn(123, 4, 4, 64, 64), hist_latents=rn(124, 4, 4, 64, 64) * 0.18215,
+                null_latent=rn(125, 4, 64, 64) * 0.18215, category_prompts=rn(126, 4, 77, cross_dim),
+                null_prompt=rn(127, 1, 77, cross_dim))
+
+
+def cpu_baseline(threads):
+    """Oracle U-Net (fp32, torch CPU) + glue on the host cores: one timed SD-1.5 forward at B=1 after one
+    untimed warm-up, extrapolated to the 16 rows of a step (the 50-step loop is never run on CPU)."""
+    from oracle import glue_ref, unet_ref
+    torch.set_num_threads(threads)
+    cfg = unet_ref.SD15
+    p = unet_ref.init_params(cfg, seed=0)
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(1, 8, 64, 64, generator=g)
+    e = torch.randn(1, 77, 768, generator=g)
+    with torch.no_grad():
+        unet_ref.unet_forward(p, cfg, x, 481, e)
+        t0 = time.perf_counter()
+        unet_ref.unet_forward(p, cfg, x, 481, e)
+        t_fwd = time.perf_counter() - t0
+        enc = {"mlp.0.weight": torch.randn(256, 16384, generator=g) * 0.01, "mlp.0.bias": torch.zeros(256),
+               "mlp.3.weight": torch.randn(16384, 256, generator=g) * 0.01, "mlp.3.bias": torch.zeros(16384)}
+        lat = torch.randn(4, 4, 64, 64, generator=g)
+        t0 = time.perf_counter()
+        m = glue_ref.mutual_encoder(enc, glue_ref.mutual_sum(torch.zeros(1, 4, dtype=torch.long), lat, lat))
+        xin = torch.cat([0.9 * torch.cat([lat] * 4) + 0.1 * torch.cat([m] * 4), torch.cat([lat] * 4)], 1)
+        t_glue = time.perf_counter() - t0
+    del p
+    return dict(value=1.0 / (16.0 * t_fwd + t_glue), unit="steps/s", cores=threads, kind="port",
+                sample=f"oracle fp32 U-Net (SD-1.5 shape) 1 forward at B=1 = {t_fwd:.2f}s, x16 rows/step + glue {t_glue * 1e3:.0f}ms; "
+                       "1 warm-up + 1 timed forward")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="sd15", choices=["sd15", "sd2base"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    import difashion_amd as da
+    from difashion_amd import _lib, dist as ddist
+
+    rank, world, local = ddist.init("nccl" if args.gpus > 1 else None)
+    if world != args.gpus:
+        log(f"[bench] WARNING: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    unet, enc = build_models(dev, args.config)
+    cross = unet.config.cross_attention_dim
+    K, W = args.steps, args.warmup
+    sampler = da.OutfitSampler(unet, enc, da.DDIMScheduler())
+    inp = outfit_inputs(dev, cross, rank)
+
+    def run_steps(n, offset):
+        for i in range(n):
+            sampler.step((offset + i) % 50)
+
+    sampler.prepare(num_inference_steps=50, cate_scale=12.0, hist_scale=4.0, mutual_scale=5.0, eta=0.1, **inp)
+    run_steps(W, 0)
+    torch.cuda.synchronize()
+    ddist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(K, W)
+    torch.cuda.synchronize()
+    ddist.barrier()
+    torch.cuda.synchronize()
+    elapsed = ddist.max_over_ranks(time.perf_counter() - t0)
+    assert torch.isfinite(sampler.latents).all(), "non-finite latents"
+
+    roofline, classes, prof_ms = None, None, None
+    if not args.no_profile and rank == 0:
+        torch.cuda.synchronize()
+        _lib.prof_begin()
+        t1 = time.perf_counter()
+        run_steps(K, W)
+        classes = _lib.prof_end()
+        prof_ms = (time.perf_counter() - t1) * 1e3 / K
+        gemm = {k: sum(classes[c][k] for c in ("gemm_conv3x3", "gemm_linear")) for k in ("launches", "ms", "flops", "bytes")}
+        achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel="gemm_bf16_kernel (conv3x3 + 1x1 + linear, implicit GEMM)",
+                        achieved=round(achieved, 1), peak=MFMA_BF16_PEAK, unit="TFLOP/s", frac=round(achieved / MFMA_BF16_PEAK, 4),
+                        traffic=None, launches_per_step=gemm["launches"] // K,
+                        avg_launch_us=round(gemm["ms"] * 1e3 / max(1, gemm["launches"]), 2),
+                        algorithmic_tflop_per_step=round(gemm["flops"] / K / 1e12, 3))
+
+    if world > 1:
+        ddist.barrier()
+    if rank != 0:
+        return
+    value = world * K / elapsed
+    out = {
+        "metric": "U-Net denoise steps/sec, 4-item outfit @ 64x64x4 latent", "value": round(value, 3), "unit": "steps/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed * 1e3 / K, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: one 4-item outfit, CFG on (4 branches) -> U-Net batch 16, DDIM-50 schedule, "
+                               f"{args.config} shape in_channels=8, 64x64x4 latents, 77 text tokens; one outfit per GPU",
+                   "unet_batch": 16, "latent": "64x64x4", "parallelism": f"outfit-replicas x{world} (no data-path collective)"},
+        "roofline": roofline,
+    }
+    if classes is not None:
+        def rate(c, key, scale):
+            return round(classes[c][key] / (classes[c]["ms"] * 1e-3) / scale, 1) if classes[c]["ms"] > 0 else None
+        out["kernel_classes"] = {
+            c: dict(launches_per_step=v["launches"] // K, ms_per_step=round(v["ms"] / K, 3),
+                    tflops=rate(c, "flops", 1e12) if v["flops"] else None, algorithmic_GBps=rate(c, "bytes", 1e9))
+            for c, v in classes.items() if v["launches"]}
+        out["profiled_pass_ms_per_step"] = round(prof_ms, 3)
+        attn = classes["attention"]
+        if attn["ms"] > 0:
+            out["attention_mfma_frac"] = round(attn["flops"] / (attn["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK, 4)
+        gn = classes["groupnorm"]
+        if gn["ms"] > 0:
+            out["groupnorm_hbm_frac"] = round(gn["bytes"] / (gn["ms"] * 1e-3) / 1e9 / HBM_PEAK, 4)
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        except Exception as e:  # the GPU number must still be reported
+            out["cpu_baseline"] = {"error": repr(e)}
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -8,11 +8,11 @@ running any op does, and fails loudly if the library was not built (no CPU fallb
 from . import _lib
 from ._lib import DfhError
 from .mutual import MutualEncoder
-from .pipeline import guidance_plan, sample_outfits, sampling_tables, train_forward, training_tables
+from .pipeline import OutfitSampler, guidance_plan, sample_outfits, sampling_tables, train_forward, training_tables
 from .schedulers import DDIMScheduler, PNDMScheduler
 from .unet import UNet2DConditionModel, UNet2DConditionOutput
 
 __all__ = [
     "DfhError", "UNet2DConditionModel", "UNet2DConditionOutput", "DDIMScheduler", "PNDMScheduler",
-    "MutualEncoder", "sample_outfits", "train_forward", "guidance_plan", "sampling_tables", "training_tables",
+    "MutualEncoder", "OutfitSampler", "sample_outfits", "train_forward", "guidance_plan", "sampling_tables", "training_tables",
 ]

@@ -54,6 +54,11 @@ class StepCoef(C.Structure):
                 ("sqrt_a_prev", C.c_float), ("dir_coef", C.c_float), ("std_dev", C.c_float)]
 
 
+class ProfClass(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_int), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); status-returning functions are wrapped to raise DfhError
@@ -61,6 +66,8 @@ SIGNATURES = {
     "dfh_abi_version": (_i, []),
     "dfh_last_error": (C.c_char_p, []),
     "dfh_build_info": (C.c_char_p, []),
+    "dfh_prof_begin": (_i, []),
+    "dfh_prof_end": (_i, [C.POINTER(ProfClass), _i]),
     "dfh_unet_create": (_i, [C.POINTER(UNetConfigC), C.POINTER(_vp)]),
     "dfh_unet_destroy": (None, [_vp]),
     "dfh_unet_num_params": (_i, [_vp]),
@@ -133,6 +140,20 @@ def call(name: str, *args):
     if name not in _NO_STATUS and SIGNATURES[name][0] is _i and rc != 0:
         raise DfhError(f"{name} failed ({rc}): {last_error()}")
     return rc
+
+
+def prof_begin():
+    call("dfh_prof_begin")
+
+
+def prof_end():
+    """-> {class name: dict(launches, ms, flops, bytes)} since prof_begin (synchronises the device)."""
+    arr = (ProfClass * 8)()
+    n = raw().dfh_prof_end(arr, 8)
+    if n < 0:
+        raise DfhError(f"dfh_prof_end failed: {last_error()}")
+    return {arr[i].name.decode(): dict(launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes)
+            for i in range(n)}
 
 
 def stream_ptr():

@@ -2,6 +2,7 @@
 // the op-level entry points.  The U-Net context entry points live in unet.hip.
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/difashion_hip.h"
 #include "attention.h"
@@ -21,6 +22,23 @@ int check_launch(const char* what) {
   }
   return 0;
 }
+
+struct ProfRec { hipEvent_t e0, e1; int cls; double flops, bytes; };
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+static size_t g_pool_next = 0;
+static bool g_prof = false;
+bool prof_enabled() { return g_prof; }
+static hipEvent_t pool_get() {
+  if (g_pool_next == g_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); g_pool.push_back(e); }
+  return g_pool[g_pool_next++];
+}
+void prof_open(int cls, double flops, double bytes, hipStream_t s) {
+  ProfRec r; r.e0 = pool_get(); r.e1 = pool_get(); r.cls = cls; r.flops = flops; r.bytes = bytes;
+  (void)hipEventRecord(r.e0, s);
+  g_recs.push_back(r);
+}
+void prof_close(hipStream_t s) { (void)hipEventRecord(g_recs.back().e1, s); }
 }  // namespace dfh
 
 static int fill_gemm(const dfh_gemm_desc* d, GemmArgs* g) {
@@ -51,6 +69,28 @@ static int fill_gemm(const dfh_gemm_desc* d, GemmArgs* g) {
 extern "C" {
 
 int dfh_abi_version(void) { return DFH_ABI_VERSION; }
+
+int dfh_prof_begin(void) {
+  dfh::g_recs.clear(); dfh::g_pool_next = 0; dfh::g_prof = true;
+  return 0;
+}
+int dfh_prof_end(dfh_prof_class* out, int max_classes) {
+  dfh::g_prof = false;
+  DFH_REQUIRE(out != nullptr && max_classes >= dfh::PC_COUNT, "need room for every kernel class");
+  static const char* names[dfh::PC_COUNT] = {"gemm_conv3x3", "gemm_linear", "attention", "groupnorm", "layernorm", "splitk_reduce", "other"};
+  for (int i = 0; i < dfh::PC_COUNT; ++i) {
+    std::memset(&out[i], 0, sizeof(out[i]));
+    std::strncpy(out[i].name, names[i], sizeof(out[i].name) - 1);
+  }
+  if (hipDeviceSynchronize() != hipSuccess) { dfh::set_error("hipDeviceSynchronize failed in dfh_prof_end"); return -2; }
+  for (const auto& r : dfh::g_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    out[r.cls].launches += 1; out[r.cls].ms += ms; out[r.cls].flops += r.flops; out[r.cls].bytes += r.bytes;
+  }
+  dfh::g_recs.clear();
+  return dfh::PC_COUNT;
+}
 const char* dfh_last_error(void) { return dfh::g_err.c_str(); }
 const char* dfh_build_info(void) { return "libdifashion_hip gfx950 (CDNA4) bf16-MFMA abi=1"; }
 

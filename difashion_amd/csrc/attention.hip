@@ -212,6 +212,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 template <int D>
 int launch(const AttnArgs& a, hipStream_t stream) {
   dim3 grid((a.Nq + 127) / 128, a.H, a.B);
+  dfh::ProfScope ps(dfh::PC_ATTN, 4.0 * a.B * a.H * (double)a.Nq * a.Nk * D,
+                    2.0 * a.B * a.H * D * (2.0 * a.Nq + 2.0 * a.Nk), stream);
   hipLaunchKernelGGL(attention_kernel<D>, grid, dim3(256), 0, stream, a);
   return dfh::check_launch("attention_kernel");
 }

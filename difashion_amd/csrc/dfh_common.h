@@ -55,6 +55,16 @@ DFH_DEVICE float wave_sum(float v) {
 namespace dfh {
 void set_error(const std::string& msg);  // api.cpp
 int check_launch(const char* what);     // returns 0 or negative and records the message
+// Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline).
+enum ProfClass { PC_CONV3 = 0, PC_LINEAR = 1, PC_ATTN = 2, PC_GNORM = 3, PC_LNORM = 4, PC_SPLITK = 5, PC_OTHER = 6, PC_COUNT = 7 };
+bool prof_enabled();
+void prof_open(int cls, double flops, double bytes, hipStream_t s);   // no-ops unless enabled
+void prof_close(hipStream_t s);
+struct ProfScope {
+  hipStream_t s; bool on;
+  ProfScope(int cls, double flops, double bytes, hipStream_t st) : s(st), on(prof_enabled()) { if (on) prof_open(cls, flops, bytes, s); }
+  ~ProfScope() { if (on) prof_close(s); }
+};
 }  // namespace dfh
 #define DFH_REQUIRE(cond, msg)                                   \
   do {                                                           \

@@ -38,7 +38,7 @@ int cfg_step_launch(const float* eps_all, float* lat, float* eps_out, const floa
 int noise_mix_launch(const float* x0, const float* noise, const long* t, const float* sqrt_a, const float* sqrt_1ma,
                      float* noisy, float* velocity, int rows, int L, hipStream_t s);
 int mse_rows_launch(const float* pred, const float* target, float* out, int rows, int L, hipStream_t s);
-int pack_conv3x3_launch(const float* w, bf16_t* out, int Cout, int Cin, int ldw, int col_off, hipStream_t s);
+int pack_conv3x3_launch(const float* w, bf16_t* out, int Cout, int Cin, int ldw, int col_off, hipStream_t s, int cin_pad = 0);
 int pack_matrix_launch(const float* w, bf16_t* out, int N, int K, int ldw, int row_off, int col_off, int geglu, hipStream_t s);
 int pack_vector_launch(const float* v, float* out, int N, int off, int geglu, int accumulate, hipStream_t s);
 }  // namespace dfh

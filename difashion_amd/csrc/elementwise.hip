@@ -27,7 +27,7 @@ __global__ void timestep_embed_kernel(const float* __restrict__ t, bf16_t* __res
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const T* __restrict__ x, bf16_t* __restrict__ out, int B, int C, int HW) {
   const long i = gtid();
-  const int C8 = C >> 3;
+  const int C8 = (C + 7) >> 3, Cp = C8 * 8;      // output channels padded to a multiple of 8 with zeros
   if (i >= (long)B * HW * C8) return;
   const int o = (int)(i % C8);
   const long bp = i / C8;
@@ -35,10 +35,14 @@ __global__ void nchw_to_nhwc_kernel(const T* __restrict__ x, bf16_t* __restrict_
   float f[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const T v = x[((long)b * C + o * 8 + k) * HW + p];
-    if constexpr (sizeof(T) == 4) f[k] = v; else f[k] = bf2f(v);
+    const int c = o * 8 + k;
+    f[k] = 0.f;
+    if (c < C) {
+      const T v = x[((long)b * C + c) * HW + p];
+      if constexpr (sizeof(T) == 4) f[k] = v; else f[k] = bf2f(v);
+    }
   }
-  *(uint4*)(out + (bp * C + o * 8)) = pack8(f);
+  *(uint4*)(out + (bp * Cp + o * 8)) = pack8(f);
 }
 
 __global__ void cast_f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n8) {
@@ -172,13 +176,13 @@ __global__ void mse_rows_kernel(const float* __restrict__ pred, const float* __r
 
 // ------------------------------------------------------------------ weight packing (fp32 master -> kernel layouts)
 // conv3x3 OIHW fp32 -> bf16 [o][col_off + (ky*3+kx)*Cin + c]
-__global__ void pack_conv3x3_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int ldw, int col_off) {
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int Cin, int ldw, int col_off, int cin_pad) {
   const long i = gtid();
   if (i >= (long)Cout * Cin * 9) return;
   const int t = (int)(i % 9);
   const long oc = i / 9;
   const int c = (int)(oc % Cin), o = (int)(oc / Cin);
-  out[(long)o * ldw + col_off + t * Cin + c] = f2bf(w[i]);
+  out[(long)o * ldw + col_off + t * cin_pad + c] = f2bf(w[i]);   // columns c >= Cin of a padded tap stay zero
 }
 
 // [N][K] fp32 -> bf16 [row_off + perm(n)][col_off + k]; geglu: value/gate halves interleaved in 16-row blocks
@@ -213,8 +217,7 @@ int timestep_embed_launch(const float* t, bf16_t* out, int B, int dim, hipStream
 }
 
 int nchw_to_nhwc_launch(const void* x, int is_bf16, bf16_t* out, int B, int C, int HW, hipStream_t s) {
-  DFH_REQUIRE(C % 8 == 0, "channels must be a multiple of 8");
-  const long n = (long)B * HW * (C / 8);
+  const long n = (long)B * HW * ((C + 7) / 8);
   if (is_bf16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, ew_grid(n), dim3(EW_BLOCK), 0, s, (const bf16_t*)x, out, B, C, HW);
   else hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, ew_grid(n), dim3(EW_BLOCK), 0, s, (const float*)x, out, B, C, HW);
   return check_launch("nchw_to_nhwc_kernel");
@@ -260,8 +263,9 @@ int mse_rows_launch(const float* pred, const float* target, float* out, int rows
   return check_launch("mse_rows_kernel");
 }
 
-int pack_conv3x3_launch(const float* w, bf16_t* out, int Cout, int Cin, int ldw, int col_off, hipStream_t s) {
-  hipLaunchKernelGGL(pack_conv3x3_kernel, ew_grid((long)Cout * Cin * 9), dim3(EW_BLOCK), 0, s, w, out, Cout, Cin, ldw, col_off);
+int pack_conv3x3_launch(const float* w, bf16_t* out, int Cout, int Cin, int ldw, int col_off, hipStream_t s, int cin_pad) {
+  if (cin_pad <= 0) cin_pad = Cin;
+  hipLaunchKernelGGL(pack_conv3x3_kernel, ew_grid((long)Cout * Cin * 9), dim3(EW_BLOCK), 0, s, w, out, Cout, Cin, ldw, col_off, cin_pad);
   return check_launch("pack_conv3x3_kernel");
 }
 int pack_matrix_launch(const float* w, bf16_t* out, int N, int K, int ldw, int row_off, int col_off, int geglu, hipStream_t s) {

@@ -423,6 +423,13 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
   if (split > 1) DFH_REQUIRE(a.partial != nullptr, "split-K needs a partial buffer");
   const bool glds = force_glds < 0 ? true : (force_glds != 0);
   int rc;
+  {
+  // algorithmic work of this launch: 2*M*N*K over the REAL K (padding excluded); bytes = each operand once + output
+  double kreal = (double)a.ntaps * a.conv_c;
+  double abytes = a.ntaps ? (double)(a.M / (a.Hout * a.Wout)) * a.Hin * a.Win * a.conv_c * 2.0 : 0.0;
+  for (int i = 0; i < a.nplain; ++i) { kreal += a.p_c[i]; abytes += (double)a.M * a.p_c[i] * 2.0; }
+  const double obytes = (double)a.M * (a.act == ACT_GEGLU ? a.N / 2 : a.N) * ((a.out_mode == OUT_F32 || a.out_mode == OUT_F32_T) ? 4.0 : 2.0);
+  ProfScope ps(a.ntaps ? PC_CONV3 : PC_LINEAR, 2.0 * a.M * a.N * kreal, abytes + (double)a.N * kreal * 2.0 + obytes, stream);
   if (glds) {
     rc = tile == 0 ? launch_tile<128, 160, true>(a, stream)
        : tile == 1 ? launch_tile<128, 128, true>(a, stream)
@@ -432,9 +439,11 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
        : tile == 1 ? launch_tile<128, 128, false>(a, stream)
                    : launch_tile<128, 64, false>(a, stream);
   }
+  }
   if (rc) return rc;
   if (split > 1) {
     const long total4 = ((long)a.M * a.N) / 4;
+    ProfScope ps(PC_SPLITK, 0.0, (double)split * a.M * a.N * 4.0 + (double)a.M * a.N * 2.0, stream);
     hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, a);
     return check_launch("gemm_splitk_reduce");
   }

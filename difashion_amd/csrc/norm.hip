@@ -190,6 +190,7 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
   DFH_REQUIRE(block <= 1024, "block too large");
   const size_t lds = (size_t)a.PL * a.C * 2 * sizeof(float);
   DFH_REQUIRE(lds <= 64 * 1024, "GroupNorm LDS reduction too large");
+  ProfScope ps(PC_GNORM, 0.0, 4.0 * a.B * (double)a.HW * a.C, stream);   // algorithmic: one read + one write (bf16)
   hipLaunchKernelGGL(gn_stats_kernel, dim3(a.chunks, a.B), dim3(block), lds, stream, a);
   if (int rc = check_launch("gn_stats_kernel")) return rc;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(achunks, a.B), dim3(block), 0, stream, a);
@@ -200,6 +201,7 @@ int layernorm_launch(const bf16_t* x, const float* gamma, const float* beta, bf1
                      hipStream_t stream) {
   DFH_REQUIRE(C % 8 == 0 && C <= 8 * 64 * 4, "LayerNorm width must be a multiple of 8 and <= 2048");
   const dim3 grid((M + 3) / 4), block(256);
+  ProfScope ps(PC_LNORM, 0.0, 4.0 * (double)M * C, stream);
   if (C <= 512) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, stream, x, gamma, beta, y, M, C, eps);
   else if (C <= 1024) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, x, gamma, beta, y, M, C, eps);
   else hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, stream, x, gamma, beta, y, M, C, eps);

@@ -38,6 +38,7 @@ struct PackOp {
   int param, kind;
   size_t dst;
   int N, K, ldw, row_off, col_off, geglu, accumulate;
+  int cin_pad = 0;   // PK_CONV3: channels per tap in the packed layout (conv_in pads 4 -> 8)
 };
 
 struct ParamDesc { std::string name; std::vector<int> shape; };
@@ -119,9 +120,11 @@ struct dfh_unet {
     mat_into(name, N, K, as_conv1x1, m, 0, 0, geglu);
     return m;
   }
-  void conv_into(const std::string& name, int cout, int cin, const Mat& dst, int col_off) {
+  void conv_into(const std::string& name, int cout, int cin, const Mat& dst, int col_off, int cin_pad = 0) {
     int p = add_param(name, {cout, cin, 3, 3});
-    packs.push_back({p, PK_CONV3, dst.off, cout, cin, dst.K, 0, col_off, 0, 0});
+    PackOp op{p, PK_CONV3, dst.off, cout, cin, dst.K, 0, col_off, 0, 0};
+    op.cin_pad = cin_pad ? cin_pad : cin;
+    packs.push_back(op);
   }
 
   void build_resnet(const std::string& pre, int cin, int cout, ResL& r) {
@@ -181,10 +184,12 @@ struct dfh_unet {
   }
 
   void build_conv(const std::string& pre, int cout, int cin, ConvL& c) {
-    c.cin = cin; c.cout = cout;
-    // conv_out has 4 output channels; conv_in 8 input channels: both go through the same GEMM
-    c.w = mat_alloc(cout, 9 * cin);
-    conv_into(pre + ".weight", cout, cin, c.w, 0);
+    // conv_out has 4 output channels; conv_in 8 (or 4, padded to 8 with zero weights) input channels:
+    // both go through the same GEMM
+    const int cp = (cin + 7) & ~7;
+    c.cin = cp; c.cout = cout;
+    c.w = mat_alloc(cout, 9 * cp);
+    conv_into(pre + ".weight", cout, cin, c.w, 0, cp);
     c.b = vec(pre + ".bias", cout);
   }
 
@@ -452,7 +457,7 @@ struct dfh_unet {
       if (ehs_bf16) (void)hipMemcpyAsync(ehs16, ehs, (size_t)B * T * X * 2, hipMemcpyDeviceToDevice, s);
       else r.rc = dfh::cast_f32_to_bf16_launch((const float*)ehs, ehs16, (long)B * T * X, s);
     }
-    Tensor x = r.palloc(S, S, cfg.in_channels);
+    Tensor x = r.palloc(S, S, conv_in.cin);   // in_channels padded to a multiple of 8
     if (!dry && !r.rc) r.rc = dfh::nchw_to_nhwc_launch(sample, sample_bf16, x.p, B, cfg.in_channels, S * S, s);
 
     Tensor h = r.conv(x, conv_in, 1, 0, true);
@@ -514,7 +519,7 @@ struct dfh_unet {
       int rc = 0;
       if (op.kind == PK_VEC) rc = dfh::pack_vector_launch(src, arena32, op.N, (int)op.dst, op.geglu, op.accumulate, s);
       else if (op.kind == PK_MAT) rc = dfh::pack_matrix_launch(src, arena16 + op.dst, op.N, op.K, op.ldw, op.row_off, op.col_off, op.geglu, s);
-      else rc = dfh::pack_conv3x3_launch(src, arena16 + op.dst, op.N, op.K, op.ldw, op.col_off, s);
+      else rc = dfh::pack_conv3x3_launch(src, arena16 + op.dst, op.N, op.K, op.ldw, op.col_off, s, op.cin_pad);
       if (rc) return rc;
     }
     return 0;
@@ -527,7 +532,7 @@ extern "C" {
 int dfh_unet_create(const dfh_unet_config* cfg, dfh_unet** out) {
   DFH_REQUIRE(cfg && out, "null argument");
   DFH_REQUIRE(cfg->num_blocks >= 2 && cfg->num_blocks <= DFH_MAX_BLOCKS, "num_blocks out of range");
-  DFH_REQUIRE(cfg->in_channels % 8 == 0, "in_channels must be a multiple of 8");
+  DFH_REQUIRE(cfg->in_channels > 0 && cfg->in_channels <= 64, "in_channels out of range");
   DFH_REQUIRE(cfg->out_channels % 4 == 0, "out_channels must be a multiple of 4");
   DFH_REQUIRE(cfg->cross_attention_dim % 8 == 0, "cross_attention_dim must be a multiple of 8");
   DFH_REQUIRE(cfg->sample_size % (1 << (cfg->num_blocks - 1)) == 0, "sample_size not divisible by the down-sampling factor");

@@ -1,0 +1,84 @@
+"""Multi-GPU launch plumbing: one process per GPU, torch.distributed over RCCL (backend "nccl").
+
+Sampling shards over OUTFITS with no data-path collective: the four items of an
+outfit are coupled every step through the mutual condition (difashion.py:475-490) so an outfit stays
+on one GPU, while different outfits are independent.  The only collectives are control-plane: a
+barrier around the timed region, a MAX over ranks of the elapsed time, and (optionally, outside the
+timed region) an all_gather of the finished latents.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the launcher environment (torchrun / torch.distributed.run)."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def init(backend: str | None = None) -> Tuple[int, int, int]:
+    """Initialise the default process group when WORLD_SIZE > 1.  backend: "nccl" (= RCCL on ROCm) on
+    GPUs, "gloo" for the CPU tests."""
+    rank, world, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int) -> range:
+    """Contiguous shard of ``n_items`` outfits for ``rank``: sizes differ by at most one, earlier ranks
+    take the remainder (every outfit assigned exactly once, order preserved)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return range(start, start + base + (1 if rank < rem else 0))
+
+
+def _reduce_device():
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value: float) -> float:
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=_reduce_device())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float) -> float:
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=_reduce_device())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_outfit_latents(local: torch.Tensor, counts: Sequence[int]) -> torch.Tensor:
+    """Concatenate every rank's finished latents in rank order (not on the timed path).
+    ``counts[r]`` = number of latent rows rank r holds."""
+    if not dist.is_initialized():
+        return local
+    world = dist.get_world_size()
+    mx = max(counts)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)

@@ -82,6 +82,90 @@ def _u8(flags, dev):
     return torch.tensor(flags, dtype=torch.uint8, device=dev)
 
 
+class OutfitSampler:
+    """State of one CFG sampling run (the loop body of fashion_generation, difashion.py:456-577).
+
+    ``prepare`` does the per-run setup (replica stacks, index tables, buffers); ``step(i)`` is one
+    denoising step = sibling reduce + MutualEncoder + input assembly + U-Net forward at batch R*F +
+    guidance combine + scheduler update.  Nothing is allocated inside ``step`` on the DDIM path."""
+
+    def __init__(self, unet, fashion_encoder: MutualEncoder, scheduler):
+        self.unet, self.enc, self.sched = unet, fashion_encoder, scheduler
+
+    @torch.no_grad()
+    def prepare(self, *, olists, all_latents, init_latents, hist_latents, null_latent, category_prompts, null_prompt,
+                num_inference_steps=50, cate_scale=12.0, hist_scale=4.0, mutual_scale=5.0, eta=0.1, ddim_eta=0.0,
+                use_history=True, use_mutual_guidance=True, generator=None, keep_eps=False):
+        dev = init_latents.device
+        if dev.type != "cuda":
+            raise _lib.DfhError("sampling runs on the HIP path only (device tensors required)")
+        self.mode_name = guidance_plan(cate_scale, hist_scale, mutual_scale, use_history, use_mutual_guidance)
+        self.mode, br = _BRANCHES[self.mode_name]
+        self.R, self.F = len(br), init_latents.shape[0]
+        self.CL, S = init_latents[0].numel(), init_latents.shape[-1]
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.latents = init_latents.to(**f32).clone().contiguous()
+        self.all_lat = all_latents.to(**f32).contiguous()
+        self.hist = hist_latents.to(**f32).contiguous()
+        self.null_lat = null_latent.to(**f32).contiguous()
+        null_prompts = null_prompt.to(dev).expand(self.F, -1, -1)
+        self.ehs = torch.cat([category_prompts.to(dev) if b[2] else null_prompts for b in br], dim=0).contiguous()
+        self.hist_real = _u8([b[0] for b in br], dev)
+        self.mutual_real = _u8([b[1] if use_mutual_guidance else 0 for b in br], dev)
+        tab, wt = sampling_tables(olists)
+        self.tab, self.wt, self.olen = tab.to(dev), wt.to(dev), olists.shape[1]
+        self.sched.set_timesteps(num_inference_steps, device=dev)
+        self.ts = list(self.sched._timesteps_host)
+        self.is_ddim = isinstance(self.sched, DDIMScheduler)
+        self.x_in = torch.empty((self.R * self.F, 2 * init_latents.shape[1], S, S), **f32)
+        self.mutual_bf = torch.empty((self.F, self.CL), dtype=torch.bfloat16, device=dev)
+        self.eps_comb = torch.empty_like(self.latents) if (keep_eps or not self.is_ddim) else None
+        self.mutual = self.null_lat.expand(self.F, -1, -1, -1).contiguous()   # stays when mutual guidance is off
+        self.scales = (float(cate_scale), float(hist_scale), float(mutual_scale))
+        self.one_minus_eta, self.eta = float(1 - eta), float(eta)
+        self.ddim_eta, self.generator, self.use_mutual = ddim_eta, generator, use_mutual_guidance
+        self.eps_all = None
+        if hasattr(self.unet, "pack"):
+            self.unet.pack()
+        return self
+
+    @torch.no_grad()
+    def step(self, i: int):
+        sp = _lib.stream_ptr
+        t = self.ts[i]
+        lat = self.latents
+        if self.use_mutual:
+            _lib.call("dfh_mutual_reduce", _lib.ptr(lat), _lib.ptr(self.all_lat), _lib.ptr(self.tab), _lib.ptr(self.wt),
+                      _lib.ptr(self.mutual_bf), None, self.F, self.olen, self.CL, sp())
+            self.mutual = self.enc.forward_bf16(self.mutual_bf)
+        _lib.call("dfh_assemble_input", _lib.ptr(lat), _lib.ptr(self.mutual), _lib.ptr(self.hist), _lib.ptr(self.null_lat),
+                  _lib.ptr(self.mutual_real), _lib.ptr(self.hist_real), _lib.ptr(self.x_in), self.R, self.F, self.CL,
+                  self.one_minus_eta, self.eta, 0, sp())
+        static = getattr(self.unet, "assume_static_weights", None)
+        if static is not None:
+            self.unet.assume_static_weights = True      # weights cannot change inside the loop: skip the dirty scan
+        try:
+            self.eps_all = self.unet(self.x_in, t, self.ehs, return_dict=False)[0]
+        finally:
+            if static is not None:
+                self.unet.assume_static_weights = static
+        sc, sh, sm = self.scales
+        if self.is_ddim:
+            k = self.sched.step_coef(t, self.ddim_eta)
+            noise = None
+            if self.ddim_eta > 0:
+                noise = torch.randn(lat.shape, generator=self.generator, device=lat.device, dtype=torch.float32)
+            _lib.call("dfh_cfg_step", _lib.ptr(self.eps_all), _lib.ptr(lat), _lib.ptr(self.eps_comb), _lib.ptr(noise),
+                      lat.numel(), self.mode, sc, sh, sm, C.byref(k), sp())
+        else:
+            k = _lib.StepCoef()
+            k.kind = STEP_NONE
+            _lib.call("dfh_cfg_step", _lib.ptr(self.eps_all), None, _lib.ptr(self.eps_comb), None, lat.numel(), self.mode,
+                      sc, sh, sm, C.byref(k), sp())
+            self.latents = self.sched.step(self.eps_comb.clone(), t, lat, return_dict=False)[0]
+        return self.latents
+
+
 @torch.no_grad()
 def sample_outfits(unet, fashion_encoder: MutualEncoder, scheduler, *, olists: torch.Tensor,
                    all_latents: torch.Tensor, init_latents: torch.Tensor, hist_latents: torch.Tensor,
@@ -96,75 +180,21 @@ def sample_outfits(unet, fashion_encoder: MutualEncoder, scheduler, *, olists: t
     ``hist_latents`` (F,4,S,S): history rows selected for the blank slots; ``category_prompts``
     (F,77,D); ``null_prompt`` (1,77,D).  ``eta`` is the mutual mix weight (args.eta), ``ddim_eta`` the
     scheduler's stochasticity (fashion_generation's ``eta``)."""
-    dev = init_latents.device
-    if dev.type != "cuda":
-        raise _lib.DfhError("sample_outfits runs on the HIP path only (device tensors required)")
-    mode_name = guidance_plan(cate_scale, hist_scale, mutual_scale, use_history, use_mutual_guidance)
-    mode, br = _BRANCHES[mode_name]
-    R = len(br)
-    F_ = init_latents.shape[0]
-    CL = init_latents[0].numel()
-    S = init_latents.shape[-1]
-    f32 = dict(dtype=torch.float32, device=dev)
-    latents = init_latents.to(**f32).clone().contiguous()
-    all_lat = all_latents.to(**f32).contiguous()
-    hist = hist_latents.to(**f32).contiguous()
-    null_lat = null_latent.to(**f32).contiguous()
-    # prompt stack per replica (constant across steps)
-    null_prompts = null_prompt.to(dev).expand(F_, -1, -1)
-    ehs = torch.cat([category_prompts.to(dev) if b[2] else null_prompts for b in br], dim=0).contiguous()
-    hist_real = _u8([b[0] for b in br], dev)
-    mutual_real = _u8([b[1] if use_mutual_guidance else 0 for b in br], dev)
-    tab, wt = sampling_tables(olists)
-    tab, wt = tab.to(dev), wt.to(dev)
-    olen = olists.shape[1]
-
-    scheduler.set_timesteps(num_inference_steps, device=dev)
-    ts_host = list(scheduler._timesteps_host)
-    is_ddim = isinstance(scheduler, DDIMScheduler)
-    x_in = torch.empty((R * F_, 2 * init_latents.shape[1], S, S), **f32)
-    mutual_bf = torch.empty((F_, CL), dtype=torch.bfloat16, device=dev)
-    eps_comb = torch.empty_like(latents) if (taps is not None or not is_ddim) else None
-    mutual = null_lat.expand(F_, -1, -1, -1).contiguous()     # used only when mutual guidance is off
-    one_minus_eta, eta_f = float(1 - eta), float(eta)
-    sp = _lib.stream_ptr
-    unet_static = getattr(unet, "assume_static_weights", None)
-    if unet_static is not None:
-        unet.pack() if hasattr(unet, "pack") else None
-        unet.assume_static_weights = True
-    try:
-        for i, t in enumerate(ts_host):
-            if use_mutual_guidance:
-                _lib.call("dfh_mutual_reduce", _lib.ptr(latents), _lib.ptr(all_lat), _lib.ptr(tab), _lib.ptr(wt),
-                          _lib.ptr(mutual_bf), None, F_, olen, CL, sp())
-                mutual = fashion_encoder.forward_bf16(mutual_bf)
-            _lib.call("dfh_assemble_input", _lib.ptr(latents), _lib.ptr(mutual), _lib.ptr(hist), _lib.ptr(null_lat),
-                      _lib.ptr(mutual_real), _lib.ptr(hist_real), _lib.ptr(x_in), R, F_, CL, one_minus_eta, eta_f, 0, sp())
-            eps_all = unet(x_in, t, ehs, return_dict=False)[0]
-            if is_ddim:
-                k = scheduler.step_coef(t, ddim_eta)
-                noise = None
-                if ddim_eta > 0:
-                    noise = torch.randn(latents.shape, generator=generator, device=dev, dtype=torch.float32)
-                _lib.call("dfh_cfg_step", _lib.ptr(eps_all), _lib.ptr(latents), _lib.ptr(eps_comb), _lib.ptr(noise),
-                          latents.numel(), mode, float(cate_scale), float(hist_scale), float(mutual_scale),
-                          C.byref(k), sp())
-            else:
-                k = _lib.StepCoef()
-                k.kind = STEP_NONE
-                _lib.call("dfh_cfg_step", _lib.ptr(eps_all), None, _lib.ptr(eps_comb), None, latents.numel(), mode,
-                          float(cate_scale), float(hist_scale), float(mutual_scale), C.byref(k), sp())
-                latents = scheduler.step(eps_comb.clone(), t, latents, return_dict=False)[0]
-            if taps is not None:
-                taps[f"x_in_{i}"] = x_in.clone()
-                taps[f"eps_{i}"] = eps_comb.clone()
-                taps[f"unet_out_{i}"] = eps_all.clone()
-            if callback is not None:
-                callback(i, t, latents)
-    finally:
-        if unet_static is not None:
-            unet.assume_static_weights = unet_static
-    return latents
+    s = OutfitSampler(unet, fashion_encoder, scheduler).prepare(
+        olists=olists, all_latents=all_latents, init_latents=init_latents, hist_latents=hist_latents,
+        null_latent=null_latent, category_prompts=category_prompts, null_prompt=null_prompt,
+        num_inference_steps=num_inference_steps, cate_scale=cate_scale, hist_scale=hist_scale,
+        mutual_scale=mutual_scale, eta=eta, ddim_eta=ddim_eta, use_history=use_history,
+        use_mutual_guidance=use_mutual_guidance, generator=generator, keep_eps=taps is not None)
+    for i, t in enumerate(s.ts):
+        s.step(i)
+        if taps is not None:
+            taps[f"x_in_{i}"] = s.x_in.clone()
+            taps[f"eps_{i}"] = s.eps_comb.clone()
+            taps[f"unet_out_{i}"] = s.eps_all.clone()
+        if callback is not None:
+            callback(i, t, s.latents)
+    return s.latents
 
 
 @torch.no_grad()
@@ -196,8 +226,9 @@ def train_forward(unet, fashion_encoder: MutualEncoder, scheduler, *, latents: t
     sp = _lib.stream_ptr
     if use_mutual_guidance:
         tab, wt = training_tables(n, olen)
+        tab, wt = tab.to(dev), wt.to(dev)      # named: a pointer taken from a temporary could be recycled
         mb = torch.empty((n, CL), dtype=torch.bfloat16, device=dev)
-        _lib.call("dfh_mutual_reduce", _lib.ptr(noisy), None, _lib.ptr(tab.to(dev)), _lib.ptr(wt.to(dev)),
+        _lib.call("dfh_mutual_reduce", _lib.ptr(noisy), None, _lib.ptr(tab), _lib.ptr(wt),
                   _lib.ptr(mb), None, n, olen, CL, sp())
         mutual = fashion_encoder.forward_bf16(mb, dropout_mask)
     else:
@@ -215,8 +246,10 @@ def train_forward(unet, fashion_encoder: MutualEncoder, scheduler, *, latents: t
         elif use_mutual_guidance:
             mutual_real = ~(rp < mask_ratio)
     x_in = torch.empty((n, 2 * latents.shape[1], S, S), **f32)
-    _lib.call("dfh_assemble_input", _lib.ptr(noisy), _lib.ptr(mutual), _lib.ptr(hist_latents.to(**f32).contiguous()),
-              _lib.ptr(null_lat), _lib.ptr(mutual_real.to(torch.uint8)), _lib.ptr(hist_real.to(torch.uint8)),
+    hist = hist_latents.to(**f32).contiguous()
+    m_u8, h_u8 = mutual_real.to(torch.uint8), hist_real.to(torch.uint8)
+    _lib.call("dfh_assemble_input", _lib.ptr(noisy), _lib.ptr(mutual), _lib.ptr(hist),
+              _lib.ptr(null_lat), _lib.ptr(m_u8), _lib.ptr(h_u8),
               _lib.ptr(x_in), 1, n, CL, float(1 - eta), float(eta), 1, sp())
     states = ehs.to(dev).clone()
     if cate_mask_ratio is not None:
@@ -230,7 +263,8 @@ def train_forward(unet, fashion_encoder: MutualEncoder, scheduler, *, latents: t
         raise ValueError(f"Unknown prediction type {ptype}")
     pred = unet(x_in, t, states, return_dict=False)[0]
     rows = torch.empty(n, **f32)
-    _lib.call("dfh_mse_rows", _lib.ptr(pred.contiguous()), _lib.ptr(target.contiguous()), _lib.ptr(rows), n, CL, sp())
+    pred, target = pred.contiguous(), target.contiguous()
+    _lib.call("dfh_mse_rows", _lib.ptr(pred), _lib.ptr(target), _lib.ptr(rows), n, CL, sp())
     if taps is not None:
         taps.update(x_in=x_in, timesteps=t, ehs=states, target=target, pred=pred)
     if snr_gamma is None:

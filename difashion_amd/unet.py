@@ -209,8 +209,9 @@ class UNet2DConditionModel(nn.Module):
                 lib.dfh_unet_destroy(ctx)
                 raise _lib.DfhError(f"parameter {name}: expected shape {shape}, module has "
                                     f"{tuple(params[name].shape) if name in params else None}")
-        a16 = torch.empty(lib.dfh_unet_arena16_bytes(ctx), dtype=torch.uint8, device=dev)
-        a32 = torch.empty(lib.dfh_unet_arena32_bytes(ctx), dtype=torch.uint8, device=dev)
+        # zero-filled: padded weight columns (conv_in with 4 input channels -> 8) must read as 0
+        a16 = torch.zeros(lib.dfh_unet_arena16_bytes(ctx), dtype=torch.uint8, device=dev)
+        a32 = torch.zeros(lib.dfh_unet_arena32_bytes(ctx), dtype=torch.uint8, device=dev)
         wsb = lib.dfh_unet_workspace_bytes(ctx, self.max_batch)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         _lib.call("dfh_unet_bind", ctx, _lib.ptr(a16), _lib.ptr(a32), _lib.ptr(ws), wsb, self.max_batch)

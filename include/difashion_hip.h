@@ -34,6 +34,18 @@ int dfh_abi_version(void);
 const char* dfh_last_error(void);          /* message of the last failing call on this thread */
 const char* dfh_build_info(void);          /* "gfx950 ..." */
 
+/* Per-kernel-class timing with HIP events recorded on the launch stream (bench.py "roofline"):
+ * between begin and end every launch is bracketed by two events; end synchronises and sums, per
+ * class, launches / elapsed ms / ALGORITHMIC flops and bytes (DESIGN.md "Measurement").  Not for
+ * use inside a timed region whose wall clock is being reported (adds two event records per launch). */
+typedef struct dfh_prof_class {
+  char name[32];
+  int launches;
+  double ms, flops, bytes;
+} dfh_prof_class;
+int dfh_prof_begin(void);
+int dfh_prof_end(dfh_prof_class* out, int max_classes);   /* returns the number of classes written (7) */
+
 /* ------------------------------------------------------------------ U-Net context
  * Replaces: diffusers UNet2DConditionModel as constructed at df.py:77-93 (in_channels widened to
  * 8) and called at df.py:249-253 (training) and df.py:518-523 (sampling). */

@@ -1,0 +1,121 @@
+"""CPU (-m "not gpu"): the C-ABI library loads without a GPU and exports every symbol the header
+declares; the host-only entry points (context creation, parameter table, workspace planning) agree
+with the oracle.  No compute call is made here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+import difashion_amd as da
+from difashion_amd import _lib
+from oracle import unet_ref
+from tests.helpers import GLUE_CFG
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "difashion_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dfh_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.raw()
+    names = header_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/difashion_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype in difashion_amd/_lib.py"
+    assert set(_lib.SIGNATURES) <= set(names)
+    assert lib.dfh_abi_version() == 1 and b"gfx950" in lib.dfh_build_info()
+
+
+def test_struct_layouts_match_header_field_order():
+    src = open(os.path.join(ROOT, "include", "difashion_hip.h")).read()
+    body = re.search(r"typedef struct dfh_gemm_desc \{(.*?)\} dfh_gemm_desc;", src, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            fields += [f.strip().lstrip("*") for f in re.sub(r"^(const\s+)?[a-z_0-9]+\*?\s+", "", decl).split(",")]
+    assert fields == [f[0] for f in _lib.GemmDesc._fields_]
+    assert C.sizeof(_lib.StepCoef) == 28 and C.sizeof(_lib.ProfClass) == 64
+
+
+def _cfg_model(cfg):
+    return da.UNet2DConditionModel(sample_size=cfg.sample_size, in_channels=cfg.in_channels,
+                                   block_out_channels=cfg.block_out_channels, cross_attention_dim=cfg.cross_attention_dim,
+                                   attention_head_dim=cfg.num_heads, use_linear_projection=cfg.use_linear_projection,
+                                   init_seed=None)
+
+
+@pytest.mark.parametrize("cfg", [unet_ref.TINY, GLUE_CFG], ids=["tiny", "glue"])
+def test_param_table_and_state_dict_match_oracle(cfg):
+    m = _cfg_model(cfg)
+    ref = unet_ref.param_shapes(cfg)
+    assert dict(m.param_table()) == {k: tuple(v) for k, v in ref.items()}
+    sd = m.state_dict()
+    assert set(sd) == set(ref) and all(tuple(sd[k].shape) == tuple(ref[k]) for k in ref)
+    m.load_state_dict(unet_ref.init_params(cfg, seed=1))          # oracle weights drop in by name
+
+
+@pytest.mark.parametrize("cfg,count", [(unet_ref.SD15, 859_532_484), (unet_ref.SD2BASE, 865_922_244)], ids=["sd15", "sd2base"])
+def test_full_size_tables_without_allocating_weights(cfg, count):
+    c = _lib.UNetConfigC()
+    c.sample_size, c.in_channels, c.out_channels, c.num_blocks = 64, 8, 4, 4
+    for i in range(4):
+        c.block_out_channels[i] = cfg.block_out_channels[i]
+        c.num_heads[i] = cfg.num_heads[i]
+        c.down_attn[i] = int(cfg.down_attn[i])
+    c.layers_per_block, c.cross_attention_dim = 2, cfg.cross_attention_dim
+    c.use_linear_projection, c.norm_num_groups, c.norm_eps, c.text_len = int(cfg.use_linear_projection), 32, 1e-5, 77
+    h = C.c_void_p()
+    _lib.call("dfh_unet_create", C.byref(c), C.byref(h))
+    lib = _lib.raw()
+    try:
+        table = {lib.dfh_unet_param_name(h, i).decode(): tuple(lib.dfh_unet_param_dim(h, i, d) for d in range(lib.dfh_unet_param_ndim(h, i)))
+                 for i in range(lib.dfh_unet_num_params(h))}
+        assert table == {k: tuple(v) for k, v in unet_ref.param_shapes(cfg).items()}
+        n = sum(int(torch.tensor(s).prod()) for s in table.values())
+        assert n == count
+        # packed bf16 arena holds every matrix once (+ alignment); workspace grows with batch
+        assert 2 * 0.99 * n < lib.dfh_unet_arena16_bytes(h) < 2 * 1.01 * n
+        w1, w16 = lib.dfh_unet_workspace_bytes(h, 1), lib.dfh_unet_workspace_bytes(h, 16)
+        assert 0 < w1 < w16 < 4 * 2**30
+    finally:
+        lib.dfh_unet_destroy(h)
+
+
+def test_bad_configs_are_rejected_with_messages():
+    with pytest.raises(_lib.DfhError, match="unsupported head dim"):
+        da.UNet2DConditionModel(sample_size=16, block_out_channels=(64, 128, 256, 256), attention_head_dim=4)
+    with pytest.raises(_lib.DfhError, match="sample_size"):
+        da.UNet2DConditionModel(sample_size=12, block_out_channels=(64, 128, 256, 256), attention_head_dim=2)
+    with pytest.raises(ValueError, match="mirror"):
+        da.UNet2DConditionModel(up_block_types=("UpBlock2D",) * 4)
+
+
+def test_compute_path_refuses_cpu_tensors():
+    m = _cfg_model(unet_ref.TINY)
+    x = torch.zeros(1, 8, 16, 16)
+    with pytest.raises(da.DfhError, match="no CPU fallback"):
+        m(x, 1, torch.zeros(1, 77, 64))
+    with pytest.raises(da.DfhError, match="HIP path only"):
+        da.DDIMScheduler().add_noise(x, x, torch.tensor([1]))
+    enc = da.MutualEncoder(cate_num=3, cate_emb_size=8, latent_channels=4, latent_size=16, hid_dim=32)
+    with pytest.raises(da.DfhError, match="HIP path only"):
+        enc.forward_bf16(torch.zeros(1, 1024, dtype=torch.bfloat16))
+
+
+def test_product_never_imports_the_oracle():
+    """Scope rule: only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "difashion_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "/root/reference" not in text, f

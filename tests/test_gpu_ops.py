@@ -152,7 +152,8 @@ def test_groupnorm_silu(C0, C1, HW, silu, eps):
     gamma, beta = rnd(C, seed=33) * 0.3 + 1, rnd(C, seed=34) * 0.2
     out = torch.empty((B, HW, C), dtype=torch.bfloat16, device=DEV)
     part = torch.empty(B * 64 * G * 2, device=DEV)
-    _lib.call("dfh_groupnorm", _lib.ptr(gu.nhwc(x0)), C0, _lib.ptr(gu.nhwc(x1)) if C1 else None, C1, B, HW, G,
+    s0, s1 = gu.nhwc(x0), (gu.nhwc(x1) if C1 else None)      # keep the NHWC copies alive across the launch
+    _lib.call("dfh_groupnorm", _lib.ptr(s0), C0, _lib.ptr(s1), C1, B, HW, G,
               _lib.ptr(gamma), _lib.ptr(beta), eps, silu, _lib.ptr(out), _lib.ptr(part), gu.stream())
     torch.cuda.synchronize()
     xin = torch.cat([x0, x1], 1).float() if C1 else x0.float()

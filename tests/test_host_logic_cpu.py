@@ -1,0 +1,130 @@
+"""CPU (-m "not gpu"): host-side logic of the product (index tables, guidance planning, scheduler
+scalars, multi-GPU sharding) against the oracle.  No kernel is launched."""
+import itertools
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import difashion_amd as da
+from difashion_amd import dist as ddist
+from difashion_amd import pipeline
+from oracle import glue_ref, sched_ref
+
+
+def test_guidance_plan_and_replica_flags_match_oracle():
+    for sc, sh, sm, uh, um in itertools.product((1.0, 7.5), (1.0, 4.0), (1.0, 5.0), (True, False), (True, False)):
+        name, rep = glue_ref.cfg_plan(sc, sh, sm, uh, um)
+        assert pipeline.guidance_plan(sc, sh, sm, uh, um) == name
+        mode, br = pipeline._BRANCHES[name]
+        assert len(br) == rep and [tuple(b) for b in br] == [tuple(b) for b in glue_ref._BRANCHES[name]]
+
+
+@pytest.mark.parametrize("olists", [[[0, 0, 0, 0]], [[3, 0, 5, 6], [7, 8, 9, 0]], [[0, 0, 5, 6], [7, 0, 0, 0], [1, 2, 3, 4]]])
+def test_sampling_tables_reproduce_reference_sibling_sum(olists):
+    """Emulate dfh_mutual_reduce's contract in torch and compare with difashion.py:475-489 (oracle)."""
+    ol = torch.tensor(olists)
+    g = torch.Generator().manual_seed(1)
+    given = torch.randn(ol.numel(), 4, 8, 8, generator=g)
+    gen = torch.randn(int((ol == 0).sum()), 4, 8, 8, generator=g)
+    if gen.shape[0] == 0:
+        pytest.skip("nothing to generate")
+    tab, wt = pipeline.sampling_tables(ol)
+    out = []
+    for j in range(tab.shape[0]):
+        acc = torch.zeros_like(gen[0])
+        for k in range(tab.shape[1]):
+            v = int(tab[j, k])
+            acc = acc + wt[j, k] * (gen[v] if v >= 0 else given[-(v + 1)])
+        out.append(acc)
+    assert torch.equal(torch.stack(out), glue_ref.mutual_sum(ol, given, gen))
+
+
+def test_training_tables_reproduce_reference_sibling_mean():
+    g = torch.Generator().manual_seed(2)
+    noisy = torch.randn(8, 4, 8, 8, generator=g)
+    tab, wt = pipeline.training_tables(8, 4)
+    out = []
+    for j in range(8):
+        acc = torch.zeros_like(noisy[0])
+        for k in range(4):
+            acc = acc + wt[j, k] * noisy[int(tab[j, k])]
+        out.append(acc)
+    assert torch.equal(torch.stack(out), glue_ref.mutual_mean(noisy, 4))
+
+
+def test_ddim_scalars_reproduce_oracle_step():
+    s, r = da.DDIMScheduler(), sched_ref.DDIMRef()
+    s.set_timesteps(50)
+    r.set_timesteps(50)
+    assert s.timesteps.tolist() == r.timesteps.tolist() and s.order == 1 and s.init_noise_sigma == 1.0
+    assert torch.equal(s.alphas_cumprod, r.alphas_cumprod)
+    g = torch.Generator().manual_seed(3)
+    x, e = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 4, 8, 8, generator=g)
+    for t in (981, 481, 21, 1):
+        k = s.step_coef(t, 0.0)
+        x0 = (x - torch.tensor(k.sqrt_b_t) * e) / torch.tensor(k.sqrt_a_t)
+        prev = torch.tensor(k.sqrt_a_prev) * x0 + torch.tensor(k.dir_coef) * e
+        torch.testing.assert_close(prev, r.step(e, t, x, return_dict=False)[0], rtol=1e-6, atol=1e-6)
+    p, pr = da.PNDMScheduler(), sched_ref.PNDMRef()
+    p.set_timesteps(50)
+    pr.set_timesteps(50)
+    assert p.timesteps.tolist() == pr.timesteps.tolist() and len(p.timesteps) == 51
+
+
+def test_scheduler_config_roundtrip(tmp_path):
+    s = da.DDIMScheduler(prediction_type="v_prediction")
+    s.save_pretrained(str(tmp_path / "scheduler"))
+    s2 = da.DDIMScheduler.from_pretrained(str(tmp_path), subfolder="scheduler")
+    assert s2.config.prediction_type == "v_prediction" and s2.config.num_train_timesteps == 1000
+
+
+def test_shard_range_partitions_exactly():
+    for n, w in itertools.product((0, 1, 7, 8, 9, 64), (1, 2, 3, 8)):
+        got = [i for r in range(w) for i in ddist.shard_range(n, r, w)]
+        assert got == list(range(n))
+        sizes = [len(ddist.shard_range(n, r, w)) for r in range(w)]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, w, _ = ddist.init("gloo")
+    # 5 "outfits" of 2 generated items each; a stand-in denoiser (the product's compute needs the GPU)
+    n_outfits = 5
+    mine = ddist.shard_range(n_outfits, r, w)
+    lat = torch.stack([torch.full((4, 2, 2), float(o * 10 + j)) for o in mine for j in range(2)]) if len(mine) else torch.zeros(0, 4, 2, 2)
+    ddist.barrier()
+    elapsed = ddist.max_over_ranks(0.5 + r)               # slowest rank defines the step time
+    total = ddist.sum_over_ranks(float(len(mine)))
+    counts = [2 * len(ddist.shard_range(n_outfits, k, w)) for k in range(w)]
+    allv = ddist.gather_outfit_latents(lat, counts)
+    q.put((r, elapsed, total, allv[:, 0, 0, 0].tolist()))
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_sharding_and_reductions():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = [float(o * 10 + j) for o in range(5) for j in range(2)]
+    for r, elapsed, total, vals in res:
+        assert elapsed == 1.5 and total == 5.0 and vals == expect

@@ -193,7 +193,9 @@ def main():
             out["groupnorm_hbm_frac"] = round(gn["bytes"] / (gn["ms"] * 1e-3) / 1e9 / HBM_PEAK, 4)
     if not args.no_cpu_baseline and world == 1:
         try:
-            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            # host threads: the cores this process may run on, capped at 16 (the fp32 oracle's convs do not
+            # scale past that; 256 oversubscribed threads measured 30x slower)
+            out["cpu_baseline"] = cpu_baseline(min(16, len(os.sched_getaffinity(0))))
         except Exception as e:  # the GPU number must still be reported
             out["cpu_baseline"] = {"error": repr(e)}
     else:

@@ -16,6 +16,12 @@
 //     produced directly by the V projection GEMM's transposed epilogue (gemm.hip OUT_BF16_T), so
 //     nothing is transposed here.  The accumulator column is the lane's own query -> the softmax
 //     rescale and the final 1/l need no cross-lane traffic either; output is 8-byte bf16x4 stores.
+//   * K/V^T tiles are double-buffered in LDS: the next tile's global loads are issued into
+//     registers before the current tile's MFMAs and written to the other buffer afterwards
+//     (issue-early / write-late), so HBM/L2 latency hides under compute; one barrier per tile.
+//   * deferred max: the running max (and the O / l rescale that costs an AGPR round trip) is only
+//     updated when some query of the wave sees its tile max exceed the running max by more than
+//     RESCALE_THR (wave-uniform branch); probabilities then stay below 2^RESCALE_THR.
 //   * LDS tiles are XOR-swizzled on the 16-byte slot so ds_read_b128 fragment reads are
 //     conflict-free; the N x N score matrix never touches HBM.
 #include "dfh_common.h"
@@ -24,6 +30,7 @@
 namespace {
 
 constexpr int KV_TILE = 64;
+constexpr float RESCALE_THR = 6.0f;   // in log2 units of the scaled scores: p <= 2^6 between rescales
 
 template <int D> struct AttnGeom {
   static constexpr int KS = (D + 31) / 32;                       // 32-deep k-steps over the head dim
@@ -31,6 +38,8 @@ template <int D> struct AttnGeom {
   static constexpr int KSTR = D <= 64 ? 128 : (D <= 128 ? 256 : 512);  // K tile row stride (bytes)
   static constexpr int K_BYTES = KV_TILE * KSTR;
   static constexpr int V_BYTES = DF * 16 * 128;
+  static constexpr int NV = (DF * 128 + 255) / 256;              // V^T staging chunks per thread
+  static constexpr int BUF = K_BYTES + V_BYTES;
 };
 
 // rho = position of a key inside its 16-row MFMA tile (see header); swizzle bits derive from it
@@ -39,10 +48,8 @@ DFH_DEVICE int key_rho(int key) { return (((key >> 3) & 3) << 2) | (key & 3); }
 template <int D>
 __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   using G = AttnGeom<D>;
-  constexpr int KS = G::KS, DF = G::DF, KSTR = G::KSTR;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[G::K_BYTES + G::V_BYTES];
-  unsigned char* Ks = smem;
-  unsigned char* Vs = smem + G::K_BYTES;
+  constexpr int KS = G::KS, DF = G::DF, KSTR = G::KSTR, NV = G::NV;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
@@ -67,50 +74,80 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     }
   }
 
+  // ---- staging bookkeeping (fixed per thread): K chunk i -> (key, slot); V^T chunk i -> (row, slot)
+  int k_key[KS], k_slot[KS], k_lds[KS];
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    const int idx = tid + i * 256;
+    k_key[i] = idx / (KS * 4);
+    k_slot[i] = idx - k_key[i] * (KS * 4);
+    const int rho = key_rho(k_key[i]);
+    const int sw = (KSTR == 128) ? ((rho >> 1) & 7) : rho;
+    k_lds[i] = k_key[i] * KSTR + ((k_slot[i] ^ sw) << 4);
+  }
+  uint4 kreg[KS], vreg[NV];
+
+  auto load_tile = [&](int kv0) {   // global -> registers (zero beyond D / beyond Nk)
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      kreg[i] = uint4{0, 0, 0, 0};
+      if (kv0 + k_key[i] < a.Nk && k_slot[i] * 8 < D)
+        kreg[i] = *(const uint4*)(Kb + (long)(kv0 + k_key[i]) * a.ldk + k_slot[i] * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
+      const int row = idx >> 3, slot = idx & 7;
+      const int k0 = kv0 + slot * 8;
+      uint4 v = uint4{0, 0, 0, 0};
+      if (idx < DF * 128 && row < D && k0 < a.Nk) {
+        v = *(const uint4*)(Vb + (long)row * a.ldvt + k0);
+        if (k0 + 8 > a.Nk) {   // ragged tail (cross-attention, Nk = 77): zero the padding keys
+          const int valid = a.Nk - k0;
+          uint32_t* w = (uint32_t*)&v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (e >= valid) w[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+        }
+      }
+      vreg[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {   // registers -> swizzled LDS image
+    unsigned char* Ks = smem + buf * G::BUF;
+    unsigned char* Vs = Ks + G::K_BYTES;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) *(uint4*)(Ks + k_lds[i]) = kreg[i];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < DF * 128) {
+        const int row = idx >> 3, slot = idx & 7;
+        *(uint4*)(Vs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) = vreg[i];
+      }
+    }
+  };
+
   f32x4_t oacc[2][DF];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
     for (int f = 0; f < DF; ++f) oacc[qt][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-INFINITY, -INFINITY};
+  float m_run[2] = {-INFINITY, -INFINITY};   // running max in units of s*c (log2 domain)
   float l_run[2] = {0.f, 0.f};
-  const float c = a.scale * 1.44269504088896340736f;   // fold log2(e): p = 2^(s*c - m*c)
+  const float c = a.scale * 1.44269504088896340736f;   // fold log2(e): p = 2^(s*c - m)
 
-  for (int kv0 = 0; kv0 < a.Nk; kv0 += KV_TILE) {
-    __syncthreads();   // every wave finished reading the previous tile
-    // ---- stage K tile: 64 keys x KS*4 16-byte slots (zero beyond D / beyond Nk)
-#pragma unroll
-    for (int i = 0; i < KS; ++i) {
-      const int idx = tid + i * 256;
-      const int key = idx / (KS * 4), slot = idx - key * (KS * 4);
-      uint4 v = uint4{0, 0, 0, 0};
-      if (kv0 + key < a.Nk && slot * 8 < D) v = *(const uint4*)(Kb + (long)(kv0 + key) * a.ldk + slot * 8);
-      const int rho = key_rho(key);
-      const int sw = (KSTR == 128) ? ((rho >> 1) & 7) : rho;
-      *(uint4*)(Ks + key * KSTR + ((slot ^ sw) << 4)) = v;
-    }
-    // ---- stage V^T tile: DF*16 rows (head-dim) x 8 slots (64 keys)
-#pragma unroll
-    for (int i = 0; i < (DF * 128 + 255) / 256; ++i) {
-      const int idx = tid + i * 256;
-      if (idx < DF * 128) {
-        const int row = idx >> 3, slot = idx & 7;
-        const int k0 = kv0 + slot * 8;
-        uint4 v = uint4{0, 0, 0, 0};
-        if (row < D && k0 < a.Nk) {
-          v = *(const uint4*)(Vb + (long)row * a.ldvt + k0);
-          if (k0 + 8 > a.Nk) {   // ragged tail (cross-attention, Nk = 77): zero the padding keys
-            const int valid = a.Nk - k0;
-            uint32_t* w = (uint32_t*)&v;
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (e >= valid) w[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
-          }
-        }
-        *(uint4*)(Vs + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) = v;
-      }
-    }
-    __syncthreads();
+  const int ntiles = (a.Nk + KV_TILE - 1) / KV_TILE;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * KV_TILE;
+    const bool more = t + 1 < ntiles;
+    if (more) load_tile(kv0 + KV_TILE);       // in flight while this tile computes
+    const unsigned char* Ks = smem + (t & 1) * G::BUF;
+    const unsigned char* Vs = Ks + G::K_BYTES;
 
     // ---- S^T tiles: 4 x (16 keys) for each of the wave's two query tiles
     f32x4_t s[2][4];
@@ -132,44 +169,55 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     bf16x8_t pf[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
+      float sc[4][4];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[tt][r] = s[qt][tt][r] * c;
+      if (ragged) {   // kernel-uniform: only the last tile of a ragged key range (cross-attention, Nk = 77)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kv0 + (tt >> 1) * 32 + fg * 8 + (tt & 1) * 4 + r;
+            if (key >= a.Nk) sc[tt][r] = -INFINITY;
+          }
+      }
       float mx = -INFINITY;
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (ragged) {
-            const int key = kv0 + (tt >> 1) * 32 + fg * 8 + (tt & 1) * 4 + r;
-            if (key >= a.Nk) s[qt][tt][r] = -INFINITY;
-          }
-          mx = fmaxf(mx, s[qt][tt][r]);
-        }
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[tt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[qt], mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * c);
-      m_run[qt] = m_new;
-      const float mc = m_new * c;
+      // deferred max (wave-uniform): rescale only if some query's max grew by more than the threshold
+      if (__any(!(mx - m_run[qt] <= RESCALE_THR))) {
+        const float m_new = fmaxf(m_run[qt], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+        m_run[qt] = m_new;
+        l_run[qt] *= alpha;
+#pragma unroll
+        for (int f = 0; f < DF; ++f) {
+          oacc[qt][f][0] *= alpha; oacc[qt][f][1] *= alpha; oacc[qt][f][2] *= alpha; oacc[qt][f][3] *= alpha;
+        }
+      }
+      const float mr = m_run[qt];
       float psum = 0.f;
-      float p[4][4];
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p[tt][r] = __builtin_amdgcn_exp2f(s[qt][tt][r] * c - mc);
-          psum += p[tt][r];
+          sc[tt][r] = __builtin_amdgcn_exp2f(sc[tt][r] - mr);
+          psum += sc[tt][r];
         }
-      l_run[qt] = l_run[qt] * alpha + psum;
-#pragma unroll
-      for (int f = 0; f < DF; ++f) {
-        oacc[qt][f][0] *= alpha; oacc[qt][f][1] *= alpha; oacc[qt][f][2] *= alpha; oacc[qt][f][3] *= alpha;
-      }
+      l_run[qt] += psum;
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch) {
         uint4 w;
-        w.x = pack2bf(p[2 * ch][0], p[2 * ch][1]);
-        w.y = pack2bf(p[2 * ch][2], p[2 * ch][3]);
-        w.z = pack2bf(p[2 * ch + 1][0], p[2 * ch + 1][1]);
-        w.w = pack2bf(p[2 * ch + 1][2], p[2 * ch + 1][3]);
+        w.x = pack2bf(sc[2 * ch][0], sc[2 * ch][1]);
+        w.y = pack2bf(sc[2 * ch][2], sc[2 * ch][3]);
+        w.z = pack2bf(sc[2 * ch + 1][0], sc[2 * ch + 1][1]);
+        w.w = pack2bf(sc[2 * ch + 1][2], sc[2 * ch + 1][3]);
         pf[qt][ch] = __builtin_bit_cast(bf16x8_t, w);
       }
     }
@@ -184,6 +232,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         oacc[1][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1][ch], oacc[1][f], 0, 0, 0);
       }
     }
+    if (more) store_tile((t + 1) & 1);   // the other buffer: last read one barrier ago
+    __syncthreads();
   }
 
   // ---- normalise and store: lane holds O[q = fr][d = f*16 + fg*4 + r]
@@ -211,10 +261,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 
 template <int D>
 int launch(const AttnArgs& a, hipStream_t stream) {
+  constexpr int lds = 2 * AttnGeom<D>::BUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attention_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
   dim3 grid((a.Nq + 127) / 128, a.H, a.B);
   dfh::ProfScope ps(dfh::PC_ATTN, 4.0 * a.B * a.H * (double)a.Nq * a.Nk * D,
                     2.0 * a.B * a.H * D * (2.0 * a.Nq + 2.0 * a.Nk), stream);
-  hipLaunchKernelGGL(attention_kernel<D>, grid, dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(attention_kernel<D>, grid, dim3(256), lds, stream, a);
   return dfh::check_launch("attention_kernel");
 }
 

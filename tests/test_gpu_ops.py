@@ -242,20 +242,20 @@ def test_mutual_reduce_sampling_and_training_bit_exact():
     L = 4 * 16 * 16
     given = rnd(12, 4, 16, 16, seed=52)
     gen = rnd(6, 4, 16, 16, seed=53)
-    tab, wt = sampling_tables(olists)
+    tab, wt = (t.to(DEV) for t in sampling_tables(olists))     # named: never take pointers of temporaries
     out = torch.empty((6, L), dtype=torch.bfloat16, device=DEV)
     out32 = torch.empty((6, L), device=DEV)
-    _lib.call("dfh_mutual_reduce", _lib.ptr(gen), _lib.ptr(given), _lib.ptr(tab.to(DEV)), _lib.ptr(wt.to(DEV)),
+    _lib.call("dfh_mutual_reduce", _lib.ptr(gen), _lib.ptr(given), _lib.ptr(tab), _lib.ptr(wt),
               _lib.ptr(out), _lib.ptr(out32), 6, 4, L, gu.stream())
     torch.cuda.synchronize()
     ref = glue_ref.mutual_sum(olists, given.cpu(), gen.cpu())
     assert torch.equal(out32.cpu().view_as(ref), ref)
     assert torch.equal(out.cpu().view_as(ref), bf(ref))
-    tab, wt = training_tables(8, 4)
+    tab, wt = (t.to(DEV) for t in training_tables(8, 4))
     noisy = rnd(8, 4, 16, 16, seed=54)
     o32 = torch.empty((8, L), device=DEV)
     o16 = torch.empty((8, L), dtype=torch.bfloat16, device=DEV)
-    _lib.call("dfh_mutual_reduce", _lib.ptr(noisy), None, _lib.ptr(tab.to(DEV)), _lib.ptr(wt.to(DEV)), _lib.ptr(o16),
+    _lib.call("dfh_mutual_reduce", _lib.ptr(noisy), None, _lib.ptr(tab), _lib.ptr(wt), _lib.ptr(o16),
               _lib.ptr(o32), 8, 4, L, gu.stream())
     torch.cuda.synchronize()
     ref = glue_ref.mutual_mean(noisy.cpu(), 4)

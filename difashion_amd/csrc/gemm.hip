@@ -11,11 +11,15 @@
 //   * global -> LDS by global_load_lds_dwordx4 (no VGPR round trip); LDS image is lane-linear,
 //     bank conflicts are removed by XOR-swizzling the 16-byte slot on the SOURCE address and on
 //     the fragment read (guide rule 21): slot' = slot ^ ((row >> 1) & 7) for 128-byte rows.
+//   * N-stage LDS ring: loads for k-step t+NSTAGE-1 are issued while k-step t computes; a wave waits
+//     with a COUNTED s_waitcnt vmcnt (never a full drain in steady state) and the workgroup meets at one
+//     raw s_barrier per k-step, so LDS-DMA stays in flight across barriers (guide T3/T4).
+//     Main tile 256 x {160,128} x 64 with 8 waves (4x2) and 3 stages = 156/144 KiB of the CU's 160 KiB;
+//     a 128-row / 4-wave / 2-stage variant (72 KiB, 2 workgroups per CU) covers narrow or tiny shapes.
 //   * the weight operand is fed as MFMA "A" so each lane ends up with 4 consecutive output
 //     channels of one pixel -> 8-byte packed bf16 stores and float4 bias loads.
-//   * 64-wide wavefronts, 4 waves as 2x2, tile 128 x {160,128,64}; 72 KiB LDS (double buffer)
-//     -> 2 workgroups per CU; XCD-aware tile order; split-K through fp32 slabs + reduce kernel
-//     for the 8x8 / 16x16 levels whose M is too small to fill 256 CUs.
+//   * XCD-aware tile order; split-K through fp32 slabs + a deterministic reduce kernel for the
+//     8x8 / 16x16 levels whose M is too small to fill 256 CUs.
 #include "gemm.h"
 
 #include <algorithm>
@@ -24,8 +28,6 @@
 namespace {
 
 constexpr int BK = 64;            // k-step depth (bf16 elements) = one 128-byte LDS row
-constexpr int NW = 4;             // waves per workgroup
-constexpr int NT = NW * 64;
 
 struct KIter {                    // which 64-deep slice of which K segment a k-step covers
   int seg;                        // 0..ntaps-1 conv taps, then plain segments
@@ -63,23 +65,27 @@ DFH_DEVICE void kiter_next(const GemmArgs& a, KIter& it) {
   }
 }
 
+// counted wait on this wave's outstanding vector-memory operations (LDS-DMA pieces)
+template <int N> DFH_DEVICE void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, bool GLDS>
-__global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs a) {
-  constexpr int WM = 2, WN = 2;
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
+  constexpr int NWV = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;       // per-wave output tile
   constexpr int FM = TM / 16, FN = TN / 16;       // 16x16 fragments per wave
-  constexpr int IA = BM / (8 * NW), IB = BN / (8 * NW);  // 1-KiB staging pieces per wave
+  constexpr int PA = BM / 8, PB = BN / 8;         // 1-KiB staging pieces (8 rows x 128 B) per stage
+  constexpr int IA = (PA + NWV - 1) / NWV, IB = (PB + NWV - 1) / NWV;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  static_assert(BM % 32 == 0 && BN % 32 == 0, "tile");
+  static_assert(TM % 16 == 0 && TN % 16 == 0 && BM % 8 == 0 && BN % 8 == 0 && NWV % 2 == 0 && NSTAGE >= 2 && NSTAGE <= 4, "tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   const int ntn = (a.N + BN - 1) / BN;
   const int ntm = (a.M + BM - 1) / BM;
@@ -93,91 +99,77 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs a) {
   const int ks_end = min(a.ksteps, ks_begin + per);
   const int nk = ks_end - ks_begin;
 
-  // ---- per-thread staging bookkeeping: piece i of this wave covers tile rows (i*NW+wave)*8 + lane/8,
+  // ---- per-thread staging bookkeeping: piece p = i*NWV + wave covers tile rows p*8 + lane/8,
   //      16-byte slot lane%8; the source slot is swizzled, the LDS image stays lane-linear.
   const int srow = lane >> 3;
-  const int sslot = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));   // == slot ^ ((row>>1)&7)
-  int a_pix[IA], a_y[IA], a_x[IA];            // conv: batch pixel base, (oy*stride-1, ox*stride-1); plain: row
+  const int sslot = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));   // == slot ^ ((row>>1)&7), NWV even
+  int a_pix[IA], a_y[IA], a_x[IA], a_bbase[IA];   // conv: (oy*stride-1, ox*stride-1), batch pixel base; plain: row
   const int HWo = a.Hout * a.Wout;
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
-    const int m = m0 + (i * NW + wave) * 8 + srow;
-    if (m < a.M) {
+    const int m = m0 + (i * NWV + wave) * 8 + srow;
+    a_pix[i] = -1; a_y[i] = 0; a_x[i] = 0; a_bbase[i] = 0;
+    if (m < a.M && i * NWV + wave < PA) {
       a_pix[i] = m;
       if (a.ntaps) {
         const int b = m / HWo, rem = m - b * HWo;
         const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
-        a_y[i] = oy * a.stride - 1; a_x[i] = ox * a.stride - 1;   // plain segments still index by output row m
-      } else { a_y[i] = 0; a_x[i] = 0; }
-    } else { a_pix[i] = -1; a_y[i] = 0; a_x[i] = 0; }
+        a_y[i] = oy * a.stride - 1; a_x[i] = ox * a.stride - 1;
+        a_bbase[i] = b * a.Hin * a.Win;
+      }
+    }
   }
-  int a_bbase[IA];
-#pragma unroll
-  for (int i = 0; i < IA; ++i) {
-    a_bbase[i] = 0;
-    if (a.ntaps && a_pix[i] >= 0) a_bbase[i] = (a_pix[i] / HWo) * a.Hin * a.Win;
-  }
-  long w_row[IB];
+  int w_row[IB];                                  // element offset of the W row (fits 31 bits), -1 = beyond N
 #pragma unroll
   for (int i = 0; i < IB; ++i) {
-    const int n = n0 + (i * NW + wave) * 8 + srow;
-    w_row[i] = (n < a.N) ? (long)n * a.ldw : -1;
+    const int n = n0 + (i * NWV + wave) * 8 + srow;
+    w_row[i] = (n < a.N) ? n * a.ldw : -1;
   }
   const int Hv = a.ups ? a.Hin * 2 : a.Hin, Wv = a.ups ? a.Win * 2 : a.Win;  // virtual (upsampled) input dims
+  // LDS-DMA pieces per stage and wave: waves below PB % NWV issue one more B piece (wave-uniform)
+  constexpr int N_LO = PA / NWV + PB / NWV, N_HI = N_LO + 1, PB_REM = PB % NWV;
+  static_assert(PA % NWV == 0, "A pieces must divide evenly over the waves");
+  const bool hi_wave = wave < PB_REM;
 
-  uint4 stage_regs[GLDS ? 1 : IA + IB];
-
+  const unsigned cc = (unsigned)a.conv_c;
+  auto glds = [&](const bf16_t* src, unsigned char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  // One stage = this wave's pieces of the A tile (gathered) and the W tile.  Straight-line code:
+  // predicates select between the real address and the zero page, the segment kind is the only branch.
   auto issue_stage = [&](const KIter& it, int buf) {
-    unsigned char* As = smem + buf * STAGE;
+    unsigned char* As = smem + buf * STAGE + wave * 1024;
     unsigned char* Bs = As + A_BYTES;
     const int ch = it.c0 + sslot * 8;                 // channel of this lane's 16-byte chunk
     const bool kin = ch < it.seglen;
-    int ky = 0, kx = 0;
-    if (it.seg < a.ntaps) { ky = it.seg / 3; kx = it.seg - ky * 3; }
+    if (it.seg < a.ntaps) {
+      const int ky = it.seg / 3, kx = it.seg - ky * 3;
 #pragma unroll
-    for (int i = 0; i < IA; ++i) {
-      const bf16_t* src = a.zero;
-      if (kin && a_pix[i] >= 0) {
-        if (it.seg < a.ntaps) {
-          const int yy = a_y[i] + ky, xx = a_x[i] + kx;
-          if ((unsigned)yy < (unsigned)Hv && (unsigned)xx < (unsigned)Wv) {
-            const int sy = a.ups ? (yy >> 1) : yy, sx = a.ups ? (xx >> 1) : xx;
-            src = a.conv_src + ((long)(a_bbase[i] + sy * a.Win + sx) * a.conv_c + ch);
-          }
-        } else {
-          const int ps = it.seg - a.ntaps;
-          src = a.p_src[ps] + ((long)a_pix[i] * a.p_c[ps] + ch);
-        }
+      for (int i = 0; i < IA; ++i) {
+        const int yy = a_y[i] + ky, xx = a_x[i] + kx;
+        const bool ok = kin & (a_pix[i] >= 0) & ((unsigned)yy < (unsigned)Hv) & ((unsigned)xx < (unsigned)Wv);
+        const int sy = a.ups ? (yy >> 1) : yy, sx = a.ups ? (xx >> 1) : xx;
+        const unsigned off = (unsigned)(a_bbase[i] + sy * a.Win + sx) * cc + (unsigned)ch;
+        glds(ok ? a.conv_src + off : a.zero, As + i * NWV * 1024);
       }
-      if constexpr (GLDS) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(As + (i * NW + wave) * 1024),
-                                         16, 0, 0);
-      } else {
-        stage_regs[i] = *(const uint4*)src;
+    } else {
+      const int ps = it.seg - a.ntaps;
+      const bf16_t* base = a.p_src[ps];
+      const unsigned pc = (unsigned)a.p_c[ps];
+#pragma unroll
+      for (int i = 0; i < IA; ++i) {
+        const bool ok = kin & (a_pix[i] >= 0);
+        const unsigned off = (unsigned)a_pix[i] * pc + (unsigned)ch;
+        glds(ok ? base + off : a.zero, As + i * NWV * 1024);
       }
     }
+    const unsigned wc = (unsigned)(it.wcol + sslot * 8);
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-      const bf16_t* src = a.zero;
-      if (kin && w_row[i] >= 0) src = a.W + (w_row[i] + it.wcol + sslot * 8);
-      if constexpr (GLDS) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(Bs + (i * NW + wave) * 1024),
-                                         16, 0, 0);
-      } else {
-        stage_regs[IA + i] = *(const uint4*)src;
-      }
-    }
-  };
-  auto commit_stage = [&](int buf) {   // register-staged variant only: write the pieces to LDS
-    if constexpr (!GLDS) {
-      unsigned char* As = smem + buf * STAGE;
-      unsigned char* Bs = As + A_BYTES;
-#pragma unroll
-      for (int i = 0; i < IA; ++i) *(uint4*)(As + (i * NW + wave) * 1024 + lane * 16) = stage_regs[i];
-#pragma unroll
-      for (int i = 0; i < IB; ++i) *(uint4*)(Bs + (i * NW + wave) * 1024 + lane * 16) = stage_regs[IA + i];
+      if (i * NWV + wave >= PB) continue;             // wave-uniform
+      const bool ok = kin & (w_row[i] >= 0);
+      glds(ok ? a.W + ((unsigned)w_row[i] + wc) : a.zero, Bs + i * NWV * 1024);
     }
   };
 
@@ -191,15 +183,32 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs a) {
 
   if (nk > 0) {
     KIter it = kiter_at(a, ks_begin);
-    issue_stage(it, 0);
-    commit_stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
+    int issued = 0;
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) {
+      if (s < nk) {
+        if (s) kiter_next(a, it);
+        issue_stage(it, s);
+        ++issued;
+      }
+    }
+    int buf = 0;
     for (int t = 0; t < nk; ++t) {
-      const bool more = (t + 1 < nk);
-      if (more) { kiter_next(a, it); issue_stage(it, cur ^ 1); }
-      const unsigned char* As = smem + cur * STAGE;
+      // stages beyond t already in flight may stay in flight: wait only for stage t's pieces
+      const int ahead = issued - 1 - t;               // 0 .. NSTAGE-2, block-uniform
+      if (ahead == 0) wait_vmcnt<0>();
+      else if (ahead == 1) { if (hi_wave) wait_vmcnt<N_HI>(); else wait_vmcnt<N_LO>(); }
+      else { if (hi_wave) wait_vmcnt<2 * N_HI>(); else wait_vmcnt<2 * N_LO>(); }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();          // stage t visible to all waves; all waves done with k-step t-1
+      asm volatile("" ::: "memory");
+      if (issued < nk) {                      // refill the buffer k-step t-1 just released
+        kiter_next(a, it);
+        int nb = buf - 1; if (nb < 0) nb += NSTAGE;
+        issue_stage(it, nb);
+        ++issued;
+      }
+      const unsigned char* As = smem + buf * STAGE;
       const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -221,10 +230,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(const GemmArgs a) {
             // weights as MFMA-A: D[row = channel (fg*4+r)][col = pixel (fr)]
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       }
-      if (more) commit_stage(cur ^ 1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      cur ^= 1;
+      if (++buf == NSTAGE) buf = 0;
     }
   }
 
@@ -350,18 +356,37 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(const GemmArgs a) {
   }
 }
 
-template <int BM, int BN, bool GLDS>
+template <int BM, int BN, int WM, int WN, int NSTAGE>
 int launch_tile(const GemmArgs& a, hipStream_t stream) {
-  constexpr int lds = 2 * (BM + BN) * BK * 2;
+  constexpr int lds = NSTAGE * (BM + BN) * BK * 2;
+  static_assert(lds <= 160 * 1024, "LDS ring exceeds the CU's 160 KiB");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, GLDS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   dim3 grid(ntm * ntn, 1, a.ksplit);
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, GLDS>), grid, dim3(NT), lds, stream, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE>), grid, dim3(WM * WN * 64), lds, stream, a);
   return dfh::check_launch("gemm_bf16_kernel");
+}
+
+struct TileInfo { int bm, bn; };
+// variant ids (force_tile - 1):
+//   0: 256x160 8 waves 3 stages   1: 256x128 8 waves 3 stages   2: 128x64 4 waves 3 stages
+//   3: 128x160 4 waves 2 stages   4: 128x128 4 waves 2 stages
+constexpr TileInfo kTiles[5] = {{256, 160}, {256, 128}, {128, 64}, {128, 160}, {128, 128}};
+constexpr int kNumTiles = 5;
+
+int launch_variant(int tile, const GemmArgs& a, hipStream_t s) {
+  switch (tile) {
+    case 0: return launch_tile<256, 160, 4, 2, 3>(a, s);
+    case 1: return launch_tile<256, 128, 4, 2, 3>(a, s);
+    case 2: return launch_tile<128, 64, 2, 2, 3>(a, s);
+    case 3: return launch_tile<128, 160, 2, 2, 2>(a, s);
+    default: return launch_tile<128, 128, 2, 2, 2>(a, s);
+  }
 }
 
 }  // namespace
@@ -374,20 +399,22 @@ int gemm_count_ksteps(const GemmArgs& a) {
   return n;
 }
 
-// tile ids: 0 = 128x160, 1 = 128x128, 2 = 128x64
 int gemm_pick_split(const GemmArgs& a, int* tile_out) {
+  // column tile: 160 when it divides N (320/640/1280/...), else 128 (GEGLU needs 32-aligned pairs), 64 for N <= 64
+  const bool geglu = a.act == ACT_GEGLU;
+  const bool n160 = !geglu && (a.N % 160 == 0 || (a.N % 128 != 0 && a.N > 128));
+  // Measured on MI355X (scripts/gemm_microbench.py): the 128-row / 4-wave / 2-stage variants at two
+  // workgroups per CU beat the 256-row / 8-wave / 3-stage ring on every U-Net shape except the 8x8 level.
   int tile;
-  if (a.act == ACT_GEGLU) tile = 1;
-  else if (a.N % 160 == 0) tile = 0;
-  else if (a.N % 128 == 0 || a.N > 320) tile = 1;
-  else if (a.N <= 64) tile = 2;
-  else tile = (a.N <= 128) ? 1 : 0;
-  const int bn = tile == 0 ? 160 : (tile == 1 ? 128 : 64);
-  const int blocks = ((a.M + 127) / 128) * ((a.N + bn - 1) / bn);
+  if (a.N <= 64 && !geglu) tile = 2;
+  else if (a.M > 128 && a.M <= 1024 && gemm_count_ksteps(a) >= 64) tile = n160 ? 0 : 1;
+  else tile = n160 ? 3 : 4;
+  const TileInfo ti = kTiles[tile];
+  const int blocks = ((a.M + ti.bm - 1) / ti.bm) * ((a.N + ti.bn - 1) / ti.bn);
   const int ksteps = gemm_count_ksteps(a);
   int split = 1;
-  if (a.act != ACT_GEGLU && blocks < 192 && ksteps >= 16) {
-    split = std::min({(512 + blocks - 1) / blocks, ksteps / 8, 64});
+  if (!geglu && blocks < 160 && ksteps >= 16) {
+    split = std::min({(256 + blocks - 1) / blocks, ksteps / 8, 64});
     if (split < 1) split = 1;
   }
   if (tile_out) *tile_out = tile;
@@ -401,6 +428,7 @@ size_t gemm_partial_floats(const GemmArgs& a) {
 }
 
 int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split, int force_glds) {
+  (void)force_glds;   // staging is always LDS-DMA; the flag is kept for ABI stability
   DFH_REQUIRE(a.M > 0 && a.N > 0, "empty GEMM");
   DFH_REQUIRE(a.N % 4 == 0, "N must be a multiple of 4");
   DFH_REQUIRE(a.ntaps == 0 || a.ntaps == 9, "ntaps must be 0 or 9");
@@ -412,33 +440,25 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
   a.ksteps = gemm_count_ksteps(a);
   int tile;
   int split = gemm_pick_split(a, &tile);
-  if (force_tile > 0) tile = force_tile - 1;
+  if (force_tile > 0) { DFH_REQUIRE(force_tile <= kNumTiles, "unknown tile variant"); tile = force_tile - 1; }
   if (force_split > 0) split = force_split;
   if (a.act == ACT_GEGLU) {
-    DFH_REQUIRE(a.N % 32 == 0 && tile != 0 && split == 1, "GEGLU needs N % 32 == 0, a 2^k tile and no split-K");
+    DFH_REQUIRE(a.N % 32 == 0 && kTiles[tile].bn != 160 && split == 1,
+                "GEGLU needs N % 32 == 0, a 64/128-wide tile and no split-K");
     DFH_REQUIRE(a.out_mode == OUT_BF16 && !a.resid && !a.rowvec, "GEGLU epilogue is bias-only, bf16 out");
   }
   split = std::min(split, a.ksteps);
   a.ksplit = split;
   if (split > 1) DFH_REQUIRE(a.partial != nullptr, "split-K needs a partial buffer");
-  const bool glds = force_glds < 0 ? true : (force_glds != 0);
   int rc;
   {
-  // algorithmic work of this launch: 2*M*N*K over the REAL K (padding excluded); bytes = each operand once + output
-  double kreal = (double)a.ntaps * a.conv_c;
-  double abytes = a.ntaps ? (double)(a.M / (a.Hout * a.Wout)) * a.Hin * a.Win * a.conv_c * 2.0 : 0.0;
-  for (int i = 0; i < a.nplain; ++i) { kreal += a.p_c[i]; abytes += (double)a.M * a.p_c[i] * 2.0; }
-  const double obytes = (double)a.M * (a.act == ACT_GEGLU ? a.N / 2 : a.N) * ((a.out_mode == OUT_F32 || a.out_mode == OUT_F32_T) ? 4.0 : 2.0);
-  ProfScope ps(a.ntaps ? PC_CONV3 : PC_LINEAR, 2.0 * a.M * a.N * kreal, abytes + (double)a.N * kreal * 2.0 + obytes, stream);
-  if (glds) {
-    rc = tile == 0 ? launch_tile<128, 160, true>(a, stream)
-       : tile == 1 ? launch_tile<128, 128, true>(a, stream)
-                   : launch_tile<128, 64, true>(a, stream);
-  } else {
-    rc = tile == 0 ? launch_tile<128, 160, false>(a, stream)
-       : tile == 1 ? launch_tile<128, 128, false>(a, stream)
-                   : launch_tile<128, 64, false>(a, stream);
-  }
+    // algorithmic work of this launch: 2*M*N*K over the REAL K (padding excluded); bytes = each operand once + output
+    double kreal = (double)a.ntaps * a.conv_c;
+    double abytes = a.ntaps ? (double)(a.M / (a.Hout * a.Wout)) * a.Hin * a.Win * a.conv_c * 2.0 : 0.0;
+    for (int i = 0; i < a.nplain; ++i) { kreal += a.p_c[i]; abytes += (double)a.M * a.p_c[i] * 2.0; }
+    const double obytes = (double)a.M * (a.act == ACT_GEGLU ? a.N / 2 : a.N) * ((a.out_mode == OUT_F32 || a.out_mode == OUT_F32_T) ? 4.0 : 2.0);
+    ProfScope ps(a.ntaps ? PC_CONV3 : PC_LINEAR, 2.0 * a.M * a.N * kreal, abytes + (double)a.N * kreal * 2.0 + obytes, stream);
+    rc = launch_variant(tile, a, stream);
   }
   if (rc) return rc;
   if (split > 1) {

@@ -57,25 +57,26 @@ def run(name, M, N, K, conv=None, bias=True, resid=True, out_mode=0, act=0, tile
 
 if __name__ == "__main__":
     print(_lib.raw().dfh_build_info().decode())
-    for bias, resid in ((True, True), (False, False)):
-        tag = "b+r" if bias else "bare"
-        run(f"linear 64^2 C320 {tag}", 65536, 320, 320, bias=bias, resid=resid)
-        run(f"linear 64^2 C320 fp32out {tag}", 65536, 320, 320, bias=bias, resid=resid, out_mode=2)
-    run("linear 64^2 C320 K1280 (ff2)", 65536, 320, 1280)
-    run("linear 64^2 qk N640", 65536, 640, 320, resid=False, bias=False)
-    run("geglu 64^2 N2560", 65536, 2560, 320, act=4)
-    run("linear 32^2 C640", 16384, 640, 640)
-    run("linear 16^2 C1280", 4096, 1280, 1280)
-    run("cross kv 1232x320x768", 1232, 320, 768, bias=False, resid=False)
+    shapes = [
+        ("linear 64^2 C320", dict(M=65536, N=320, K=320)),
+        ("linear 64^2 C320 K1280 (ff2)", dict(M=65536, N=320, K=1280)),
+        ("linear 64^2 qk N640", dict(M=65536, N=640, K=320, resid=False, bias=False)),
+        ("linear 32^2 C640", dict(M=16384, N=640, K=640)),
+        ("linear 16^2 C1280", dict(M=4096, N=1280, K=1280)),
+        ("linear 8^2 C1280", dict(M=1024, N=1280, K=1280)),
+        ("cross kv 1232x320x768", dict(M=1232, N=320, K=768, bias=False, resid=False)),
+        ("conv 320->320 @64", dict(M=65536, N=320, K=0, conv=(16, 64, 320, 1, 0), resid=False)),
+        ("conv 960->320 @64", dict(M=65536, N=320, K=0, conv=(16, 64, 960, 1, 0), resid=False)),
+        ("conv 640->640 @32", dict(M=16384, N=640, K=0, conv=(16, 32, 640, 1, 0), resid=False)),
+        ("conv 1280->1280 @16", dict(M=4096, N=1280, K=0, conv=(16, 16, 1280, 1, 0), resid=False)),
+        ("conv 1280->1280 @8", dict(M=1024, N=1280, K=0, conv=(16, 8, 1280, 1, 0), resid=False)),
+    ]
+    for name, kw in shapes:
+        for tile, tag in ((0, "auto"), (1, "256x160r3"), (4, "128x160s2")):
+            run(f"{name} [{tag}]", tile=tile, **kw)
+    run("geglu 64^2 N2560 [auto]", 65536, 2560, 320, act=4)
+    run("geglu 64^2 N2560 [128x128s2]", 65536, 2560, 320, act=4, tile=5)
+    run("geglu 32^2 N5120 [auto]", 16384, 5120, 640, act=4)
     run("temb 16x20480x1280", 16, 20480, 1280, resid=False, out_mode=2)
-    run("conv 320->320 @64", 65536, 320, 0, conv=(16, 64, 320, 1, 0), resid=False)
-    run("conv 640->640 @32", 16384, 640, 0, conv=(16, 32, 640, 1, 0), resid=False)
-    run("conv 1280->1280 @16", 4096, 1280, 0, conv=(16, 16, 1280, 1, 0), resid=False)
-    run("conv 1280->1280 @8", 1024, 1280, 0, conv=(16, 8, 1280, 1, 0), resid=False)
-    run("conv 960->320 @64", 65536, 320, 0, conv=(16, 64, 960, 1, 0), resid=False)
     run("conv 8->320 @64 (conv_in)", 65536, 320, 0, conv=(16, 64, 8, 1, 0), resid=False)
     run("conv 320->4 @64 (conv_out)", 65536, 4, 0, conv=(16, 64, 320, 1, 0), resid=False)
-    for t in (1, 2):
-        run(f"conv 320->320 @64 tile{t}", 65536, 320, 0, conv=(16, 64, 320, 1, 0), resid=False, tile=t)
-    run("conv 320->320 @64 regstage", 65536, 320, 0, conv=(16, 64, 320, 1, 0), resid=False, glds=0)
-    run("linear 64^2 C320 regstage", 65536, 320, 320, glds=0)

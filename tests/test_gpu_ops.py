@@ -16,8 +16,8 @@ pytestmark = pytest.mark.gpu
 
 
 # ----------------------------------------------------------------------------- GEMM (linear / 1x1 conv)
-@pytest.mark.parametrize("tile", [1, 2, 3])
-@pytest.mark.parametrize("glds", [1, 0])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])     # every tile / pipeline-depth variant of gemm.hip
+@pytest.mark.parametrize("glds", [1])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (128, 160, 64), (77 * 3, 64, 768), (16, 1280, 200), (4, 256, 2048)])
 def test_gemm_plain(tile, glds, M, N, K):
     a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05))
@@ -99,7 +99,7 @@ def test_gemm_transposed_outputs():
     (64, 4, 16, 1, 0),      # conv_out shape class
     (128, 128, 2, 1, 0),    # 2x2 level of the tiny configs: every tap hits padding somewhere
 ])
-@pytest.mark.parametrize("glds", [1, 0])
+@pytest.mark.parametrize("glds", [0, 1, 4])   # here: forced tile variant (0 = heuristic, 1 = 256x160 ring, 4 = 128x160 2-stage)
 def test_conv3x3(cin, cout, H, stride, ups, glds):
     B = 2
     x = bf(rnd(B, cin, H, H, seed=20))
@@ -107,7 +107,7 @@ def test_conv3x3(cin, cout, H, stride, ups, glds):
     bias = rnd(cout, seed=22)
     Ho = H * 2 if ups else H // stride
     out = gu.gemm(M=B * Ho * Ho, N=cout, W=gu.pack_conv(w), ldw=9 * cin, conv_src=gu.nhwc(x), conv_c=cin, batch=B,
-                  Hin=H, Win=H, stride=stride, upsample=ups, bias=bias, force_glds=glds)
+                  Hin=H, Win=H, stride=stride, upsample=ups, bias=bias, force_tile=glds)
     xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
     ref = F.conv2d(xin, bf(w).float(), bias, stride=stride, padding=1)
     gu.assert_close_bf16(gu.nchw(out.view(B, Ho, Ho, cout)), ref, f"conv {cin}->{cout}@{H} s{stride} u{ups}")

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
 
   const bf16_t* Qb = a.Q + (long)b * a.Nq * a.ldq + h * D;
   const bf16_t* Kb = a.K + (long)b * a.Nk * a.ldk + h * D;
-  const bf16_t* Vb = a.Vt + ((long)b * a.H * D + (long)h * D) * a.ldvt;
+  const bf16_t* Vb = a.Vt + (long)b * (a.vt_bstride ? a.vt_bstride : (long)a.H * D * a.ldvt) + (long)h * D * a.ldvt;
 
   // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q = fr][d = ks*32 + fg*8 ..+8]
   bf16x8_t qf[2][KS];

@@ -48,9 +48,9 @@ struct ResL {
   Vec n1w, n1b, b1, n2w, n2b, b2; Mat w1, w2;
 };
 struct AttL {
-  int C = 0, heads = 0;
+  int C = 0, heads = 0, x_off = 0;   // x_off: this layer's row offset in the batched cross K / V matrices
   Vec nw, nb, pinb, l1w, l1b, o1b, l2w, l2b, o2b, l3w, l3b, ff1b, ff2b, poutb;
-  Mat pin, qk, v, o1, q2, k2, v2, o2, ff1, ff2, pout;
+  Mat pin, qk, v, o1, q2, o2, ff1, ff2, pout;
 };
 struct ConvL { Mat w; Vec b; int cin = 0, cout = 0; };
 
@@ -76,8 +76,8 @@ struct dfh_unet {
   size_t a16 = 0, a32 = 0;         // arena sizes in elements
   // layers
   ConvL conv_in, conv_out;
-  Mat te1, te2, tproj; Vec te1b, te2b, tprojb, cnw, cnb;
-  int temb_total = 0;
+  Mat te1, te2, tproj, kx_all, vx_all; Vec te1b, te2b, tprojb, cnw, cnb;
+  int temb_total = 0, x_total = 0;   // x_total: sum of C over all transformer layers (batched text K/V)
   std::vector<std::vector<ResL>> down_res, up_res;
   std::vector<std::vector<AttL>> down_att, up_att;
   std::vector<ConvL> down_samp, up_samp;
@@ -170,8 +170,10 @@ struct dfh_unet {
     a.o1 = mat(tb + ".attn1.to_out.0.weight", C, C);
     a.o1b = vec(tb + ".attn1.to_out.0.bias", C);
     a.q2 = mat(tb + ".attn2.to_q.weight", C, C);
-    a.k2 = mat(tb + ".attn2.to_k.weight", C, X);
-    a.v2 = mat(tb + ".attn2.to_v.weight", C, X);
+    a.x_off = x_total;            // to_k / to_v of every layer are packed into two stacked matrices (below)
+    x_total += C;
+    add_param(tb + ".attn2.to_k.weight", {C, X});
+    add_param(tb + ".attn2.to_v.weight", {C, X});
     a.o2 = mat(tb + ".attn2.to_out.0.weight", C, C);
     a.o2b = vec(tb + ".attn2.to_out.0.bias", C);
     a.ff1 = mat(tb + ".ff.net.0.proj.weight", 8 * C, C, false, /*geglu=*/1);
@@ -247,6 +249,25 @@ struct dfh_unet {
     // batched time_emb_proj: [temb_total][temb] + bias; rows of each resnet at its temb_off
     tproj = mat_alloc(temb_total, temb);
     tprojb.N = temb_total; tprojb.off = alloc32(temb_total);
+    // batched cross-attention K / V projections of the text states: [x_total][cross_dim] each
+    kx_all = mat_alloc(x_total, cfg.cross_attention_dim);
+    vx_all = mat_alloc(x_total, cfg.cross_attention_dim);
+    auto pack_cross = [&](const AttL& a, const std::string& pre) {
+      const std::string tb = pre + ".transformer_blocks.0";
+      for (int p = 0; p < (int)params.size(); ++p) {
+        if (params[p].name == tb + ".attn2.to_k.weight")
+          packs.push_back({p, PK_MAT, kx_all.off, a.C, cfg.cross_attention_dim, cfg.cross_attention_dim, a.x_off, 0, 0, 0});
+        else if (params[p].name == tb + ".attn2.to_v.weight")
+          packs.push_back({p, PK_MAT, vx_all.off, a.C, cfg.cross_attention_dim, cfg.cross_attention_dim, a.x_off, 0, 0, 0});
+      }
+    };
+    for (int i = 0; i < nb; ++i)
+      for (int j = 0; j < (int)down_att[i].size(); ++j)
+        pack_cross(down_att[i][j], "down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j));
+    pack_cross(mid_att, "mid_block.attentions.0");
+    for (int i = 0; i < nb; ++i)
+      for (int j = 0; j < (int)up_att[i].size(); ++j)
+        pack_cross(up_att[i][j], "up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j));
     auto pack_tproj = [&](const ResL& r, const std::string& pre) {
       for (int p = 0; p < (int)params.size(); ++p) {
         if (params[p].name == pre + ".time_emb_proj.weight")
@@ -316,9 +337,10 @@ struct dfh_unet {
       rc = dfh::layernorm_launch(x, v32(w), v32(b), y, M, C, 1e-5f, s);
     }
     void attention(const bf16_t* Q, int ldq, const bf16_t* K, int ldk, const bf16_t* Vt, int ldvt, bf16_t* O, int C,
-                   int heads, int Nq, int Nk) {
+                   int heads, int Nq, int Nk, long vt_bstride = 0) {
       if (rc || dry) return;
       AttnArgs a; std::memset(&a, 0, sizeof(a));
+      a.vt_bstride = vt_bstride;
       a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.Vt = Vt; a.ldvt = ldvt; a.O = O; a.ldo = C;
       a.B = B; a.H = heads; a.D = C / heads; a.Nq = Nq; a.Nk = Nk;
       a.scale = 1.0f / sqrtf((float)a.D);
@@ -375,9 +397,8 @@ struct dfh_unet {
       return out;
     }
 
-    Tensor transformer(const Tensor& x, const AttL& a, const bf16_t* ehs, int T) {
+    Tensor transformer(const Tensor& x, const AttL& a, const bf16_t* kx, const bf16_t* vxt, int T) {
       const int H = x.H, W = x.W, C = a.C, N = H * W, M = B * N;
-      const int X = u->cfg.cross_attention_dim;
       Tensor out = palloc(H, W, C);
       const size_t mark = temp.off;
       Tensor gn = talloc(H, W, C);
@@ -400,11 +421,9 @@ struct dfh_unet {
       const int Tp = (T + 7) & ~7;
       layernorm(h1.p, a.l2w, a.l2b, n1.p, M, C);
       linear(n1.p, M, C, a.q2, nullptr, ACT_NONE, nullptr, qk.p, C);
-      bf16_t* k2 = (bf16_t*)temp.alloc((size_t)B * T * C * 2);
-      bf16_t* v2t = (bf16_t*)temp.alloc((size_t)B * C * Tp * 2);
-      linear(ehs, B * T, X, a.k2, nullptr, ACT_NONE, nullptr, k2, C);
-      linear(ehs, B * T, X, a.v2, nullptr, ACT_NONE, nullptr, v2t, C, OUT_BF16_T, Tp, T);
-      attention(qk.p, C, k2, C, v2t, Tp, at.p, C, a.heads, N, T);
+      // text K / V^T of this layer live inside the batched projections computed once per forward
+      const int XT = u->x_total;
+      attention(qk.p, C, kx + a.x_off, XT, vxt + (size_t)a.x_off * Tp, Tp, at.p, C, a.heads, N, T, (long)XT * Tp);
       Tensor h2 = talloc(H, W, C);
       linear(at.p, M, C, a.o2, &a.o2b, ACT_NONE, h1.p, h2.p, C);
       // --- GEGLU feed-forward
@@ -457,6 +476,12 @@ struct dfh_unet {
       if (ehs_bf16) (void)hipMemcpyAsync(ehs16, ehs, (size_t)B * T * X * 2, hipMemcpyDeviceToDevice, s);
       else r.rc = dfh::cast_f32_to_bf16_launch((const float*)ehs, ehs16, (long)B * T * X, s);
     }
+    // text K for every transformer layer in one GEMM ([B*T][x_total]) and V^T in another ([B][x_total][Tp])
+    const int Tp = (T + 7) & ~7;
+    bf16_t* kx = (bf16_t*)r.persist.alloc((size_t)B * T * x_total * 2);
+    bf16_t* vxt = (bf16_t*)r.persist.alloc((size_t)B * x_total * Tp * 2);
+    r.linear(ehs16, B * T, X, kx_all, nullptr, ACT_NONE, nullptr, kx, x_total);
+    r.linear(ehs16, B * T, X, vx_all, nullptr, ACT_NONE, nullptr, vxt, x_total, OUT_BF16_T, Tp, T);
     Tensor x = r.palloc(S, S, conv_in.cin);   // in_channels padded to a multiple of 8
     if (!dry && !r.rc) r.rc = dfh::nchw_to_nhwc_launch(sample, sample_bf16, x.p, B, cfg.in_channels, S * S, s);
 
@@ -466,21 +491,21 @@ struct dfh_unet {
     for (int i = 0; i < nb; ++i) {
       for (int j = 0; j < cfg.layers_per_block; ++j) {
         h = r.resnet(h, nullptr, down_res[i][j], temb_all);
-        if (cfg.down_attn[i]) h = r.transformer(h, down_att[i][j], ehs16, T);
+        if (cfg.down_attn[i]) h = r.transformer(h, down_att[i][j], kx, vxt, T);
         skips.push_back(h);
       }
       if (i != nb - 1) { h = r.conv(h, down_samp[i], 2, 0, true); skips.push_back(h); }
       taps["down" + std::to_string(i)] = h;
     }
     h = r.resnet(h, nullptr, mid_res[0], temb_all);
-    h = r.transformer(h, mid_att, ehs16, T);
+    h = r.transformer(h, mid_att, kx, vxt, T);
     h = r.resnet(h, nullptr, mid_res[1], temb_all);
     taps["mid"] = h;
     for (int i = 0; i < nb; ++i) {
       for (int j = 0; j < (int)up_res[i].size(); ++j) {
         Tensor sk = skips.back(); skips.pop_back();
         h = r.resnet(h, &sk, up_res[i][j], temb_all);
-        if (!up_att[i].empty()) h = r.transformer(h, up_att[i][j], ehs16, T);
+        if (!up_att[i].empty()) h = r.transformer(h, up_att[i][j], kx, vxt, T);
       }
       if (i != nb - 1) h = r.conv(h, up_samp[i], 1, 1, true);
       taps["up" + std::to_string(i)] = h;

@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   }
   uint4 kreg[KS], vreg[NV];
 
+  // When D is not a multiple of 16 the V^T tile has spare rows: row D holds ONES, so the P.V MFMA
+  // also accumulates the softmax denominator l = sum_k p (in O^T row D) -- no per-score VALU add.
+  constexpr bool ONES_ROW = (D % 16) != 0;
   auto load_tile = [&](int kv0) {   // global -> registers (zero beyond D / beyond Nk)
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
@@ -100,6 +103,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
       const int row = idx >> 3, slot = idx & 7;
       const int k0 = kv0 + slot * 8;
       uint4 v = uint4{0, 0, 0, 0};
+      if (ONES_ROW && row == D) v = uint4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};   // bf16 1.0 x8
       if (idx < DF * 128 && row < D && k0 < a.Nk) {
         v = *(const uint4*)(Vb + (long)row * a.ldvt + k0);
         if (k0 + 8 > a.Nk) {   // ragged tail (cross-attention, Nk = 77): zero the padding keys
@@ -169,11 +173,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     bf16x8_t pf[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      float sc[4][4];
+      float sc[4][4];      // raw scores; the scale c is folded into the exp2 argument (one FMA per score)
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sc[tt][r] = s[qt][tt][r] * c;
+        for (int r = 0; r < 4; ++r) sc[tt][r] = s[qt][tt][r];
       if (ragged) {   // kernel-uniform: only the last tile of a ragged key range (cross-attention, Nk = 77)
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
@@ -190,6 +194,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[tt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx *= c;             // c > 0: max commutes with the scale
       // deferred max (wave-uniform): rescale only if some query's max grew by more than the threshold
       if (__any(!(mx - m_run[qt] <= RESCALE_THR))) {
         const float m_new = fmaxf(m_run[qt], mx);
@@ -201,16 +206,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
           oacc[qt][f][0] *= alpha; oacc[qt][f][1] *= alpha; oacc[qt][f][2] *= alpha; oacc[qt][f][3] *= alpha;
         }
       }
-      const float mr = m_run[qt];
+      const float nmr = -m_run[qt];
       float psum = 0.f;
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          sc[tt][r] = __builtin_amdgcn_exp2f(sc[tt][r] - mr);
-          psum += sc[tt][r];
+          sc[tt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[tt][r], c, nmr));
+          if (!ONES_ROW) psum += sc[tt][r];
         }
-      l_run[qt] += psum;
+      if (!ONES_ROW) l_run[qt] += psum;
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch) {
         uint4 w;
@@ -239,9 +244,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   // ---- normalise and store: lane holds O[q = fr][d = f*16 + fg*4 + r]
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    float l = l_run[qt];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    float l;
+    if (ONES_ROW) {        // O^T row D (the ones row of V^T) lives in lane group fg = (D%16)/4, register (D%16)%4
+      l = __shfl(oacc[qt][D / 16][(D % 16) % 4], ((D % 16) / 4) * 16 + fr, 64);
+    } else {
+      l = l_run[qt];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
     const float inv = 1.0f / l;
     const int q = q0 + qt * 16 + fr;
     if (q >= a.Nq) continue;

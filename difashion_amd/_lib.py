@@ -83,6 +83,8 @@ SIGNATURES = {
     "dfh_unet_debug_tap": (_i, [_vp, C.c_char_p, _vp, _sz, _vp]),
     "dfh_gemm_partial_floats": (_sz, [C.POINTER(GemmDesc)]),
     "dfh_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
+    "dfh_gemm_wgrad": (_i, [C.POINTER(GemmDesc), _vp, _i, _vp, _i, _i, _vp]),
+    "dfh_colsum": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "dfh_groupnorm": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     "dfh_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "dfh_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
@@ -148,8 +150,8 @@ def prof_begin():
 
 def prof_end():
     """-> {class name: dict(launches, ms, flops, bytes)} since prof_begin (synchronises the device)."""
-    arr = (ProfClass * 8)()
-    n = raw().dfh_prof_end(arr, 8)
+    arr = (ProfClass * 16)()
+    n = raw().dfh_prof_end(arr, 16)
     if n < 0:
         raise DfhError(f"dfh_prof_end failed: {last_error()}")
     return {arr[i].name.decode(): dict(launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes)

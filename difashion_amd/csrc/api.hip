@@ -10,6 +10,7 @@
 #include "elementwise.h"
 #include "gemm.h"
 #include "norm.h"
+#include "wgrad.h"
 
 namespace dfh {
 static thread_local std::string g_err;
@@ -77,7 +78,8 @@ int dfh_prof_begin(void) {
 int dfh_prof_end(dfh_prof_class* out, int max_classes) {
   dfh::g_prof = false;
   DFH_REQUIRE(out != nullptr && max_classes >= dfh::PC_COUNT, "need room for every kernel class");
-  static const char* names[dfh::PC_COUNT] = {"gemm_conv3x3", "gemm_linear", "attention", "groupnorm", "layernorm", "splitk_reduce", "other"};
+  static const char* names[dfh::PC_COUNT] = {"gemm_conv3x3", "gemm_linear", "attention", "groupnorm", "layernorm", "splitk_reduce", "other",
+                                                  "gemm_wgrad", "attention_bwd", "norm_bwd", "optimizer"};
   for (int i = 0; i < dfh::PC_COUNT; ++i) {
     std::memset(&out[i], 0, sizeof(out[i]));
     std::strncpy(out[i].name, names[i], sizeof(out[i].name) - 1);
@@ -107,6 +109,28 @@ int dfh_gemm(const dfh_gemm_desc* d, void* stream) {
   const size_t need = d->force_split > 1 ? (size_t)d->force_split * g.M * g.N : dfh::gemm_partial_floats(g);
   DFH_REQUIRE(need == 0 || (d->partial && d->partial_floats >= need), "partial buffer too small for split-K");
   return dfh::gemm_launch(g, (hipStream_t)stream, d->force_tile, d->force_split, d->force_glds);
+}
+
+int dfh_gemm_wgrad(const dfh_gemm_desc* d, const void* dY, int ldy, float* dW, int ldw, int msplit, void* stream) {
+  GemmArgs g;
+  DFH_REQUIRE(d && dY && dW, "null argument");
+  // only the A-operand description (K segments), M, N and the zero page of the descriptor are used
+  dfh_gemm_desc tmp = *d;
+  int dummy = 0;
+  if (!tmp.W) tmp.W = &dummy;
+  if (!tmp.out) tmp.out = &dummy;
+  if (int rc = fill_gemm(&tmp, &g)) return rc;
+  WgradArgs w; std::memset(&w, 0, sizeof(w));
+  w.conv_src = g.conv_src; w.conv_c = g.conv_c; w.ntaps = g.ntaps;
+  w.Hin = g.Hin; w.Win = g.Win; w.Hout = g.Hout; w.Wout = g.Wout; w.stride = g.stride; w.ups = g.ups;
+  w.p_src[0] = g.p_src[0]; w.p_src[1] = g.p_src[1]; w.p_c[0] = g.p_c[0]; w.p_c[1] = g.p_c[1]; w.nplain = g.nplain;
+  w.dY = (const bf16_t*)dY; w.ldy = ldy; w.zero = g.zero; w.M = g.M; w.N = g.N; w.dW = dW; w.ldw = ldw; w.msplit = msplit;
+  return dfh::wgrad_launch(w, (hipStream_t)stream);
+}
+
+int dfh_colsum(const void* Y, int ldy, int N, int groups, int rows_per_group, float* out, int ld_out, void* stream) {
+  DFH_REQUIRE(Y && out, "null argument");
+  return dfh::colsum_launch((const bf16_t*)Y, ldy, N, groups, rows_per_group, out, ld_out, (hipStream_t)stream);
 }
 
 int dfh_groupnorm(const void* src0, int c0, const void* src1, int c1, int batch, int hw, int groups, const float* gamma,

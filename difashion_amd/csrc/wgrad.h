@@ -1,0 +1,21 @@
+#pragma once
+#include "dfh_common.h"
+#include <algorithm>
+
+struct WgradArgs {
+  // forward A operand, same K-segment description as GemmArgs
+  const bf16_t* conv_src; int conv_c; int ntaps;
+  int Hin, Win, Hout, Wout, stride, ups;
+  const bf16_t* p_src[2]; int p_c[2]; int nplain;
+  const bf16_t* dY; int ldy;     // output gradient rows [M][ldy] (N columns used)
+  const bf16_t* zero;
+  int M, N;
+  float* dW; int ldw;            // fp32 [N][ldw] in the PACKED weight layout, accumulated (+=)
+  int msplit;                    // 0 = heuristic
+};
+
+namespace dfh {
+int wgrad_launch(WgradArgs a, hipStream_t s);
+// out[g][n] += sum_{m in group g} Y[m][n]   (bias gradient: groups = 1; time-embedding gradient: groups = batch)
+int colsum_launch(const bf16_t* Y, int ldy, int N, int groups, int rows_per_group, float* out, int ld_out, hipStream_t s);
+}  // namespace dfh

@@ -120,6 +120,13 @@ typedef struct dfh_gemm_desc {
 } dfh_gemm_desc;
 size_t dfh_gemm_partial_floats(const dfh_gemm_desc* d);
 int dfh_gemm(const dfh_gemm_desc* d, void* stream);
+/* Weight gradient of the same op (train.py:699 backward): dW[n][k] += sum_m dY[m][n] * A[m][k], where A is the
+ * forward operand described by d (conv_src / a0 / a1 segments, M, N, zero_page; W / out / epilogue fields unused).
+ * dW: fp32 [N][ldw] in the PACKED weight layout, accumulated with atomics (zero it first).  msplit 0 = heuristic. */
+int dfh_gemm_wgrad(const dfh_gemm_desc* d, const void* dY, int ldy, float* dW, int ldw, int msplit, void* stream);
+/* out[g][n] += sum over the rows of group g of Y[m][n] (bias gradient: groups = 1; time-embedding gradient:
+ * groups = batch, rows_per_group = H*W). */
+int dfh_colsum(const void* Y, int ldy, int N, int groups, int rows_per_group, float* out, int ld_out, void* stream);
 
 /* GroupNorm(32, C, eps)(+SiLU) over NHWC bf16, optional fused channel concat of two sources
  * (ResnetBlock2D.norm1/norm2, conv_norm_out, Transformer2DModel.norm).  partial: >= B*64*G*2 floats */

@@ -86,6 +86,27 @@ SIGNATURES = {
     "dfh_gemm_wgrad": (_i, [C.POINTER(GemmDesc), _vp, _i, _vp, _i, _i, _vp]),
     "dfh_colsum": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "dfh_groupnorm": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    "dfh_groupnorm_stats": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
+    "dfh_groupnorm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "dfh_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp]),
+    "dfh_pack_matrix_t": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "dfh_pack_conv3x3_t": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "dfh_unpack_matrix": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "dfh_unpack_conv3x3": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "dfh_unpack_vector": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "dfh_pool2x2_sum": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "dfh_add_bf16": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "dfh_geglu_fwd": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "dfh_geglu_bwd": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    "dfh_act_fwd": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "dfh_act_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _f, _vp]),
+    "dfh_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "dfh_transpose_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp]),
+    "dfh_mse_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "dfh_assemble_bwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
+    "dfh_sumsq": (_i, [_vp, _sz, _vp, _vp]),
+    "dfh_adamw": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
+    "dfh_ema": (_i, [_vp, _vp, _sz, _f, _vp]),
     "dfh_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "dfh_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "dfh_timestep_embedding": (_i, [_vp, _vp, _i, _i, _vp]),

@@ -11,6 +11,7 @@
 #include "gemm.h"
 #include "norm.h"
 #include "wgrad.h"
+#include "bwd_elementwise.h"
 
 namespace dfh {
 static thread_local std::string g_err;
@@ -140,6 +141,86 @@ int dfh_groupnorm(const void* src0, int c0, const void* src1, int c1, int batch,
   a.B = batch; a.HW = hw; a.G = groups; a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu;
   a.out = (bf16_t*)out; a.partial = partial;
   return dfh::groupnorm_launch(a, (hipStream_t)stream);
+}
+
+int dfh_groupnorm_stats(const void* src0, int c0, const void* src1, int c1, int batch, int hw, int groups, const float* gamma,
+                        const float* beta, float eps, int silu, void* out, float* partial, float* stats_out, void* stream) {
+  GnArgs a; std::memset(&a, 0, sizeof(a));
+  a.src0 = (const bf16_t*)src0; a.C0 = c0; a.src1 = (const bf16_t*)src1; a.C1 = src1 ? c1 : 0;
+  a.B = batch; a.HW = hw; a.G = groups; a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu;
+  a.out = (bf16_t*)out; a.partial = partial; a.stats_out = stats_out;
+  return dfh::groupnorm_launch(a, (hipStream_t)stream);
+}
+int dfh_groupnorm_bwd(const void* src0, int c0, const void* src1, int c1, const void* dy, int batch, int hw, int groups,
+                      const float* gamma, const float* beta, const float* stats, int silu, void* dx0, int acc0, void* dx1,
+                      int acc1, float* dgamma, float* dbeta, float* partial, void* stream) {
+  GnBwdArgs a; std::memset(&a, 0, sizeof(a));
+  a.src0 = (const bf16_t*)src0; a.C0 = c0; a.src1 = (const bf16_t*)src1; a.C1 = src1 ? c1 : 0; a.dy = (const bf16_t*)dy;
+  a.B = batch; a.HW = hw; a.G = groups; a.gamma = gamma; a.beta = beta; a.stats = stats; a.silu = silu;
+  a.dx0 = (bf16_t*)dx0; a.dx1 = (bf16_t*)dx1; a.acc0 = acc0; a.acc1 = acc1; a.dgamma = dgamma; a.dbeta = dbeta; a.partial = partial;
+  return dfh::groupnorm_bwd_launch(a, (hipStream_t)stream);
+}
+int dfh_layernorm_bwd(const void* x, const void* dy, const float* gamma, void* dx, int accumulate, float* dgamma, float* dbeta,
+                      int M, int C, float eps, void* stream) {
+  return dfh::layernorm_bwd_launch((const bf16_t*)x, (const bf16_t*)dy, gamma, (bf16_t*)dx, accumulate, dgamma, dbeta, M, C, eps,
+                                   (hipStream_t)stream);
+}
+int dfh_pack_matrix_t(const float* w, void* out, int N, int K, int ldt, int t_row_off, int t_col_off, int geglu, void* stream) {
+  return dfh::pack_matrix_t_launch(w, (bf16_t*)out, N, K, ldt, t_row_off, t_col_off, geglu, (hipStream_t)stream);
+}
+int dfh_pack_conv3x3_t(const float* w, void* out, int Cout, int Cin, int ldt, int t_col_off, int o_pad, void* stream) {
+  return dfh::pack_conv3x3_t_launch(w, (bf16_t*)out, Cout, Cin, ldt, t_col_off, o_pad, (hipStream_t)stream);
+}
+int dfh_unpack_matrix(const float* g, float* grad, int N, int K, int ldw, int row_off, int col_off, int geglu, void* stream) {
+  return dfh::unpack_matrix_launch(g, grad, N, K, ldw, row_off, col_off, geglu, (hipStream_t)stream);
+}
+int dfh_unpack_conv3x3(const float* g, float* grad, int Cout, int Cin, int ldw, int col_off, int cin_pad, void* stream) {
+  return dfh::unpack_conv3x3_launch(g, grad, Cout, Cin, ldw, col_off, cin_pad, (hipStream_t)stream);
+}
+int dfh_unpack_vector(const float* g, float* grad, int N, int off, int geglu, void* stream) {
+  return dfh::unpack_vector_launch(g, grad, N, off, geglu, (hipStream_t)stream);
+}
+int dfh_pool2x2_sum(const void* in, void* out, int batch, int H, int W, int C, void* stream) {
+  return dfh::pool2x2_sum_launch((const bf16_t*)in, (bf16_t*)out, batch, H, W, C, (hipStream_t)stream);
+}
+int dfh_add_bf16(void* dst, const void* src, size_t n, int accumulate, void* stream) {
+  return dfh::add_bf16_launch((bf16_t*)dst, (const bf16_t*)src, (long)n, accumulate, (hipStream_t)stream);
+}
+int dfh_geglu_fwd(const void* pre, void* y, size_t M, int N2, void* stream) {
+  return dfh::geglu_fwd_launch((const bf16_t*)pre, (bf16_t*)y, (long)M, N2, (hipStream_t)stream);
+}
+int dfh_geglu_bwd(const void* pre, const void* dy, void* dpre, size_t M, int N2, void* stream) {
+  return dfh::geglu_bwd_launch((const bf16_t*)pre, (const bf16_t*)dy, (bf16_t*)dpre, (long)M, N2, (hipStream_t)stream);
+}
+int dfh_act_fwd(const void* pre, void* y, size_t n, int kind, void* stream) {
+  return dfh::act_fwd_launch((const bf16_t*)pre, (bf16_t*)y, (long)n, kind, (hipStream_t)stream);
+}
+int dfh_act_bwd(const void* ref_bf16, const float* ref_f32, const void* dy_bf16, const float* dy_f32, void* dpre, size_t n, int kind,
+                float scale, void* stream) {
+  return dfh::act_bwd_launch((const bf16_t*)ref_bf16, ref_f32, (const bf16_t*)dy_bf16, dy_f32, (bf16_t*)dpre, (long)n, kind, scale,
+                             (hipStream_t)stream);
+}
+int dfh_nhwc_to_nchw_f32(const void* src, float* dst, int batch, int HW, int Cp, int C, float scale, int accumulate, void* stream) {
+  return dfh::nhwc_to_nchw_f32_launch((const bf16_t*)src, dst, batch, HW, Cp, C, scale, accumulate, (hipStream_t)stream);
+}
+int dfh_transpose_bf16(const void* in, void* out, int batch, int R, int C, int ld_in, int ld_out, size_t in_bstride,
+                       size_t out_bstride, void* stream) {
+  return dfh::transpose_bf16_launch((const bf16_t*)in, (bf16_t*)out, batch, R, C, ld_in, ld_out, (long)in_bstride, (long)out_bstride,
+                                    (hipStream_t)stream);
+}
+int dfh_mse_bwd(const float* pred, const float* target, const float* w, float* dpred, int rows, int L, float loss_scale, void* stream) {
+  return dfh::mse_bwd_launch(pred, target, w, dpred, rows, L, loss_scale, (hipStream_t)stream);
+}
+int dfh_assemble_bwd(const float* dx, const uint8_t* mutual_real, float* dmutual, int rows, int CL, float eta, void* stream) {
+  return dfh::assemble_bwd_launch(dx, mutual_real, dmutual, rows, CL, eta, (hipStream_t)stream);
+}
+int dfh_sumsq(const float* g, size_t n, float* out, void* stream) { return dfh::sumsq_launch(g, (long)n, out, (hipStream_t)stream); }
+int dfh_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+              float weight_decay, int step, const float* sumsq, float max_norm, void* stream) {
+  return dfh::adamw_launch(p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, step, sumsq, max_norm, (hipStream_t)stream);
+}
+int dfh_ema(float* shadow, const float* p, size_t n, float decay, void* stream) {
+  return dfh::ema_launch(shadow, p, (long)n, decay, (hipStream_t)stream);
 }
 
 int dfh_layernorm(const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps, void* stream) {

@@ -148,7 +148,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a
 #pragma unroll
       for (int i = 0; i < IA; ++i) {
         const int yy = a_y[i] + ky, xx = a_x[i] + kx;
-        const bool ok = kin & (a_pix[i] >= 0) & ((unsigned)yy < (unsigned)Hv) & ((unsigned)xx < (unsigned)Wv);
+        // ups == 1: nearest-2x upsampled input; ups == 2: zero-inserted input (only even virtual pixels exist) --
+        // the data-gradient of a stride-2 conv is a stride-1 conv of the zero-inserted output gradient
+        const bool ok = kin & (a_pix[i] >= 0) & ((unsigned)yy < (unsigned)Hv) & ((unsigned)xx < (unsigned)Wv) &
+                        ((a.ups != 2) | (((yy | xx) & 1) == 0));
         const int sy = a.ups ? (yy >> 1) : yy, sx = a.ups ? (xx >> 1) : xx;
         const unsigned off = (unsigned)(a_bbase[i] + sy * a.Win + sx) * cc + (unsigned)ch;
         glds(ok ? a.conv_src + off : a.zero, As + i * NWV * 1024);

@@ -12,11 +12,28 @@ struct GnArgs {
   float eps; int silu;
   bf16_t* out;                               // [B][HW][C0+C1]
   float* partial;                            // >= B * GN_MAX_CHUNKS * G * 2 floats
+  float* stats_out;                          // optional [B][G][2] (mean, rstd), kept for the backward pass
   // filled by the launcher
   int C, PL, chunks, pix_per_chunk, apix_per_chunk;
 };
 
+// GroupNorm(+SiLU) backward.  x = concat(src0, src1) as in the forward; dy [B][HW][C]; stats [B][G][2] from the forward.
+struct GnBwdArgs {
+  const bf16_t* src0; const bf16_t* src1; int C0, C1;
+  const bf16_t* dy;
+  int B, HW, G;
+  const float* gamma; const float* beta; const float* stats; int silu;
+  bf16_t* dx0; bf16_t* dx1; int acc0, acc1;  // gradient wrt each source; acc: add into existing contents
+  float* dgamma; float* dbeta;               // fp32 [C], accumulated with atomics
+  float* partial;                            // >= B * GN_MAX_CHUNKS * G * 2 floats
+  int C, PL, chunks, pix_per_chunk, apix_per_chunk;
+};
+
 namespace dfh {
+int groupnorm_bwd_launch(GnBwdArgs a, hipStream_t stream);
+// LayerNorm backward over rows [M][C]; dx (=|+=); dgamma/dbeta fp32 atomics
+int layernorm_bwd_launch(const bf16_t* x, const bf16_t* dy, const float* gamma, bf16_t* dx, int accumulate, float* dgamma,
+                         float* dbeta, int M, int C, float eps, hipStream_t stream);
 int groupnorm_launch(GnArgs a, hipStream_t stream);
 int layernorm_launch(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int M, int C, float eps,
                      hipStream_t stream);

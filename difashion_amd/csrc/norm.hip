@@ -97,6 +97,10 @@ __global__ void gn_apply_kernel(const GnArgs a) {
     const float var = fmaxf(qq / n - mean * mean, 0.f);
     mean_s[tid] = mean;
     rstd_s[tid] = rsqrtf(var + a.eps);
+    if (a.stats_out && blockIdx.x == 0) {
+      a.stats_out[((long)b * a.G + tid) * 2 + 0] = mean;
+      a.stats_out[((long)b * a.G + tid) * 2 + 1] = rstd_s[tid];
+    }
   }
   __syncthreads();
   if (pl >= a.PL) return;

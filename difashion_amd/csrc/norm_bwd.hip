@@ -1,0 +1,258 @@
+// GroupNorm(+SiLU) and LayerNorm backward for NHWC bf16 activations (training step: torch autograd of
+// diffusers ResnetBlock2D.norm1/norm2, Transformer2DModel.norm, BasicTransformerBlock.norm1/2/3 reached
+// through DiFashion/train.py:699).  Same thread mapping and deterministic group reduction as the
+// forward kernels in norm.hip; per-channel dgamma / dbeta are accumulated with fp32 atomics.
+//
+//   x^ = (x - mu) * rstd,  z = gamma * x^ + beta,  y = silu(z) | z
+//   dz = dy * silu'(z) | dy;  dbeta_c = sum dz;  dgamma_c = sum dz * x^
+//   per (b, group), n = HW * cpg:  s1 = sum gamma*dz,  s2 = sum gamma*dz*x^
+//   dx = rstd * (gamma*dz - s1/n - x^ * s2/n)
+#include "dfh_common.h"
+#include "norm.h"
+
+namespace {
+
+DFH_DEVICE const uint4* gnb_src(const GnBwdArgs& a, int b, int p, int o) {
+  const int o0 = a.C0 >> 3;
+  if (o < o0) return (const uint4*)(a.src0 + ((long)(b * a.HW + p) * a.C0 + o * 8));
+  return (const uint4*)(a.src1 + ((long)(b * a.HW + p) * a.C1 + (o - o0) * 8));
+}
+
+DFH_DEVICE float dsilu(float z) { const float s = 1.0f / (1.0f + __expf(-z)); return s * (1.0f + z * (1.0f - s)); }
+
+// grid (chunks, B): per-channel sums A_c = sum dz, B_c = sum dz*x^ over this chunk's pixels
+__global__ void gn_bwd_stats_kernel(const GnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [PL][C][2]
+  const int C8 = a.C >> 3, cpg = a.C / a.G;
+  const int tid = threadIdx.x;
+  const int o = tid % C8, pl = tid / C8;
+  const int b = blockIdx.y;
+  const int p_begin = blockIdx.x * a.pix_per_chunk, p_end = min(a.HW, p_begin + a.pix_per_chunk);
+  if (pl < a.PL) {
+    float ga[8], be[8], mu[8], rs[8], A[8], Bq[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = o * 8 + k, g = c / cpg;
+      ga[k] = a.gamma[c]; be[k] = a.beta[c];
+      mu[k] = a.stats[((long)b * a.G + g) * 2]; rs[k] = a.stats[((long)b * a.G + g) * 2 + 1];
+      A[k] = 0.f; Bq[k] = 0.f;
+    }
+    for (int p = p_begin + pl; p < p_end; p += a.PL) {
+      float x[8], d[8];
+      unpack8(*gnb_src(a, b, p, o), x);
+      unpack8(*(const uint4*)(a.dy + ((long)(b * a.HW + p) * a.C + o * 8)), d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float xh = (x[k] - mu[k]) * rs[k];
+        const float dz = a.silu ? d[k] * dsilu(ga[k] * xh + be[k]) : d[k];
+        A[k] += dz; Bq[k] += dz * xh;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      red[((pl * a.C) + o * 8 + k) * 2 + 0] = A[k];
+      red[((pl * a.C) + o * 8 + k) * 2 + 1] = Bq[k];
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < a.C; c += blockDim.x) {   // reduce over pixel lanes into slot 0, publish dgamma / dbeta
+    float sa = 0.f, sb = 0.f;
+    for (int l = 0; l < a.PL; ++l) { sa += red[(l * a.C + c) * 2]; sb += red[(l * a.C + c) * 2 + 1]; }
+    red[c * 2] = sa; red[c * 2 + 1] = sb;
+    atomicAdd(a.dbeta + c, sa);
+    atomicAdd(a.dgamma + c, sb);
+  }
+  __syncthreads();
+  if (tid < a.G) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s1 += a.gamma[c] * red[c * 2]; s2 += a.gamma[c] * red[c * 2 + 1]; }
+    float* dst = a.partial + (((long)b * gridDim.x + blockIdx.x) * a.G + tid) * 2;
+    dst[0] = s1; dst[1] = s2;
+  }
+}
+
+// grid (achunks, B): dx
+__global__ void gn_bwd_apply_kernel(const GnBwdArgs a) {
+  __shared__ float s1_s[64], s2_s[64];
+  const int C8 = a.C >> 3, cpg = a.C / a.G;
+  const int tid = threadIdx.x;
+  const int o = tid % C8, pl = tid / C8;
+  const int b = blockIdx.y;
+  if (tid < a.G) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < a.chunks; ++c) {
+      const float* src = a.partial + (((long)b * a.chunks + c) * a.G + tid) * 2;
+      s1 += src[0]; s2 += src[1];
+    }
+    const float n = (float)a.HW * (float)cpg;
+    s1_s[tid] = s1 / n; s2_s[tid] = s2 / n;
+  }
+  __syncthreads();
+  if (pl >= a.PL) return;
+  float ga[8], be[8], mu[8], rs[8], m1[8], m2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = o * 8 + k, g = c / cpg;
+    ga[k] = a.gamma[c]; be[k] = a.beta[c];
+    mu[k] = a.stats[((long)b * a.G + g) * 2]; rs[k] = a.stats[((long)b * a.G + g) * 2 + 1];
+    m1[k] = s1_s[g]; m2[k] = s2_s[g];
+  }
+  const int o0 = a.C0 >> 3;
+  const bool first = o < o0;
+  bf16_t* dbase = first ? a.dx0 : a.dx1;
+  const int Cd = first ? a.C0 : a.C1, od = first ? o : o - o0;
+  const int acc = first ? a.acc0 : a.acc1;
+  const int p_begin = blockIdx.x * a.apix_per_chunk, p_end = min(a.HW, p_begin + a.apix_per_chunk);
+  for (int p = p_begin + pl; p < p_end; p += a.PL) {
+    float x[8], d[8], r[8];
+    unpack8(*gnb_src(a, b, p, o), x);
+    unpack8(*(const uint4*)(a.dy + ((long)(b * a.HW + p) * a.C + o * 8)), d);
+    uint4* dst = (uint4*)(dbase + ((long)(b * a.HW + p) * Cd + od * 8));
+    if (acc) unpack8(*dst, r);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float xh = (x[k] - mu[k]) * rs[k];
+      const float dz = a.silu ? d[k] * dsilu(ga[k] * xh + be[k]) : d[k];
+      const float dx = rs[k] * (ga[k] * dz - m1[k] - xh * m2[k]);
+      r[k] = acc ? r[k] + dx : dx;
+    }
+    *dst = pack8(r);
+  }
+}
+
+// LayerNorm backward: a workgroup owns 64 consecutive rows, one wave per row in turn; lanes own fixed columns so
+// dgamma / dbeta accumulate in registers and leave the workgroup as one atomic per column.
+template <int MAXO>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                            const float* __restrict__ gamma, bf16_t* __restrict__ dx,
+                                                            int accumulate, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int M, int C, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4 waves][C][2]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C8 = C >> 3;
+  float gg[MAXO][8], dgam[MAXO][8], dbet[MAXO][8];
+#pragma unroll
+  for (int i = 0; i < MAXO; ++i) {
+    const int o = lane + i * 64;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { gg[i][k] = o < C8 ? gamma[o * 8 + k] : 0.f; dgam[i][k] = 0.f; dbet[i][k] = 0.f; }
+  }
+  const int r_end = min(M, (int)(blockIdx.x + 1) * 64);
+  for (int row = blockIdx.x * 64 + wave; row < r_end; row += 4) {
+    float v[MAXO][8], d[MAXO][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) {
+      const int o = lane + i * 64;
+      if (o < C8) {
+        unpack8(*(const uint4*)(x + (long)row * C + o * 8), v[i]);
+        unpack8(*(const uint4*)(dy + (long)row * C + o * 8), d[i]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[i][k];
+      }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i)
+      if (lane + i * 64 < C8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float t = v[i][k] - mean; q += t * t; }
+      }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i)
+      if (lane + i * 64 < C8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float xh = (v[i][k] - mean) * rstd;
+          v[i][k] = xh;
+          dbet[i][k] += d[i][k]; dgam[i][k] += d[i][k] * xh;
+          d[i][k] *= gg[i][k];
+          s1 += d[i][k]; s2 += d[i][k] * xh;
+        }
+      }
+    s1 = wave_sum(s1) / (float)C; s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) {
+      const int o = lane + i * 64;
+      if (o < C8) {
+        float r[8];
+        uint4* dst = (uint4*)(dx + (long)row * C + o * 8);
+        if (accumulate) unpack8(*dst, r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float g = rstd * (d[i][k] - s1 - v[i][k] * s2);
+          r[k] = accumulate ? r[k] + g : g;
+        }
+        *dst = pack8(r);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXO; ++i) {
+    const int o = lane + i * 64;
+    if (o < C8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        red[(wave * C + o * 8 + k) * 2] = dgam[i][k];
+        red[(wave * C + o * 8 + k) * 2 + 1] = dbet[i][k];
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < 4; ++w) { a += red[(w * C + c) * 2]; b += red[(w * C + c) * 2 + 1]; }
+    atomicAdd(dgamma + c, a);
+    atomicAdd(dbeta + c, b);
+  }
+}
+
+}  // namespace
+
+namespace dfh {
+
+int groupnorm_bwd_launch(GnBwdArgs a, hipStream_t stream) {
+  a.C = a.C0 + a.C1;
+  DFH_REQUIRE(a.C % 8 == 0 && a.C0 % 8 == 0 && a.C1 % 8 == 0, "channels must be multiples of 8");
+  DFH_REQUIRE(a.G > 0 && a.G <= 64 && a.C % a.G == 0, "bad group count");
+  DFH_REQUIRE(a.src0 && a.dy && a.stats && a.gamma && a.beta && a.dx0 && a.dgamma && a.dbeta && a.partial, "null pointer");
+  DFH_REQUIRE(a.C1 == 0 || (a.src1 && a.dx1), "second source / gradient missing");
+  const int C8 = a.C / 8;
+  int PL = 256 / C8;
+  if (PL < 1) PL = 1;
+  if (PL > a.HW) PL = a.HW;
+  a.PL = PL;
+  const int block = ((C8 * PL + 63) / 64) * 64;
+  DFH_REQUIRE(block <= 1024, "block too large");
+  const int max_by_pix = (a.HW + PL - 1) / PL;
+  int chunks = std::max(1, std::min({(512 + a.B - 1) / a.B, max_by_pix, (int)GN_MAX_CHUNKS}));
+  a.pix_per_chunk = (a.HW + chunks - 1) / chunks;
+  a.chunks = (a.HW + a.pix_per_chunk - 1) / a.pix_per_chunk;
+  int ac = std::max(1, std::min((2048 + a.B - 1) / a.B, max_by_pix));
+  a.apix_per_chunk = (a.HW + ac - 1) / ac;
+  const int achunks = (a.HW + a.apix_per_chunk - 1) / a.apix_per_chunk;
+  const size_t lds = (size_t)a.PL * a.C * 2 * sizeof(float);
+  DFH_REQUIRE(lds <= 64 * 1024, "GroupNorm LDS reduction too large");
+  ProfScope ps(PC_NORM_BWD, 0.0, 10.0 * a.B * (double)a.HW * a.C, stream);   // x, dy read twice, dx written
+  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(a.chunks, a.B), dim3(block), lds, stream, a);
+  if (int rc = check_launch("gn_bwd_stats_kernel")) return rc;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(achunks, a.B), dim3(block), 0, stream, a);
+  return check_launch("gn_bwd_apply_kernel");
+}
+
+int layernorm_bwd_launch(const bf16_t* x, const bf16_t* dy, const float* gamma, bf16_t* dx, int accumulate, float* dgamma,
+                         float* dbeta, int M, int C, float eps, hipStream_t stream) {
+  DFH_REQUIRE(C % 8 == 0 && C <= 8 * 64 * 4, "LayerNorm width must be a multiple of 8 and <= 2048");
+  const dim3 grid((M + 63) / 64), block(256);
+  const size_t lds = (size_t)4 * C * 2 * sizeof(float);
+  ProfScope ps(PC_NORM_BWD, 0.0, 6.0 * (double)M * C, stream);
+  if (C <= 512) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, lds, stream, x, dy, gamma, dx, accumulate, dgamma, dbeta, M, C, eps);
+  else if (C <= 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, lds, stream, x, dy, gamma, dx, accumulate, dgamma, dbeta, M, C, eps);
+  else hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, lds, stream, x, dy, gamma, dx, accumulate, dgamma, dbeta, M, C, eps);
+  return check_launch("layernorm_bwd_kernel");
+}
+
+}  // namespace dfh

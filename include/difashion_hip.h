@@ -147,6 +147,44 @@ int dfh_pack_conv3x3(const float* w_oihw, void* out, int Cout, int Cin, int ldw,
 int dfh_pack_matrix(const float* w, void* out, int N, int K, int ldw, int row_off, int col_off, int geglu, void* stream);
 int dfh_pack_vector(const float* v, float* out, int N, int off, int geglu, int accumulate, void* stream);
 
+/* ------------------------------------------------------------------ backward / training-step ops (train.py:691-716)
+ * dfh_groupnorm with the (mean, rstd) pairs [B][G][2] kept for the backward pass */
+int dfh_groupnorm_stats(const void* src0, int c0, const void* src1, int c1, int batch, int hw, int groups,
+                        const float* gamma, const float* beta, float eps, int silu, void* out, float* partial,
+                        float* stats_out, void* stream);
+/* GroupNorm(+SiLU) backward: dx0/dx1 bf16 (acc != 0: add into the buffer), dgamma/dbeta fp32 += (atomics) */
+int dfh_groupnorm_bwd(const void* src0, int c0, const void* src1, int c1, const void* dy, int batch, int hw, int groups,
+                      const float* gamma, const float* beta, const float* stats, int silu, void* dx0, int acc0,
+                      void* dx1, int acc1, float* dgamma, float* dbeta, float* partial, void* stream);
+int dfh_layernorm_bwd(const void* x, const void* dy, const float* gamma, void* dx, int accumulate, float* dgamma,
+                      float* dbeta, int M, int C, float eps, void* stream);
+/* transposed / flipped weight packing so that data gradients reuse dfh_gemm:
+ *   linear: Wt[t_row_off + k][t_col_off + n] = w[n][k];  conv3x3: W'[c][t_col_off + (8-t)*o_pad + o] = w[o][c][t] */
+int dfh_pack_matrix_t(const float* w, void* out, int N, int K, int ldt, int t_row_off, int t_col_off, int geglu, void* stream);
+int dfh_pack_conv3x3_t(const float* w, void* out, int Cout, int Cin, int ldt, int t_col_off, int o_pad, void* stream);
+/* packed fp32 gradient -> master layout (+=): inverses of dfh_pack_matrix / dfh_pack_conv3x3 / dfh_pack_vector */
+int dfh_unpack_matrix(const float* g, float* grad, int N, int K, int ldw, int row_off, int col_off, int geglu, void* stream);
+int dfh_unpack_conv3x3(const float* g, float* grad, int Cout, int Cin, int ldw, int col_off, int cin_pad, void* stream);
+int dfh_unpack_vector(const float* g, float* grad, int N, int off, int geglu, void* stream);
+int dfh_pool2x2_sum(const void* in, void* out, int batch, int H, int W, int C, void* stream);   /* nearest-2x backward */
+int dfh_add_bf16(void* dst, const void* src, size_t n, int accumulate, void* stream);
+int dfh_geglu_fwd(const void* pre, void* y, size_t M, int N2, void* stream);
+int dfh_geglu_bwd(const void* pre, const void* dy, void* dpre, size_t M, int N2, void* stream);
+int dfh_act_fwd(const void* pre, void* y, size_t n, int kind, void* stream);      /* 1 silu 2 leaky_relu 3 tanh */
+int dfh_act_bwd(const void* ref_bf16, const float* ref_f32, const void* dy_bf16, const float* dy_f32, void* dpre, size_t n,
+                int kind, float scale, void* stream);
+int dfh_nhwc_to_nchw_f32(const void* src, float* dst, int batch, int HW, int Cp, int C, float scale, int accumulate, void* stream);
+int dfh_transpose_bf16(const void* in, void* out, int batch, int R, int C, int ld_in, int ld_out, size_t in_bstride,
+                       size_t out_bstride, void* stream);
+int dfh_mse_bwd(const float* pred, const float* target, const float* w, float* dpred, int rows, int L, float loss_scale, void* stream);
+int dfh_assemble_bwd(const float* dx, const uint8_t* mutual_real, float* dmutual, int rows, int CL, float eta, void* stream);
+/* optimizer: torch.optim.AdamW step with the clip_grad_norm_ coefficient derived on device from *sumsq (may be NULL),
+ * squared-norm accumulation, diffusers EMAModel update */
+int dfh_sumsq(const float* g, size_t n, float* out, void* stream);
+int dfh_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+              float weight_decay, int step, const float* sumsq, float max_norm, void* stream);
+int dfh_ema(float* shadow, const float* p, size_t n, float decay, void* stream);
+
 /* ------------------------------------------------------------------ DiFashion glue (reference-owned arithmetic)
  * Sibling reduce feeding MutualEncoder: df.py:160-170 (training mean) / df.py:475-489 (sampling sum).
  *   out[j] = sum_k wtab[j][k] * (table[j][k] >= 0 ? gen[table] : given[-(table+1)])   (slot order)

@@ -95,3 +95,164 @@ def test_colsum_bias_and_time_embedding_grads():
     assert gu.rel_err(out[0], dy.float().sum(0)) < 1e-5
     assert gu.rel_err(outb[:, N:], dy.float().view(B, HW, N).sum(1)) < 1e-5
     assert float(outb[:, :N].abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------- data gradients through the forward GEMM
+def test_dgrad_linear_with_transposed_pack():
+    M, N, K = 300, 320, 192
+    w = rnd(N, K, seed=20, scale=0.05)
+    dy = bf(rnd(M, N, seed=21))
+    wt = torch.zeros((K, N), dtype=torch.bfloat16, device=DEV)
+    _lib.call("dfh_pack_matrix_t", _lib.ptr(w), _lib.ptr(wt), N, K, N, 0, 0, 0, gu.stream())
+    dx = gu.gemm(M=M, N=K, W=wt, ldw=N, a0=dy, a0_c=N)
+    gu.assert_close_bf16(dx, dy.float() @ bf(w).float(), "dgrad linear")
+
+
+@pytest.mark.parametrize("cin,cout,H,stride,ups", [(64, 96, 16, 1, 0), (32, 64, 8, 1, 0), (64, 64, 16, 2, 0), (64, 128, 8, 1, 1),
+                                                   (128, 128, 2, 1, 0)])
+def test_dgrad_conv3x3(cin, cout, H, stride, ups):
+    """dX = conv3x3(dY, flipped/transposed W): stride 1 directly, stride 2 over the zero-inserted dY (upsample = 2),
+    nearest-2x upsample + conv as dgrad at 2H followed by the 2x2 sum pool."""
+    B = 2
+    x = bf(rnd(B, cin, H, H, seed=22)).float().requires_grad_(True)
+    w = rnd(cout, cin, 3, 3, seed=23, scale=0.05)
+    Ho = H * 2 if ups else H // stride
+    dy = bf(rnd(B, cout, Ho, Ho, seed=24))
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    y = F.conv2d(xin, bf(w).float(), None, stride=stride, padding=1)
+    (ref,) = torch.autograd.grad(y, x, dy.float())
+    wt = torch.zeros((cin, 9 * cout), dtype=torch.bfloat16, device=DEV)
+    _lib.call("dfh_pack_conv3x3_t", _lib.ptr(w), _lib.ptr(wt), cout, cin, 9 * cout, 0, cout, gu.stream())
+    dyn = gu.nhwc(dy)
+    if stride == 2:
+        dx = gu.gemm(M=B * H * H, N=cin, W=wt, ldw=9 * cout, conv_src=dyn, conv_c=cout, batch=B, Hin=Ho, Win=Ho, upsample=2)
+    else:
+        dx = gu.gemm(M=B * Ho * Ho, N=cin, W=wt, ldw=9 * cout, conv_src=dyn, conv_c=cout, batch=B, Hin=Ho, Win=Ho)
+        if ups:
+            pooled = torch.empty((B * H * H, cin), dtype=torch.bfloat16, device=DEV)
+            _lib.call("dfh_pool2x2_sum", _lib.ptr(dx), _lib.ptr(pooled), B, H, H, cin, gu.stream())
+            torch.cuda.synchronize()
+            dx = pooled
+    gu.assert_close_bf16(gu.nchw(dx.view(B, H, H, cin)), ref, f"dgrad conv s{stride} u{ups}", rel=8e-3, max_rel=4e-2)
+
+
+# ----------------------------------------------------------------------------- normalisation backward
+@pytest.mark.parametrize("C0,C1,HW,silu,eps", [(320, 0, 256, 1, 1e-5), (640, 320, 64, 1, 1e-5), (64, 0, 4, 0, 1e-6), (32, 32, 256, 1, 1e-5)])
+def test_groupnorm_backward(C0, C1, HW, silu, eps):
+    import math
+    B, G = 3, 32
+    C, H = C0 + C1, int(math.isqrt(HW))
+    x0 = bf(rnd(B, C0, H, H, seed=31) * 2 + 0.7)
+    x1 = bf(rnd(B, C1, H, H, seed=32) - 0.4) if C1 else None
+    gamma, beta = rnd(C, seed=33) * 0.3 + 1, rnd(C, seed=34) * 0.2
+    dy = bf(rnd(B, C, H, H, seed=35))
+    s0, s1, dyn = gu.nhwc(x0), (gu.nhwc(x1) if C1 else None), gu.nhwc(dy)
+    out = torch.empty((B, HW, C), dtype=torch.bfloat16, device=DEV)
+    part = torch.empty(B * 64 * G * 2, device=DEV)
+    stats = torch.empty(B * G * 2, device=DEV)
+    _lib.call("dfh_groupnorm_stats", _lib.ptr(s0), C0, _lib.ptr(s1), C1, B, HW, G, _lib.ptr(gamma), _lib.ptr(beta), eps, silu,
+              _lib.ptr(out), _lib.ptr(part), _lib.ptr(stats), gu.stream())
+    pre0 = bf(rnd(B, HW, C0, seed=36))                   # existing gradient contents to accumulate into
+    dx0, dx1 = pre0.clone(), (torch.empty((B, HW, C1), dtype=torch.bfloat16, device=DEV) if C1 else None)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    _lib.call("dfh_groupnorm_bwd", _lib.ptr(s0), C0, _lib.ptr(s1), C1, _lib.ptr(dyn), B, HW, G, _lib.ptr(gamma), _lib.ptr(beta),
+              _lib.ptr(stats), silu, _lib.ptr(dx0), 1, _lib.ptr(dx1), 0, _lib.ptr(dg), _lib.ptr(db), _lib.ptr(part), gu.stream())
+    torch.cuda.synchronize()
+    xin = (torch.cat([x0, x1], 1) if C1 else x0).float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = F.group_norm(xin, G, gr, br, eps)
+    y = F.silu(y) if silu else y
+    rx, rg, rb = torch.autograd.grad(y, (xin, gr, br), dy.float())
+    got0 = gu.nchw(dx0.view(B, H, H, C0)).float() - gu.nchw(pre0.view(B, H, H, C0)).float()
+    gu.assert_close_bf16(got0, rx[:, :C0], "gn dx0 (accumulated)", rel=2e-2, max_rel=5e-2)
+    if C1:
+        gu.assert_close_bf16(gu.nchw(dx1.view(B, H, H, C1)), rx[:, C0:], "gn dx1", rel=8e-3, max_rel=4e-2)
+    assert gu.rel_err(dg, rg) < 2e-3 and gu.rel_err(db, rb) < 2e-3
+
+
+@pytest.mark.parametrize("M,C", [(300, 320), (64, 1280), (37, 32), (130, 640)])
+def test_layernorm_backward(M, C):
+    x = bf(rnd(M, C, seed=37) * 3 + 1.5)
+    dy = bf(rnd(M, C, seed=38))
+    gamma, beta = rnd(C, seed=39) * 0.3 + 1, rnd(C, seed=40) * 0.2
+    dx = torch.empty_like(x)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    _lib.call("dfh_layernorm_bwd", _lib.ptr(x), _lib.ptr(dy), _lib.ptr(gamma), _lib.ptr(dx), 0, _lib.ptr(dg), _lib.ptr(db), M, C,
+              1e-5, gu.stream())
+    torch.cuda.synchronize()
+    xr, gr, br = x.float().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rx, rg, rb = torch.autograd.grad(F.layer_norm(xr, (C,), gr, br, 1e-5), (xr, gr, br), dy.float())
+    gu.assert_close_bf16(dx, rx, "ln dx", rel=8e-3, max_rel=4e-2)
+    assert gu.rel_err(dg, rg) < 2e-3 and gu.rel_err(db, rb) < 2e-3
+
+
+def test_geglu_forward_backward_on_packed_layout():
+    M, C4 = 100, 128                      # 4C outputs, 8C packed pre-activations
+    pre_std = rnd(M, 2 * C4, seed=41)     # [value | gate] standard order
+    dy = bf(rnd(M, C4, seed=42))
+    idx = torch.arange(2 * C4)
+    j = torch.where(idx < C4, idx, idx - C4)
+    packed_col = (j // 16) * 32 + torch.where(idx < C4, 0, 16) + (j % 16)
+    pre = torch.empty((M, 2 * C4), dtype=torch.bfloat16, device=DEV)
+    pre[:, packed_col.to(DEV)] = bf(pre_std)
+    y = torch.empty((M, C4), dtype=torch.bfloat16, device=DEV)
+    dpre = torch.empty_like(pre)
+    _lib.call("dfh_geglu_fwd", _lib.ptr(pre), _lib.ptr(y), M, 2 * C4, gu.stream())
+    _lib.call("dfh_geglu_bwd", _lib.ptr(pre), _lib.ptr(dy), _lib.ptr(dpre), M, 2 * C4, gu.stream())
+    torch.cuda.synchronize()
+    p = bf(pre_std).float().requires_grad_(True)
+    v, g = p.chunk(2, -1)
+    ref = v * F.gelu(g)
+    (rp,) = torch.autograd.grad(ref, p, dy.float())
+    gu.assert_close_bf16(y, ref, "geglu fwd")
+    gu.assert_close_bf16(dpre[:, packed_col.to(DEV)], rp, "geglu bwd", rel=8e-3, max_rel=4e-2)
+
+
+@pytest.mark.parametrize("kind,fn,from_out", [(1, F.silu, False), (2, lambda t: F.leaky_relu(t, 0.01), True), (3, torch.tanh, True)])
+def test_pointwise_activation_backward(kind, fn, from_out):
+    x = bf(rnd(4096, seed=43) * 2)
+    dy = bf(rnd(4096, seed=44))
+    xr = x.float().requires_grad_(True)
+    y = fn(xr)
+    (ref,) = torch.autograd.grad(y, xr, dy.float())
+    refin = bf(y.detach()) if from_out else x
+    out = torch.empty_like(x)
+    _lib.call("dfh_act_bwd", _lib.ptr(refin), None, _lib.ptr(dy), None, _lib.ptr(out), x.numel(), kind, 1.0, gu.stream())
+    torch.cuda.synchronize()
+    gu.assert_close_bf16(out, ref, f"act bwd {kind}", rel=1.5e-2, max_rel=5e-2)
+
+
+def test_unpack_is_inverse_of_pack_layouts():
+    cout, cin = 24, 16
+    g = rnd(cout, 9 * cin + 40, seed=45)                     # packed fp32 gradient [N][9*Cin | 40 more columns]
+    grad = torch.zeros(cout, cin, 3, 3, device=DEV)
+    _lib.call("dfh_unpack_conv3x3", _lib.ptr(g), _lib.ptr(grad), cout, cin, g.shape[1], 0, cin, gu.stream())
+    gm = torch.ones(cout, 40, device=DEV)
+    _lib.call("dfh_unpack_matrix", _lib.ptr(g), _lib.ptr(gm), cout, 40, g.shape[1], 0, 9 * cin, 0, gu.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(grad, g[:, :9 * cin].view(cout, 3, 3, cin).permute(0, 3, 1, 2))
+    assert torch.equal(gm, g[:, 9 * cin:] + 1.0)
+
+
+def test_adamw_clip_and_ema_match_torch():
+    n = 10_000
+    p0, shadow0 = rnd(n, seed=46), rnd(n, seed=47)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref_p], lr=1e-2, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    shadow, ref_shadow = shadow0.clone(), shadow0.clone()
+    for step in range(1, 4):
+        g = rnd(n, seed=50 + step) * 3
+        ref_p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        ref_shadow.sub_((1 - 0.999) * (ref_shadow - ref_p.detach()))
+        ss = torch.zeros(1, device=DEV)
+        _lib.call("dfh_sumsq", _lib.ptr(g), n, _lib.ptr(ss), gu.stream())
+        _lib.call("dfh_adamw", _lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), n, 1e-2, 0.9, 0.999, 1e-8, 1e-2, step,
+                  _lib.ptr(ss), 1.0, gu.stream())
+        _lib.call("dfh_ema", _lib.ptr(shadow), _lib.ptr(p), n, 0.999, gu.stream())
+        torch.cuda.synchronize()
+        torch.testing.assert_close(ss[0], (g.double() ** 2).sum().float(), rtol=1e-5, atol=0)
+        torch.testing.assert_close(p, ref_p.detach(), rtol=2e-5, atol=2e-6)
+        torch.testing.assert_close(shadow, ref_shadow, rtol=1e-6, atol=1e-7)

@@ -88,6 +88,9 @@ SIGNATURES = {
     "dfh_groupnorm": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     "dfh_groupnorm_stats": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     "dfh_groupnorm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "dfh_attention_lse": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "dfh_attention_delta": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "dfh_attention_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "dfh_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp]),
     "dfh_pack_matrix_t": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "dfh_pack_conv3x3_t": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

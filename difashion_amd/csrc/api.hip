@@ -160,6 +160,26 @@ int dfh_groupnorm_bwd(const void* src0, int c0, const void* src1, int c1, const 
   a.dx0 = (bf16_t*)dx0; a.dx1 = (bf16_t*)dx1; a.acc0 = acc0; a.acc1 = acc1; a.dgamma = dgamma; a.dbeta = dbeta; a.partial = partial;
   return dfh::groupnorm_bwd_launch(a, (hipStream_t)stream);
 }
+int dfh_attention_lse(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo, int batch,
+                      int heads, int head_dim, int Nq, int Nk, float scale, float* lse, void* stream) {
+  AttnArgs a; std::memset(&a, 0, sizeof(a));
+  a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.Vt = (const bf16_t*)Vt; a.ldvt = ldvt;
+  a.O = (bf16_t*)O; a.ldo = ldo; a.B = batch; a.H = heads; a.D = head_dim; a.Nq = Nq; a.Nk = Nk; a.scale = scale; a.lse = lse;
+  return dfh::attention_launch(a, (hipStream_t)stream);
+}
+int dfh_attention_delta(const void* O, const void* dO, int ld, float* delta, int batch, int heads, int head_dim, int Nq, void* stream) {
+  return dfh::attention_delta_launch((const bf16_t*)O, (const bf16_t*)dO, ld, delta, batch, heads, head_dim, Nq, (hipStream_t)stream);
+}
+int dfh_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* dO, int ldo,
+                      const float* lse, const float* delta, void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv, int batch,
+                      int heads, int head_dim, int Nq, int Nk, float scale, void* stream) {
+  AttnBwdArgs a; std::memset(&a, 0, sizeof(a));
+  a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
+  a.dO = (const bf16_t*)dO; a.ldo = ldo; a.lse = lse; a.delta = delta;
+  a.dQ = (bf16_t*)dQ; a.lddq = lddq; a.dK = (bf16_t*)dK; a.lddk = lddk; a.dV = (bf16_t*)dV; a.lddv = lddv;
+  a.B = batch; a.H = heads; a.D = head_dim; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+  return dfh::attention_bwd_launch(a, (hipStream_t)stream);
+}
 int dfh_layernorm_bwd(const void* x, const void* dy, const float* gamma, void* dx, int accumulate, float* dgamma, float* dbeta,
                       int M, int C, float eps, void* stream) {
   return dfh::layernorm_bwd_launch((const bf16_t*)x, (const bf16_t*)dy, gamma, (bf16_t*)dx, accumulate, dgamma, dbeta, M, C, eps,

@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     const float inv = 1.0f / l;
     const int q = q0 + qt * 16 + fr;
     if (q >= a.Nq) continue;
+    if (a.lse && fg == 0) a.lse[((long)b * a.H + h) * a.Nq + q] = m_run[qt] + __builtin_amdgcn_logf(l);   // v_log_f32 = log2
     bf16_t* orow = a.O + ((long)b * a.Nq + q) * a.ldo + h * D;
 #pragma unroll
     for (int f = 0; f < DF; ++f) {

@@ -1,0 +1,317 @@
+// Attention backward for the training step (torch autograd of diffusers Attention / xformers
+// memory_efficient_attention reached through DiFashion/train.py:699).  Flash-style: the N x N matrices
+// P and dS are recomputed tile by tile from Q, K, V, dO and the forward's per-row log-sum-exp; nothing
+// quadratic is stored.  With S = scale * Q K^T, P = softmax(S), delta = rowsum(dO * O):
+//     dV = P^T dO          dP = dO V^T          dS = P o (dP - delta)
+//     dQ = scale * dS K    dK = scale * dS^T Q
+//
+// One kernel template, run twice (no atomics, deterministic):
+//   pass dQ   : a wave owns 32 QUERY columns (registers: Q, dO fragments); K / V tiles stream through LDS
+//   pass dK,dV: a wave owns 16/32 KEY columns (registers: K, V fragments); Q / dO tiles stream through LDS
+// In both, the "row side" tiles X1 (K | Q) and X2 (V | dO) give  T = X1 . Y1^T  (scores) and
+// U = X2 . Y2^T (dP) as 16x16x32 MFMAs with the rows read by ds_read_b128 in the same permuted order
+// as the forward kernel, so a lane ends up with 8 CONSECUTIVE rows per 32-row chunk for its own column:
+// P and dS go straight back in as MFMA B operands, while the A operands of the accumulations
+// (X^T fragments: head-dim rows, tile rows as contraction) are read transposed from the same row-major
+// LDS tiles with ds_read_b64_tr_b16.  Accumulators are transposed (out^T[d][col]) so a lane finishes with
+// 4 consecutive head-dim values of its own query / key: 8-byte stores, no cross-lane traffic.
+#include "dfh_common.h"
+#include "attention.h"
+
+namespace {
+
+constexpr int XT = 64;   // rows per streamed tile
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+DFH_DEVICE int row_rho(int r) { return (((r >> 3) & 3) << 2) | (r & 3); }
+
+template <int D> struct BwdGeom {
+  static constexpr int KS = (D + 31) / 32;
+  static constexpr int DF = (D + 15) / 16;
+  static constexpr int STR = D <= 64 ? 128 : (D <= 128 ? 256 : 512);   // tile row stride (bytes)
+  static constexpr int TILE = XT * STR;
+  static constexpr int BUF = 2 * TILE + 2 * XT * 4;                    // X1, X2, row stats (lse, delta)
+};
+
+template <int STR> DFH_DEVICE int swz(int row) {
+  const int rho = row_rho(row);
+  return STR == 128 ? ((rho >> 1) & 7) : rho;
+}
+
+// transposed fragment: 8 consecutive tile rows m0..m0+7 of head-dim column d0 + L (A operand rows = head dim)
+template <int STR>
+DFH_DEVICE bf16x8_t tr_frag(const unsigned char* tile, int m0, int d0, int L) {
+  const int col = d0 + (L & 3) * 4;
+  const int r0 = m0 + (L >> 2), r1 = r0 + 4;
+  const unsigned char* p0 = tile + r0 * STR + ((((col >> 3)) ^ swz<STR>(r0)) << 4) + (col & 7) * 2;
+  const unsigned char* p1 = tile + r1 * STR + ((((col >> 3)) ^ swz<STR>(r1)) << 4) + (col & 7) * 2;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// KV_SIDE = false: columns are queries (dQ pass); true: columns are keys (dK / dV pass)
+template <int D, bool KV_SIDE, int NT>
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const AttnBwdArgs a) {
+  using G = BwdGeom<D>;
+  constexpr int KS = G::KS, DF = G::DF, STR = G::STR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int ncols = KV_SIDE ? a.Nk : a.Nq;     // column entities (owned by lanes)
+  const int nrows = KV_SIDE ? a.Nq : a.Nk;     // row entities (streamed)
+  const int c0 = blockIdx.x * (4 * NT * 16) + wave * (NT * 16);
+
+  // column-side operands (registers) and row-side operands (streamed)
+  const bf16_t* Y1 = KV_SIDE ? a.K + (long)b * a.Nk * a.ldk + h * D : a.Q + (long)b * a.Nq * a.ldq + h * D;
+  const bf16_t* Y2 = KV_SIDE ? a.V + (long)b * a.Nk * a.ldv + h * D : a.dO + (long)b * a.Nq * a.ldo + h * D;
+  const int ldy1 = KV_SIDE ? a.ldk : a.ldq, ldy2 = KV_SIDE ? a.ldv : a.ldo;
+  const bf16_t* X1 = KV_SIDE ? a.Q + (long)b * a.Nq * a.ldq + h * D : a.K + (long)b * a.Nk * a.ldk + h * D;
+  const bf16_t* X2 = KV_SIDE ? a.dO + (long)b * a.Nq * a.ldo + h * D : a.V + (long)b * a.Nk * a.ldv + h * D;
+  const int ldx1 = KV_SIDE ? a.ldq : a.ldk, ldx2 = KV_SIDE ? a.ldo : a.ldv;
+  const float* lse = a.lse + ((long)b * a.H + h) * a.Nq;
+  const float* dlt = a.delta + ((long)b * a.H + h) * a.Nq;
+
+  bf16x8_t y1[NT][KS], y2[NT][KS];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = c0 + nt * 16 + fr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = ks * 32 + fg * 8;
+      uint4 v1 = uint4{0, 0, 0, 0}, v2 = uint4{0, 0, 0, 0};
+      if (col < ncols && d0 < D) {
+        v1 = *(const uint4*)(Y1 + (long)col * ldy1 + d0);
+        v2 = *(const uint4*)(Y2 + (long)col * ldy2 + d0);
+      }
+      y1[nt][ks] = __builtin_bit_cast(bf16x8_t, v1);
+      y2[nt][ks] = __builtin_bit_cast(bf16x8_t, v2);
+    }
+  }
+  // per-column softmax statistics (dQ pass: the lane's own query)
+  float col_l[NT], col_d[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = c0 + nt * 16 + fr;
+    col_l[nt] = (!KV_SIDE && col < ncols) ? lse[col] : INFINITY;
+    col_d[nt] = (!KV_SIDE && col < ncols) ? dlt[col] : 0.f;
+  }
+
+  // staging bookkeeping: chunk i of a tile -> (row, 16-byte slot)
+  int s_row[KS], s_slot[KS], s_lds[KS];
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    const int idx = tid + i * 256;
+    s_row[i] = idx / (KS * 4);
+    s_slot[i] = idx - s_row[i] * (KS * 4);
+    s_lds[i] = s_row[i] * STR + ((s_slot[i] ^ swz<STR>(s_row[i])) << 4);
+  }
+  uint4 r1[KS], r2[KS];
+  float rl = 0.f, rd = 0.f;
+  auto load_tile = [&](int row0) {
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      r1[i] = uint4{0, 0, 0, 0}; r2[i] = uint4{0, 0, 0, 0};
+      const int r = row0 + s_row[i];
+      if (r < nrows && s_slot[i] * 8 < D) {
+        r1[i] = *(const uint4*)(X1 + (long)r * ldx1 + s_slot[i] * 8);
+        r2[i] = *(const uint4*)(X2 + (long)r * ldx2 + s_slot[i] * 8);
+      }
+    }
+    if (KV_SIDE && tid < XT) {     // row statistics: +inf lse for rows beyond Nq makes their P exactly 0
+      const int r = row0 + tid;
+      rl = r < nrows ? lse[r] : INFINITY;
+      rd = r < nrows ? dlt[r] : 0.f;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* T1 = smem + buf * G::BUF;
+    unsigned char* T2 = T1 + G::TILE;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) { *(uint4*)(T1 + s_lds[i]) = r1[i]; *(uint4*)(T2 + s_lds[i]) = r2[i]; }
+    if (KV_SIDE && tid < XT) {
+      float* st = (float*)(T2 + G::TILE);
+      st[tid] = rl; st[XT + tid] = rd;
+    }
+  };
+
+  f32x4_t acc1[NT][DF], acc2[KV_SIDE ? NT : 1][KV_SIDE ? DF : 1];   // acc1: dQ^T | dK^T ; acc2: dV^T
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int f = 0; f < DF; ++f) {
+      acc1[nt][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (KV_SIDE) acc2[nt][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+  const float c = a.scale * 1.44269504088896340736f;
+
+  const int ntiles = (nrows + XT - 1) / XT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int row0 = t * XT;
+    const bool more = t + 1 < ntiles;
+    if (more) load_tile(row0 + XT);
+    const unsigned char* T1 = smem + (t & 1) * G::BUF;
+    const unsigned char* T2 = T1 + G::TILE;
+    const float* st = (const float*)(T2 + G::TILE);
+
+    bf16x8_t pf[NT][2], dsf[NT][2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      // two 16-row MFMA tiles cover rows ch*32 + fg*8 + {0..3} and {4..7} for this lane
+      f32x4_t tS[NT][2], tU[NT][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int row = ch * 32 + (fr >> 2) * 8 + u * 4 + (fr & 3);
+        const int sw = swz<STR>(row);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { tS[nt][u] = f32x4_t{0.f, 0.f, 0.f, 0.f}; tU[nt][u] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8_t x1 = *(const bf16x8_t*)(T1 + row * STR + (((ks * 4 + fg) ^ sw) << 4));
+          const bf16x8_t x2 = *(const bf16x8_t*)(T2 + row * STR + (((ks * 4 + fg) ^ sw) << 4));
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            tS[nt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, y1[nt][ks], tS[nt][u], 0, 0, 0);
+            tU[nt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, y2[nt][ks], tU[nt][u], 0, 0, 0);
+          }
+        }
+      }
+      // lane (column fr, group fg) holds rows row0 + ch*32 + fg*8 + u*4 + r
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float p[8], ds[8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int lr = ch * 32 + fg * 8 + u * 4 + r;      // row inside the tile
+            float L, Dl;
+            if (KV_SIDE) { L = st[lr]; Dl = st[XT + lr]; }
+            else { L = (row0 + lr < nrows) ? col_l[nt] : INFINITY; Dl = col_d[nt]; }
+            const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(tS[nt][u][r], c, -L));
+            p[u * 4 + r] = pv;
+            ds[u * 4 + r] = pv * (tU[nt][u][r] - Dl);
+          }
+        uint4 wp, wd;
+        wp.x = pack2bf(p[0], p[1]); wp.y = pack2bf(p[2], p[3]); wp.z = pack2bf(p[4], p[5]); wp.w = pack2bf(p[6], p[7]);
+        wd.x = pack2bf(ds[0], ds[1]); wd.y = pack2bf(ds[2], ds[3]); wd.z = pack2bf(ds[4], ds[5]); wd.w = pack2bf(ds[6], ds[7]);
+        pf[nt][ch] = __builtin_bit_cast(bf16x8_t, wp);
+        dsf[nt][ch] = __builtin_bit_cast(bf16x8_t, wd);
+      }
+    }
+    // ---- accumulate  out^T[d][col] += X^T[d][rows] . Z[rows][col]
+#pragma unroll
+    for (int f = 0; f < DF; ++f)
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        const bf16x8_t a1 = tr_frag<STR>(T1, ch * 32 + fg * 8, f * 16, fr);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc1[nt][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, dsf[nt][ch], acc1[nt][f], 0, 0, 0);
+        if (KV_SIDE) {
+          const bf16x8_t a2 = tr_frag<STR>(T2, ch * 32 + fg * 8, f * 16, fr);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc2[nt][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, pf[nt][ch], acc2[nt][f], 0, 0, 0);
+        }
+      }
+    if (more) store_tile((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- store: lane holds out[col = fr][d = f*16 + fg*4 + r]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = c0 + nt * 16 + fr;
+    if (col >= ncols) continue;
+    bf16_t* o1 = KV_SIDE ? a.dK + ((long)b * a.Nk + col) * a.lddk + h * D : a.dQ + ((long)b * a.Nq + col) * a.lddq + h * D;
+#pragma unroll
+    for (int f = 0; f < DF; ++f) {
+      const int d0 = f * 16 + fg * 4;
+      if (d0 >= D) continue;
+      uint2 o;
+      o.x = pack2bf(acc1[nt][f][0] * a.scale, acc1[nt][f][1] * a.scale);
+      o.y = pack2bf(acc1[nt][f][2] * a.scale, acc1[nt][f][3] * a.scale);
+      *(uint2*)(o1 + d0) = o;
+      if (KV_SIDE) {
+        bf16_t* o2 = a.dV + ((long)b * a.Nk + col) * a.lddv + h * D;
+        uint2 v;
+        v.x = pack2bf(acc2[nt][f][0], acc2[nt][f][1]);
+        v.y = pack2bf(acc2[nt][f][2], acc2[nt][f][3]);
+        *(uint2*)(o2 + d0) = v;
+      }
+    }
+  }
+}
+
+// delta[b][h][q] = sum_d dO * O : one wave per (b, q) row, lanes over channels, per-head segments reduced by shuffles
+__global__ __launch_bounds__(256) void attention_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, int ld,
+                                                              float* __restrict__ delta, int B, int H, int D, int Nq) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)B * Nq) return;
+  const int lane = threadIdx.x & 63;
+  const int b = (int)(row / Nq), q = (int)(row - (long)b * Nq);
+  for (int h = 0; h < H; ++h) {
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += bf2f(O[row * ld + h * D + d]) * bf2f(dO[row * ld + h * D + d]);
+    s = wave_sum(s);
+    if (lane == 0) delta[((long)b * H + h) * Nq + q] = s;
+  }
+}
+
+template <int D, bool KV, int NT>
+int launch_pass(const AttnBwdArgs& a, hipStream_t stream) {
+  constexpr int lds = 2 * BwdGeom<D>::BUF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attention_bwd_kernel<D, KV, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const int ncols = KV ? a.Nk : a.Nq;
+  dim3 grid((ncols + 4 * NT * 16 - 1) / (4 * NT * 16), a.H, a.B);
+  hipLaunchKernelGGL((attention_bwd_kernel<D, KV, NT>), grid, dim3(256), lds, stream, a);
+  return dfh::check_launch("attention_bwd_kernel");
+}
+
+template <int D>
+int launch_bwd(const AttnBwdArgs& a, hipStream_t stream) {
+  dfh::ProfScope ps(dfh::PC_ATTN_BWD, 14.0 * a.B * a.H * (double)a.Nq * a.Nk * D, 2.0 * a.B * a.H * D * (4.0 * a.Nq + 4.0 * a.Nk), stream);
+  if (int rc = launch_pass<D, false, 2>(a, stream)) return rc;
+  return launch_pass<D, true, (D > 80 ? 1 : 2)>(a, stream);
+}
+
+}  // namespace
+
+namespace dfh {
+
+int attention_delta_launch(const bf16_t* O, const bf16_t* dO, int ld, float* delta, int B, int H, int D, int Nq, hipStream_t stream) {
+  const long rows = (long)B * Nq;
+  hipLaunchKernelGGL(attention_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, O, dO, ld, delta, B, H, D, Nq);
+  return check_launch("attention_delta_kernel");
+}
+
+int attention_bwd_launch(const AttnBwdArgs& a, hipStream_t stream) {
+  DFH_REQUIRE(a.Nq > 0 && a.Nk > 0 && a.B > 0 && a.H > 0, "empty attention");
+  DFH_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 8 == 0, "leading dims must be 16-byte aligned");
+  DFH_REQUIRE(a.lddq % 4 == 0 && a.lddk % 4 == 0 && a.lddv % 4 == 0, "gradient leading dims must be 8-byte aligned");
+  DFH_REQUIRE(a.lse && a.delta && a.dQ && a.dK && a.dV, "null pointer");
+  switch (a.D) {
+    case 32: return launch_bwd<32>(a, stream);
+    case 40: return launch_bwd<40>(a, stream);
+    case 64: return launch_bwd<64>(a, stream);
+    case 80: return launch_bwd<80>(a, stream);
+    case 128: return launch_bwd<128>(a, stream);
+    case 160: return launch_bwd<160>(a, stream);
+    default: break;
+  }
+  set_error("attention_bwd_launch: unsupported head dim " + std::to_string(a.D));
+  return -1;
+}
+
+}  // namespace dfh

@@ -156,6 +156,14 @@ int dfh_groupnorm_stats(const void* src0, int c0, const void* src1, int c1, int 
 int dfh_groupnorm_bwd(const void* src0, int c0, const void* src1, int c1, const void* dy, int batch, int hw, int groups,
                       const float* gamma, const float* beta, const float* stats, int silu, void* dx0, int acc0,
                       void* dx1, int acc1, float* dgamma, float* dbeta, float* partial, void* stream);
+/* attention for training: forward that also returns the per-row log2-domain log-sum-exp [B][H][Nq], and the
+ * flash-style backward (V ROW-major [B][Nk][ldv] here; delta = rowsum(dO * O) from dfh_attention_delta) */
+int dfh_attention_lse(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
+                      int batch, int heads, int head_dim, int Nq, int Nk, float scale, float* lse, void* stream);
+int dfh_attention_delta(const void* O, const void* dO, int ld, float* delta, int batch, int heads, int head_dim, int Nq, void* stream);
+int dfh_attention_bwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* dO, int ldo,
+                      const float* lse, const float* delta, void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv,
+                      int batch, int heads, int head_dim, int Nq, int Nk, float scale, void* stream);
 int dfh_layernorm_bwd(const void* x, const void* dy, const float* gamma, void* dx, int accumulate, float* dgamma,
                       float* dbeta, int M, int C, float eps, void* stream);
 /* transposed / flipped weight packing so that data gradients reuse dfh_gemm:

@@ -256,3 +256,37 @@ def test_adamw_clip_and_ema_match_torch():
         torch.testing.assert_close(ss[0], (g.double() ** 2).sum().float(), rtol=1e-5, atol=0)
         torch.testing.assert_close(p, ref_p.detach(), rtol=2e-5, atol=2e-6)
         torch.testing.assert_close(shadow, ref_shadow, rtol=1e-6, atol=1e-7)
+
+
+# ----------------------------------------------------------------------------- attention backward
+@pytest.mark.parametrize("d,heads", [(40, 8), (80, 4), (160, 2), (32, 2), (64, 5), (128, 2)])
+@pytest.mark.parametrize("Nq,Nk", [(256, 256), (64, 64), (200, 77), (4, 4), (320, 1024)])
+def test_attention_backward(d, heads, Nq, Nk):
+    B, Cc = 2, d * heads
+    q, k, v = bf(rnd(B, Nq, Cc, seed=60)), bf(rnd(B, Nk, Cc, seed=61)), bf(rnd(B, Nk, Cc, seed=62))
+    do = bf(rnd(B, Nq, Cc, seed=63))
+    ld = (Nk + 7) // 8 * 8
+    vt = torch.zeros((B, Cc, ld), dtype=torch.bfloat16, device=DEV)
+    vt[:, :, :Nk] = v.transpose(1, 2)
+    o = torch.empty_like(q)
+    lse = torch.empty((B, heads, Nq), device=DEV)
+    scale = d ** -0.5
+    _lib.call("dfh_attention_lse", _lib.ptr(q), Cc, _lib.ptr(k), Cc, _lib.ptr(vt), ld, _lib.ptr(o), Cc, B, heads, d, Nq, Nk,
+              scale, _lib.ptr(lse), gu.stream())
+    delta = torch.empty((B, heads, Nq), device=DEV)
+    _lib.call("dfh_attention_delta", _lib.ptr(o), _lib.ptr(do), Cc, _lib.ptr(delta), B, heads, d, Nq, gu.stream())
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    _lib.call("dfh_attention_bwd", _lib.ptr(q), Cc, _lib.ptr(k), Cc, _lib.ptr(v), Cc, _lib.ptr(do), Cc, _lib.ptr(lse),
+              _lib.ptr(delta), _lib.ptr(dq), Cc, _lib.ptr(dk), Cc, _lib.ptr(dv), Cc, B, heads, d, Nq, Nk, scale, gu.stream())
+    torch.cuda.synchronize()
+    qr, kr, vr = (t.float().view(B, -1, heads, d).transpose(1, 2).detach().requires_grad_(True) for t in (q, k, v))
+    s = (qr @ kr.transpose(-1, -2)) * scale
+    ref_o = torch.softmax(s, -1) @ vr
+    ref_lse = torch.logsumexp(s, -1) * 1.4426950408889634       # log2 domain
+    gq, gk, gv = torch.autograd.grad(ref_o, (qr, kr, vr), do.float().view(B, Nq, heads, d).transpose(1, 2))
+    back = lambda t, n: t.transpose(1, 2).reshape(B, n, Cc)
+    assert gu.max_err(lse, ref_lse) < 2e-2
+    # P and dS are rounded to bf16 before their MFMAs: ~2^-8 relative on top of the bf16 output rounding
+    gu.assert_close_bf16(dv, back(gv, Nk), f"dV d={d} {Nq}x{Nk}", rel=1.5e-2, max_rel=6e-2)
+    gu.assert_close_bf16(dq, back(gq, Nq), f"dQ d={d} {Nq}x{Nk}", rel=1.5e-2, max_rel=6e-2)
+    gu.assert_close_bf16(dk, back(gk, Nk), f"dK d={d} {Nq}x{Nk}", rel=1.5e-2, max_rel=6e-2)

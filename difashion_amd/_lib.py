@@ -81,6 +81,14 @@ SIGNATURES = {
     "dfh_unet_pack": (_i, [_vp, C.POINTER(_vp), _i, _vp]),
     "dfh_unet_forward": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "dfh_unet_debug_tap": (_i, [_vp, C.c_char_p, _vp, _sz, _vp]),
+    "dfh_unet_arena16t_bytes": (_sz, [_vp]),
+    "dfh_unet_grad16_bytes": (_sz, [_vp]),
+    "dfh_unet_grad32_bytes": (_sz, [_vp]),
+    "dfh_unet_train_workspace_bytes": (_sz, [_vp, _i]),
+    "dfh_unet_bind_train": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
+    "dfh_unet_pack_train": (_i, [_vp, C.POINTER(_vp), _i, _vp]),
+    "dfh_unet_forward_train": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "dfh_unet_backward": (_i, [_vp, _vp, _vp, C.POINTER(_vp), _i, _vp]),
     "dfh_gemm_partial_floats": (_sz, [C.POINTER(GemmDesc)]),
     "dfh_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "dfh_gemm_wgrad": (_i, [C.POINTER(GemmDesc), _vp, _i, _vp, _i, _i, _vp]),

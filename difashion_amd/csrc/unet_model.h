@@ -1,0 +1,559 @@
+// Shared definition of the U-Net runtime object (parameter table, packing plan, inference walk).
+// Included by unet.hip (inference + C ABI) and unet_train.hip (training forward / backward).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/difashion_hip.h"
+#include "attention.h"
+#include "dfh_common.h"
+#include "elementwise.h"
+#include "gemm.h"
+#include "norm.h"
+
+namespace dfhm {
+
+struct Mat { size_t off = 0; int N = 0, K = 0; };    // bf16 [N][K] at arena16 + off (elements)
+struct Vec { size_t off = 0; int N = 0; };           // fp32 [N] at arena32 + off (elements)
+
+enum PackKind { PK_VEC = 0, PK_MAT = 1, PK_CONV3 = 2 };
+struct PackOp {
+  int param, kind;
+  size_t dst;
+  int N, K, ldw, row_off, col_off, geglu, accumulate;
+  int cin_pad = 0;   // PK_CONV3: channels per tap in the packed layout (conv_in pads 4 -> 8)
+};
+
+struct ParamDesc { std::string name; std::vector<int> shape; };
+
+// transposed pack (training): master weight -> arena16t, see bwd_elementwise.hip pack_*_t kernels
+struct TPackOp { int param, conv; size_t dst; int N, K, ldt, t_row_off, t_col_off, geglu, o_pad; };
+
+struct ResL {
+  int cin = 0, cout = 0, temb_off = 0; bool shortcut = false;
+  Vec n1w, n1b, b1, n2w, n2b, b2; Mat w1, w2;
+  std::string pre; Mat w1t, w2t, wst;   // training: transposed packs for the data-gradient GEMMs
+};
+struct AttL {
+  int C = 0, heads = 0, x_off = 0;   // x_off: this layer's row offset in the batched cross K / V matrices
+  Vec nw, nb, pinb, l1w, l1b, o1b, l2w, l2b, o2b, l3w, l3b, ff1b, ff2b, poutb;
+  Mat pin, qk, v, o1, q2, o2, ff1, ff2, pout;
+  std::string pre; Mat pint, qkvt, o1t, q2t, o2t, ff1t, ff2t, poutt;
+};
+struct ConvL { Mat w; Vec b; int cin = 0, cout = 0; std::string pre; Mat wt; };
+
+struct Tensor { bf16_t* p = nullptr; int H = 0, W = 0, C = 0; };
+
+struct Bump {
+  char* base = nullptr; size_t cap = 0, off = 0, peak = 0;
+  void* alloc(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    char* p = base + off;
+    off += bytes;
+    if (off > peak) peak = off;
+    return p;
+  }
+};
+
+}  // namespace dfhm
+using namespace dfhm;
+
+struct dfh_unet {
+  dfh_unet_config cfg{};
+  std::vector<ParamDesc> params;
+  std::vector<PackOp> packs;
+  size_t a16 = 0, a32 = 0;         // arena sizes in elements
+  // layers
+  ConvL conv_in, conv_out;
+  Mat te1, te2, tproj, kx_all, vx_all; Vec te1b, te2b, tprojb, cnw, cnb;
+  int temb_total = 0, x_total = 0;   // x_total: sum of C over all transformer layers (batched text K/V)
+  std::vector<std::vector<ResL>> down_res, up_res;
+  std::vector<std::vector<AttL>> down_att, up_att;
+  std::vector<ConvL> down_samp, up_samp;
+  ResL mid_res[2]; AttL mid_att;
+  // bound memory
+  bf16_t* arena16 = nullptr; float* arena32 = nullptr;
+  char* ws = nullptr; size_t ws_bytes = 0; int max_batch = 0;
+  // planning results (bytes) for the last planned batch
+  size_t plan_persist = 0, plan_temp = 0, plan_partial = 0, plan_total = 0; int plan_batch = 0;
+  // taps of the last forward
+  std::map<std::string, Tensor> taps; int last_batch = 0;
+  // ---- training state (unet_train.hip)
+  std::vector<TPackOp> tpacks; size_t a16t = 0; bool train_built = false;
+  Mat te2t, tprojt;
+  bf16_t* arena16t = nullptr; float* grad16 = nullptr; float* grad32 = nullptr;   // grad16/32: fp32, packed layouts of arena16/32
+  char* tws = nullptr; size_t tws_bytes = 0; int train_max_batch = 0;
+  size_t tplan_total = 0; int tplan_batch = 0;
+  struct TrainRun; TrainRun* tr = nullptr;
+  int build_train();
+  size_t plan_train(int B);
+  int forward_train(const void* sample, int sample_bf16, const float* timestep, const void* ehs, int ehs_bf16, float* out, int B,
+                    hipStream_t s);
+  int backward(const float* d_out, float* d_sample, float* const* master_grads, int count, hipStream_t s);
+  int pack_train(const float* const* master, int count, hipStream_t s);
+  ~dfh_unet();
+
+  // ---------------------------------------------------------------- build
+  int add_param(const std::string& name, std::vector<int> shape) {
+    params.push_back({name, std::move(shape)});
+    return (int)params.size() - 1;
+  }
+  size_t alloc16(size_t n) { size_t o = a16; a16 += (n + 127) & ~(size_t)127; return o; }
+  size_t alloc32(size_t n) { size_t o = a32; a32 += (n + 63) & ~(size_t)63; return o; }
+
+  Vec vec(const std::string& name, int N) {
+    Vec v; v.N = N; v.off = alloc32(N);
+    int p = add_param(name, {N});
+    packs.push_back({p, PK_VEC, v.off, N, 0, 0, 0, 0, 0, 0});
+    return v;
+  }
+  // packs a vector parameter into an existing fp32 range (batched biases / fused shortcut bias)
+  void vec_into(const std::string& name, int N, size_t dst, int geglu, int accumulate) {
+    int p = add_param(name, {N});
+    packs.push_back({p, PK_VEC, dst, N, 0, 0, 0, 0, geglu, accumulate});
+  }
+  Mat mat_alloc(int N, int K) { Mat m; m.N = N; m.K = K; m.off = alloc16((size_t)N * K); return m; }
+  void mat_into(const std::string& name, int N, int K, bool as_conv1x1, const Mat& dst, int row_off, int col_off, int geglu) {
+    std::vector<int> shape = as_conv1x1 ? std::vector<int>{N, K, 1, 1} : std::vector<int>{N, K};
+    int p = add_param(name, shape);
+    packs.push_back({p, PK_MAT, dst.off, N, K, dst.K, row_off, col_off, geglu, 0});
+  }
+  Mat mat(const std::string& name, int N, int K, bool as_conv1x1 = false, int geglu = 0) {
+    Mat m = mat_alloc(N, K);
+    mat_into(name, N, K, as_conv1x1, m, 0, 0, geglu);
+    return m;
+  }
+  void conv_into(const std::string& name, int cout, int cin, const Mat& dst, int col_off, int cin_pad = 0) {
+    int p = add_param(name, {cout, cin, 3, 3});
+    PackOp op{p, PK_CONV3, dst.off, cout, cin, dst.K, 0, col_off, 0, 0};
+    op.cin_pad = cin_pad ? cin_pad : cin;
+    packs.push_back(op);
+  }
+
+  void build_resnet(const std::string& pre, int cin, int cout, ResL& r) {
+    const int temb = cfg.block_out_channels[0] * 4;
+    r.cin = cin; r.cout = cout; r.shortcut = cin != cout; r.pre = pre;
+    r.n1w = vec(pre + ".norm1.weight", cin);
+    r.n1b = vec(pre + ".norm1.bias", cin);
+    r.w1 = mat_alloc(cout, 9 * cin);
+    conv_into(pre + ".conv1.weight", cout, cin, r.w1, 0);
+    r.b1 = vec(pre + ".conv1.bias", cout);
+    r.temb_off = temb_total;
+    temb_total += cout;
+    // time_emb_proj rows are packed later into the batched matrix (needs the final total): remember via params
+    add_param(pre + ".time_emb_proj.weight", {cout, temb});
+    add_param(pre + ".time_emb_proj.bias", {cout});
+    r.n2w = vec(pre + ".norm2.weight", cout);
+    r.n2b = vec(pre + ".norm2.bias", cout);
+    r.w2 = mat_alloc(cout, 9 * cout + (r.shortcut ? cin : 0));
+    conv_into(pre + ".conv2.weight", cout, cout, r.w2, 0);
+    r.b2 = vec(pre + ".conv2.bias", cout);
+    if (r.shortcut) {
+      mat_into(pre + ".conv_shortcut.weight", cout, cin, true, r.w2, 0, 9 * cout, 0);
+      vec_into(pre + ".conv_shortcut.bias", cout, r.b2.off, 0, /*accumulate=*/1);
+    }
+  }
+
+  void build_attn(const std::string& pre, int C, int heads, AttL& a) {
+    const bool lin = cfg.use_linear_projection != 0;
+    const int X = cfg.cross_attention_dim;
+    a.C = C; a.heads = heads; a.pre = pre;
+    a.nw = vec(pre + ".norm.weight", C);
+    a.nb = vec(pre + ".norm.bias", C);
+    a.pin = mat(pre + ".proj_in.weight", C, C, !lin);
+    a.pinb = vec(pre + ".proj_in.bias", C);
+    const std::string tb = pre + ".transformer_blocks.0";
+    a.l1w = vec(tb + ".norm1.weight", C); a.l1b = vec(tb + ".norm1.bias", C);
+    a.l2w = vec(tb + ".norm2.weight", C); a.l2b = vec(tb + ".norm2.bias", C);
+    a.l3w = vec(tb + ".norm3.weight", C); a.l3b = vec(tb + ".norm3.bias", C);
+    a.qk = mat_alloc(2 * C, C);
+    mat_into(tb + ".attn1.to_q.weight", C, C, false, a.qk, 0, 0, 0);
+    mat_into(tb + ".attn1.to_k.weight", C, C, false, a.qk, C, 0, 0);
+    a.v = mat(tb + ".attn1.to_v.weight", C, C);
+    a.o1 = mat(tb + ".attn1.to_out.0.weight", C, C);
+    a.o1b = vec(tb + ".attn1.to_out.0.bias", C);
+    a.q2 = mat(tb + ".attn2.to_q.weight", C, C);
+    a.x_off = x_total;            // to_k / to_v of every layer are packed into two stacked matrices (below)
+    x_total += C;
+    add_param(tb + ".attn2.to_k.weight", {C, X});
+    add_param(tb + ".attn2.to_v.weight", {C, X});
+    a.o2 = mat(tb + ".attn2.to_out.0.weight", C, C);
+    a.o2b = vec(tb + ".attn2.to_out.0.bias", C);
+    a.ff1 = mat(tb + ".ff.net.0.proj.weight", 8 * C, C, false, /*geglu=*/1);
+    a.ff1b.N = 8 * C; a.ff1b.off = alloc32(8 * C);
+    vec_into(tb + ".ff.net.0.proj.bias", 8 * C, a.ff1b.off, 1, 0);
+    a.ff2 = mat(tb + ".ff.net.2.weight", C, 4 * C);
+    a.ff2b = vec(tb + ".ff.net.2.bias", C);
+    a.pout = mat(pre + ".proj_out.weight", C, C, !lin);
+    a.poutb = vec(pre + ".proj_out.bias", C);
+  }
+
+  void build_conv(const std::string& pre, int cout, int cin, ConvL& c) {
+    // conv_out has 4 output channels; conv_in 8 (or 4, padded to 8 with zero weights) input channels:
+    // both go through the same GEMM
+    const int cp = (cin + 7) & ~7;
+    c.cin = cp; c.cout = cout; c.pre = pre;
+    c.w = mat_alloc(cout, 9 * cp);
+    conv_into(pre + ".weight", cout, cin, c.w, 0, cp);
+    c.b = vec(pre + ".bias", cout);
+  }
+
+  int build() {
+    const int nb = cfg.num_blocks;
+    const int* boc = cfg.block_out_channels;
+    const int temb = boc[0] * 4;
+    build_conv("conv_in", boc[0], cfg.in_channels, conv_in);
+    te1 = mat("time_embedding.linear_1.weight", temb, boc[0]);
+    te1b = vec("time_embedding.linear_1.bias", temb);
+    te2 = mat("time_embedding.linear_2.weight", temb, temb);
+    te2b = vec("time_embedding.linear_2.bias", temb);
+    down_res.resize(nb); down_att.resize(nb); down_samp.resize(nb);
+    up_res.resize(nb); up_att.resize(nb); up_samp.resize(nb);
+    int ch = boc[0];
+    for (int i = 0; i < nb; ++i) {
+      const int oc = boc[i];
+      down_res[i].resize(cfg.layers_per_block);
+      if (cfg.down_attn[i]) down_att[i].resize(cfg.layers_per_block);
+      for (int j = 0; j < cfg.layers_per_block; ++j) {
+        const std::string b = "down_blocks." + std::to_string(i);
+        build_resnet(b + ".resnets." + std::to_string(j), j == 0 ? ch : oc, oc, down_res[i][j]);
+      }
+      for (int j = 0; j < cfg.layers_per_block && cfg.down_attn[i]; ++j)
+        build_attn("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), oc, cfg.num_heads[i], down_att[i][j]);
+      if (i != nb - 1) build_conv("down_blocks." + std::to_string(i) + ".downsamplers.0.conv", oc, oc, down_samp[i]);
+      ch = oc;
+    }
+    const int mid = boc[nb - 1];
+    build_resnet("mid_block.resnets.0", mid, mid, mid_res[0]);
+    build_attn("mid_block.attentions.0", mid, cfg.num_heads[nb - 1], mid_att);
+    build_resnet("mid_block.resnets.1", mid, mid, mid_res[1]);
+    int out_ch = boc[nb - 1];
+    for (int i = 0; i < nb; ++i) {
+      const int prev = out_ch;
+      out_ch = boc[nb - 1 - i];
+      const int in_ch = boc[nb - 1 - std::min(i + 1, nb - 1)];
+      const bool att = cfg.down_attn[nb - 1 - i] != 0;
+      const int L = cfg.layers_per_block + 1;
+      up_res[i].resize(L);
+      if (att) up_att[i].resize(L);
+      const std::string b = "up_blocks." + std::to_string(i);
+      for (int j = 0; j < L; ++j) {
+        const int skip = (j == L - 1) ? in_ch : out_ch;
+        const int hid = (j == 0) ? prev : out_ch;
+        build_resnet(b + ".resnets." + std::to_string(j), hid + skip, out_ch, up_res[i][j]);
+      }
+      for (int j = 0; j < L && att; ++j)
+        build_attn(b + ".attentions." + std::to_string(j), out_ch, cfg.num_heads[nb - 1 - i], up_att[i][j]);
+      if (i != nb - 1) build_conv(b + ".upsamplers.0.conv", out_ch, out_ch, up_samp[i]);
+    }
+    cnw = vec("conv_norm_out.weight", boc[0]);
+    cnb = vec("conv_norm_out.bias", boc[0]);
+    build_conv("conv_out", cfg.out_channels, boc[0], conv_out);
+    // batched time_emb_proj: [temb_total][temb] + bias; rows of each resnet at its temb_off
+    tproj = mat_alloc(temb_total, temb);
+    tprojb.N = temb_total; tprojb.off = alloc32(temb_total);
+    // batched cross-attention K / V projections of the text states: [x_total][cross_dim] each
+    kx_all = mat_alloc(x_total, cfg.cross_attention_dim);
+    vx_all = mat_alloc(x_total, cfg.cross_attention_dim);
+    auto pack_cross = [&](const AttL& a, const std::string& pre) {
+      const std::string tb = pre + ".transformer_blocks.0";
+      for (int p = 0; p < (int)params.size(); ++p) {
+        if (params[p].name == tb + ".attn2.to_k.weight")
+          packs.push_back({p, PK_MAT, kx_all.off, a.C, cfg.cross_attention_dim, cfg.cross_attention_dim, a.x_off, 0, 0, 0});
+        else if (params[p].name == tb + ".attn2.to_v.weight")
+          packs.push_back({p, PK_MAT, vx_all.off, a.C, cfg.cross_attention_dim, cfg.cross_attention_dim, a.x_off, 0, 0, 0});
+      }
+    };
+    for (int i = 0; i < nb; ++i)
+      for (int j = 0; j < (int)down_att[i].size(); ++j)
+        pack_cross(down_att[i][j], "down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j));
+    pack_cross(mid_att, "mid_block.attentions.0");
+    for (int i = 0; i < nb; ++i)
+      for (int j = 0; j < (int)up_att[i].size(); ++j)
+        pack_cross(up_att[i][j], "up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j));
+    auto pack_tproj = [&](const ResL& r, const std::string& pre) {
+      for (int p = 0; p < (int)params.size(); ++p) {
+        if (params[p].name == pre + ".time_emb_proj.weight")
+          packs.push_back({p, PK_MAT, tproj.off, r.cout, temb, temb, r.temb_off, 0, 0, 0});
+        else if (params[p].name == pre + ".time_emb_proj.bias")
+          packs.push_back({p, PK_VEC, tprojb.off + (size_t)r.temb_off, r.cout, 0, 0, 0, 0, 0, 0});
+      }
+    };
+    for (int i = 0; i < nb; ++i)
+      for (int j = 0; j < (int)down_res[i].size(); ++j)
+        pack_tproj(down_res[i][j], "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j));
+    pack_tproj(mid_res[0], "mid_block.resnets.0");
+    pack_tproj(mid_res[1], "mid_block.resnets.1");
+    for (int i = 0; i < nb; ++i)
+      for (int j = 0; j < (int)up_res[i].size(); ++j)
+        pack_tproj(up_res[i][j], "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j));
+    return 0;
+  }
+
+  // ---------------------------------------------------------------- run
+  struct Run {
+    dfh_unet* u; int B; hipStream_t s; bool dry;
+    Bump persist, temp; size_t partial_need = 0;
+    float* partial = nullptr; size_t partial_cap = 0;
+    float* gn_partial = nullptr; bf16_t* zero = nullptr;
+    int rc = 0;
+
+    bf16_t* w16(const Mat& m) const { return u->arena16 + m.off; }
+    float* v32(const Vec& v) const { return u->arena32 + v.off; }
+    Tensor palloc(int H, int W, int C) { return Tensor{(bf16_t*)persist.alloc((size_t)B * H * W * C * 2), H, W, C}; }
+    Tensor talloc(int H, int W, int C) { return Tensor{(bf16_t*)temp.alloc((size_t)B * H * W * C * 2), H, W, C}; }
+
+    void gemm(GemmArgs g) {
+      if (rc) return;
+      g.zero = zero; g.partial = partial;
+      if (dry) { partial_need = std::max(partial_need, dfh::gemm_partial_floats(g) * sizeof(float)); return; }
+      if (dfh::gemm_partial_floats(g) * sizeof(float) > partial_cap) { dfh::set_error("split-K partial buffer too small"); rc = -1; return; }
+      rc = dfh::gemm_launch(g, s);
+    }
+    static GemmArgs base(int M, int N) {
+      GemmArgs g; std::memset(&g, 0, sizeof(g));
+      g.M = M; g.N = N; g.rows_per_b = M; g.out_mode = OUT_BF16; g.ld_out = N;
+      return g;
+    }
+    // out = act(x . W^T + bias) (+resid); x rows [M][K]
+    void linear(const bf16_t* x, int M, int K, const Mat& W, const Vec* bias, int act, const bf16_t* resid, void* out,
+                int N, int out_mode = OUT_BF16, int ld_out = -1, int rows_per_b = 0) {
+      GemmArgs g = base(M, N);
+      g.p_src[0] = x; g.p_c[0] = K; g.nplain = 1;
+      g.W = w16(W); g.ldw = W.K;
+      g.bias = bias ? v32(*bias) : nullptr;
+      g.act = act; g.resid = resid; g.ld_res = N;
+      g.out = out; g.out_mode = out_mode; g.ld_out = ld_out < 0 ? (act == ACT_GEGLU ? N / 2 : N) : ld_out;
+      if (rows_per_b) g.rows_per_b = rows_per_b;
+      gemm(g);
+    }
+    void groupnorm(const Tensor& x0, const Tensor* x1, const Vec& w, const Vec& b, float eps, int silu, Tensor& out) {
+      if (rc || dry) return;
+      GnArgs a; std::memset(&a, 0, sizeof(a));
+      a.src0 = x0.p; a.C0 = x0.C; a.src1 = x1 ? x1->p : nullptr; a.C1 = x1 ? x1->C : 0;
+      a.B = B; a.HW = x0.H * x0.W; a.G = u->cfg.norm_num_groups;
+      a.gamma = v32(w); a.beta = v32(b); a.eps = eps; a.silu = silu; a.out = out.p; a.partial = gn_partial;
+      rc = dfh::groupnorm_launch(a, s);
+    }
+    void layernorm(const bf16_t* x, const Vec& w, const Vec& b, bf16_t* y, int M, int C) {
+      if (rc || dry) return;
+      rc = dfh::layernorm_launch(x, v32(w), v32(b), y, M, C, 1e-5f, s);
+    }
+    void attention(const bf16_t* Q, int ldq, const bf16_t* K, int ldk, const bf16_t* Vt, int ldvt, bf16_t* O, int C,
+                   int heads, int Nq, int Nk, long vt_bstride = 0) {
+      if (rc || dry) return;
+      AttnArgs a; std::memset(&a, 0, sizeof(a));
+      a.vt_bstride = vt_bstride;
+      a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.Vt = Vt; a.ldvt = ldvt; a.O = O; a.ldo = C;
+      a.B = B; a.H = heads; a.D = C / heads; a.Nq = Nq; a.Nk = Nk;
+      a.scale = 1.0f / sqrtf((float)a.D);
+      rc = dfh::attention_launch(a, s);
+    }
+
+    // 3x3 conv (pad 1) as implicit GEMM; optional stride-2 / fused nearest-2x upsample
+    Tensor conv(const Tensor& x, const ConvL& c, int stride, int ups, bool to_persist) {
+      const int Ho = ups ? x.H * 2 : (stride == 2 ? x.H / 2 : x.H);
+      const int Wo = ups ? x.W * 2 : (stride == 2 ? x.W / 2 : x.W);
+      Tensor o = to_persist ? palloc(Ho, Wo, c.cout) : talloc(Ho, Wo, c.cout);
+      GemmArgs g = base(B * Ho * Wo, c.cout);
+      g.conv_src = x.p; g.conv_c = x.C; g.ntaps = 9;
+      g.Hin = x.H; g.Win = x.W; g.Hout = Ho; g.Wout = Wo; g.stride = stride; g.ups = ups;
+      g.W = w16(c.w); g.ldw = c.w.K; g.bias = v32(c.b);
+      g.out = o.p;
+      gemm(g);
+      return o;
+    }
+
+    Tensor resnet(const Tensor& x0, const Tensor* x1, const ResL& r, const float* temb_all) {
+      const int H = x0.H, W = x0.W;
+      Tensor out = palloc(H, W, r.cout);
+      const size_t mark = temp.off;
+      Tensor g1 = talloc(H, W, r.cin);
+      groupnorm(x0, x1, r.n1w, r.n1b, u->cfg.norm_eps, 1, g1);
+      Tensor h1 = talloc(H, W, r.cout);
+      {
+        GemmArgs g = base(B * H * W, r.cout);
+        g.conv_src = g1.p; g.conv_c = r.cin; g.ntaps = 9;
+        g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.stride = 1;
+        g.W = w16(r.w1); g.ldw = r.w1.K; g.bias = v32(r.b1);
+        g.rowvec = temb_all; g.rv_ld = u->temb_total; g.rv_off = r.temb_off; g.rows_per_b = H * W;
+        g.out = h1.p;
+        gemm(g);
+      }
+      Tensor g2 = talloc(H, W, r.cout);
+      groupnorm(h1, nullptr, r.n2w, r.n2b, u->cfg.norm_eps, 1, g2);
+      {
+        GemmArgs g = base(B * H * W, r.cout);
+        g.conv_src = g2.p; g.conv_c = r.cout; g.ntaps = 9;
+        g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.stride = 1;
+        g.W = w16(r.w2); g.ldw = r.w2.K; g.bias = v32(r.b2);
+        if (r.shortcut) {   // 1x1 shortcut over the (possibly concatenated) block input rides along as K segments
+          g.p_src[0] = x0.p; g.p_c[0] = x0.C; g.nplain = 1;
+          if (x1) { g.p_src[1] = x1->p; g.p_c[1] = x1->C; g.nplain = 2; }
+        } else {
+          g.resid = x0.p; g.ld_res = r.cout;
+        }
+        g.out = out.p;
+        gemm(g);
+      }
+      temp.off = mark;
+      return out;
+    }
+
+    Tensor transformer(const Tensor& x, const AttL& a, const bf16_t* kx, const bf16_t* vxt, int T) {
+      const int H = x.H, W = x.W, C = a.C, N = H * W, M = B * N;
+      Tensor out = palloc(H, W, C);
+      const size_t mark = temp.off;
+      Tensor gn = talloc(H, W, C);
+      groupnorm(x, nullptr, a.nw, a.nb, 1e-6f, 0, gn);
+      Tensor h0 = talloc(H, W, C);
+      linear(gn.p, M, C, a.pin, &a.pinb, ACT_NONE, nullptr, h0.p, C);
+      // --- self attention
+      Tensor n1 = talloc(H, W, C);
+      layernorm(h0.p, a.l1w, a.l1b, n1.p, M, C);
+      Tensor qk = talloc(H, W, 2 * C);
+      linear(n1.p, M, C, a.qk, nullptr, ACT_NONE, nullptr, qk.p, 2 * C);
+      const int Np = (N + 7) & ~7;    // V^T rows padded to 8 keys (the 2x2 level of tiny configs has N = 4)
+      bf16_t* vt = (bf16_t*)temp.alloc((size_t)B * C * Np * 2);   // [B][C][Np]
+      linear(n1.p, M, C, a.v, nullptr, ACT_NONE, nullptr, vt, C, OUT_BF16_T, Np, N);
+      Tensor at = talloc(H, W, C);
+      attention(qk.p, 2 * C, qk.p + C, 2 * C, vt, Np, at.p, C, a.heads, N, N);
+      Tensor h1 = talloc(H, W, C);
+      linear(at.p, M, C, a.o1, &a.o1b, ACT_NONE, h0.p, h1.p, C);
+      // --- cross attention over the T text tokens
+      const int Tp = (T + 7) & ~7;
+      layernorm(h1.p, a.l2w, a.l2b, n1.p, M, C);
+      linear(n1.p, M, C, a.q2, nullptr, ACT_NONE, nullptr, qk.p, C);
+      // text K / V^T of this layer live inside the batched projections computed once per forward
+      const int XT = u->x_total;
+      attention(qk.p, C, kx + a.x_off, XT, vxt + (size_t)a.x_off * Tp, Tp, at.p, C, a.heads, N, T, (long)XT * Tp);
+      Tensor h2 = talloc(H, W, C);
+      linear(at.p, M, C, a.o2, &a.o2b, ACT_NONE, h1.p, h2.p, C);
+      // --- GEGLU feed-forward
+      layernorm(h2.p, a.l3w, a.l3b, n1.p, M, C);
+      Tensor ff = talloc(H, W, 4 * C);
+      linear(n1.p, M, C, a.ff1, &a.ff1b, ACT_GEGLU, nullptr, ff.p, 8 * C);
+      linear(ff.p, M, 4 * C, a.ff2, &a.ff2b, ACT_NONE, h2.p, h0.p, C);   // h0 is dead by now: reuse
+      linear(h0.p, M, C, a.pout, &a.poutb, ACT_NONE, x.p, out.p, C);
+      temp.off = mark;
+      return out;
+    }
+  };
+
+  int run(const void* sample, int sample_bf16, const float* timestep, const void* ehs, int ehs_bf16, float* out, int B,
+          hipStream_t s, bool dry) {
+    Run r; r.u = this; r.B = B; r.s = s; r.dry = dry;
+    const int S = cfg.sample_size, T = cfg.text_len, X = cfg.cross_attention_dim;
+    const int* boc = cfg.block_out_channels;
+    const int nb = cfg.num_blocks, temb = boc[0] * 4;
+    // fixed regions at the head of the workspace
+    Bump head; head.base = dry ? nullptr : ws;
+    r.zero = (bf16_t*)head.alloc(256);
+    r.gn_partial = (float*)head.alloc((size_t)B * GN_MAX_CHUNKS * 64 * 2 * sizeof(float));
+    r.partial = (float*)head.alloc(dry ? 0 : plan_partial);
+    r.partial_cap = dry ? 0 : plan_partial;
+    const size_t head_bytes = (head.off + 255) & ~(size_t)255;
+    if (!dry) {
+      if (B != plan_batch) { dfh::set_error("forward batch differs from the planned batch"); return -1; }
+      r.persist.base = ws + head_bytes;
+      r.temp.base = ws + head_bytes + plan_persist;
+      if (head_bytes + plan_persist + plan_temp > ws_bytes) { dfh::set_error("workspace too small"); return -1; }
+      (void)hipMemsetAsync(r.zero, 0, 256, s);
+    }
+    taps.clear();
+
+    // ---- time embedding: sinusoid -> MLP (SiLU folded into both epilogues: only silu(emb) is ever
+    //      consumed) -> all 22 time_emb_proj rows in one GEMM (fp32 [B][temb_total])
+    bf16_t* tsin = (bf16_t*)r.persist.alloc((size_t)B * boc[0] * 2);
+    bf16_t* e1 = (bf16_t*)r.persist.alloc((size_t)B * temb * 2);
+    bf16_t* e2 = (bf16_t*)r.persist.alloc((size_t)B * temb * 2);
+    float* temb_all = (float*)r.persist.alloc((size_t)B * temb_total * 4);
+    if (!dry) r.rc = dfh::timestep_embed_launch(timestep, tsin, B, boc[0], s);
+    r.linear(tsin, B, boc[0], te1, &te1b, ACT_SILU, nullptr, e1, temb);
+    r.linear(e1, B, temb, te2, &te2b, ACT_SILU, nullptr, e2, temb);
+    r.linear(e2, B, temb, tproj, &tprojb, ACT_NONE, nullptr, temb_all, temb_total, OUT_F32);
+
+    // ---- inputs to kernel layout
+    bf16_t* ehs16 = (bf16_t*)r.persist.alloc((size_t)B * T * X * 2);
+    if (!dry && !r.rc) {
+      if (ehs_bf16) (void)hipMemcpyAsync(ehs16, ehs, (size_t)B * T * X * 2, hipMemcpyDeviceToDevice, s);
+      else r.rc = dfh::cast_f32_to_bf16_launch((const float*)ehs, ehs16, (long)B * T * X, s);
+    }
+    // text K for every transformer layer in one GEMM ([B*T][x_total]) and V^T in another ([B][x_total][Tp])
+    const int Tp = (T + 7) & ~7;
+    bf16_t* kx = (bf16_t*)r.persist.alloc((size_t)B * T * x_total * 2);
+    bf16_t* vxt = (bf16_t*)r.persist.alloc((size_t)B * x_total * Tp * 2);
+    r.linear(ehs16, B * T, X, kx_all, nullptr, ACT_NONE, nullptr, kx, x_total);
+    r.linear(ehs16, B * T, X, vx_all, nullptr, ACT_NONE, nullptr, vxt, x_total, OUT_BF16_T, Tp, T);
+    Tensor x = r.palloc(S, S, conv_in.cin);   // in_channels padded to a multiple of 8
+    if (!dry && !r.rc) r.rc = dfh::nchw_to_nhwc_launch(sample, sample_bf16, x.p, B, cfg.in_channels, S * S, s);
+
+    Tensor h = r.conv(x, conv_in, 1, 0, true);
+    taps["conv_in"] = h;
+    std::vector<Tensor> skips{h};
+    for (int i = 0; i < nb; ++i) {
+      for (int j = 0; j < cfg.layers_per_block; ++j) {
+        h = r.resnet(h, nullptr, down_res[i][j], temb_all);
+        if (cfg.down_attn[i]) h = r.transformer(h, down_att[i][j], kx, vxt, T);
+        skips.push_back(h);
+      }
+      if (i != nb - 1) { h = r.conv(h, down_samp[i], 2, 0, true); skips.push_back(h); }
+      taps["down" + std::to_string(i)] = h;
+    }
+    h = r.resnet(h, nullptr, mid_res[0], temb_all);
+    h = r.transformer(h, mid_att, kx, vxt, T);
+    h = r.resnet(h, nullptr, mid_res[1], temb_all);
+    taps["mid"] = h;
+    for (int i = 0; i < nb; ++i) {
+      for (int j = 0; j < (int)up_res[i].size(); ++j) {
+        Tensor sk = skips.back(); skips.pop_back();
+        h = r.resnet(h, &sk, up_res[i][j], temb_all);
+        if (!up_att[i].empty()) h = r.transformer(h, up_att[i][j], kx, vxt, T);
+      }
+      if (i != nb - 1) h = r.conv(h, up_samp[i], 1, 1, true);
+      taps["up" + std::to_string(i)] = h;
+    }
+    Tensor g = r.palloc(h.H, h.W, h.C);
+    r.groupnorm(h, nullptr, cnw, cnb, cfg.norm_eps, 1, g);
+    {
+      GemmArgs ga = Run::base(B * S * S, cfg.out_channels);
+      ga.conv_src = g.p; ga.conv_c = g.C; ga.ntaps = 9;
+      ga.Hin = S; ga.Win = S; ga.Hout = S; ga.Wout = S; ga.stride = 1;
+      ga.W = r.w16(conv_out.w); ga.ldw = conv_out.w.K; ga.bias = r.v32(conv_out.b);
+      ga.out = out; ga.out_mode = OUT_F32_T; ga.ld_out = S * S; ga.rows_per_b = S * S;
+      r.gemm(ga);
+    }
+    if (dry) {
+      plan_persist = (r.persist.peak + 255) & ~(size_t)255;
+      plan_temp = (r.temp.peak + 255) & ~(size_t)255;
+      plan_partial = (r.partial_need + 255) & ~(size_t)255;
+      plan_batch = B;
+      // head is re-derived with the real partial size
+      Bump hd; hd.alloc(256); hd.alloc((size_t)B * GN_MAX_CHUNKS * 64 * 2 * sizeof(float)); hd.alloc(plan_partial);
+      plan_total = ((hd.off + 255) & ~(size_t)255) + plan_persist + plan_temp;
+      taps.clear();
+    } else {
+      last_batch = B;
+    }
+    return r.rc;
+  }
+
+  int pack(const float* const* master, int count, hipStream_t s) {
+    DFH_REQUIRE(count == (int)params.size(), "parameter count mismatch");
+    DFH_REQUIRE(arena16 && arena32, "arenas not bound");
+    for (const PackOp& op : packs) {
+      const float* src = master[op.param];
+      DFH_REQUIRE(src != nullptr, "null master parameter: " + params[op.param].name);
+      int rc = 0;
+      if (op.kind == PK_VEC) rc = dfh::pack_vector_launch(src, arena32, op.N, (int)op.dst, op.geglu, op.accumulate, s);
+      else if (op.kind == PK_MAT) rc = dfh::pack_matrix_launch(src, arena16 + op.dst, op.N, op.K, op.ldw, op.row_off, op.col_off, op.geglu, s);
+      else rc = dfh::pack_conv3x3_launch(src, arena16 + op.dst, op.N, op.K, op.ldw, op.col_off, s, op.cin_pad);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+};

@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 namespace dfh {
 
 int wgrad_launch(WgradArgs a, hipStream_t s) {
-  DFH_REQUIRE(a.M > 0 && a.N > 0 && a.N % 8 == 0, "wgrad: N must be a positive multiple of 8");
+  DFH_REQUIRE(a.M > 0 && a.N > 0 && a.N % 4 == 0 && a.ldy % 8 == 0 && a.ldy >= ((a.N + 7) & ~7),
+              "wgrad: N must be a positive multiple of 4, dY rows padded to a multiple of 8 columns");
   DFH_REQUIRE(a.ntaps == 0 || a.ntaps == 9, "ntaps must be 0 or 9");
   DFH_REQUIRE(a.ntaps + a.nplain >= 1 && a.zero && a.dY && a.dW, "wgrad: missing operand");
   int chunks = a.ntaps * ((a.conv_c + WBK - 1) / WBK);

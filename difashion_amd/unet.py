@@ -10,6 +10,12 @@ Mirrors what the reference glue requires of ``self.unet``:
   * ``enable_gradient_checkpointing()`` / ``enable_xformers_memory_efficient_attention()`` (train.py:560,
     difashion.py:118) -- accepted; attention here is always the fused flash-style HIP kernel.
 
+Training (train.py:691-716): with grad enabled and parameters that require grad, ``forward`` runs the
+saving forward of the native library and hooks one autograd node onto the result; ``loss.backward()``
+then runs the native backward walk, which ADDS the parameter gradients straight into ``p.grad`` (views of
+one flat fp32 buffer; created zero-filled when ``p.grad is None``) and hands autograd only the gradient
+of ``sample`` (the path to the MutualEncoder).  encoder_hidden_states gets no gradient (frozen CLIP).
+
 All arithmetic runs in libdifashion_hip.so (include/difashion_hip.h).  The fp32 ``nn.Parameter``s are
 the master weights (optimizers / EMA / checkpoints keep working on them); ``pack()`` converts them to
 the bf16 kernel layouts whenever they change.  There is no PyTorch/CPU fallback.
@@ -40,6 +46,24 @@ class FrozenDict(dict):
             return self[k]
         except KeyError as e:
             raise AttributeError(k) from e
+
+
+class _UNetStep(torch.autograd.Function):
+    """One autograd node for the whole U-Net: forward = dfh_unet_forward_train, backward = dfh_unet_backward."""
+
+    @staticmethod
+    def forward(ctx, model, sample, t, ehs, anchor):
+        ctx.model = model
+        ctx.need_dsample = bool(sample.requires_grad)
+        ctx.in_dtype = sample.dtype
+        return model._native_forward(sample, t, ehs, train=True)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        d_sample = ctx.model._native_backward(d_out, ctx.need_dsample)
+        if d_sample is not None and d_sample.dtype != ctx.in_dtype:
+            d_sample = d_sample.to(ctx.in_dtype)
+        return None, d_sample, None, None, None
 
 
 class _Node(nn.Module):
@@ -84,6 +108,10 @@ class UNet2DConditionModel(nn.Module):
         self._names = None
         self._buffers_dev = None
         self._packed_sig = None
+        self._train_buffers = None      # (arena16t, grad16, grad32, workspace) once a training step has run
+        self._train_batch = 0
+        self._grad_flat = None
+        self._anchor = None
         # parameter tree straight from the C table (single source of truth for names and shapes)
         ctx = self._make_ctx()
         try:
@@ -219,6 +247,27 @@ class UNet2DConditionModel(nn.Module):
         self._names = [n for n, _ in table]
         self._buffers_dev = (a16, a32, ws)
         self._packed_sig = None
+        self._train_buffers = None
+        self._train_batch = 0
+
+    def _ensure_train(self, batch: int):
+        """Bind the training arenas / workspace (sized for ``batch``; grows on demand)."""
+        self._ensure_ctx(min(batch, self.max_batch))
+        if self._train_buffers is not None and batch <= self._train_batch:
+            return
+        lib = _lib.raw()
+        dev = self.device
+        ctx = self._ctx
+        a16t = torch.zeros(lib.dfh_unet_arena16t_bytes(ctx), dtype=torch.uint8, device=dev)
+        g16 = torch.empty(lib.dfh_unet_grad16_bytes(ctx), dtype=torch.uint8, device=dev)
+        g32 = torch.empty(lib.dfh_unet_grad32_bytes(ctx), dtype=torch.uint8, device=dev)
+        wsb = lib.dfh_unet_train_workspace_bytes(ctx, batch)
+        self._train_buffers = None          # release the previous workspace before allocating the next
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _lib.call("dfh_unet_bind_train", ctx, _lib.ptr(a16t), _lib.ptr(g16), _lib.ptr(g32), _lib.ptr(ws), wsb, batch)
+        self._train_buffers = (a16t, g16, g32, ws)
+        self._train_batch = batch
+        self._packed_sig = None             # the transposed packs have to be (re)built
 
     def _signature(self, params):
         return tuple((p.data_ptr(), p._version) for p in params)
@@ -233,10 +282,76 @@ class UNet2DConditionModel(nn.Module):
             return
         arr = (C.c_void_p * len(plist))(*[p.data_ptr() for p in plist])
         _lib.call("dfh_unet_pack", self._ctx, arr, len(plist), _lib.stream_ptr())
+        if self._train_buffers is not None:
+            _lib.call("dfh_unet_pack_train", self._ctx, arr, len(plist), _lib.stream_ptr())
         self._packed_sig = sig
 
     def workspace_bytes(self) -> int:
-        return 0 if self._buffers_dev is None else sum(b.numel() for b in self._buffers_dev)
+        n = 0 if self._buffers_dev is None else sum(b.numel() for b in self._buffers_dev)
+        return n + (0 if self._train_buffers is None else sum(b.numel() for b in self._train_buffers))
+
+    # ------------------------------------------------------------------ native calls
+    def _native_forward(self, sample, t, ehs, train: bool):
+        B = sample.shape[0]
+        cfg = self.config
+        if train:
+            self._ensure_train(B)
+        else:
+            self._ensure_ctx(B)
+        if not (self.assume_static_weights and self._packed_sig is not None):
+            self.pack()
+        dt = {torch.float32: 0, torch.bfloat16: 1}
+        out = torch.empty((B, cfg["out_channels"], sample.shape[2], sample.shape[3]), dtype=torch.float32, device=sample.device)
+        _lib.call("dfh_unet_forward_train" if train else "dfh_unet_forward", self._ctx, _lib.ptr(sample), dt[sample.dtype],
+                  _lib.ptr(t), _lib.ptr(ehs), dt[ehs.dtype], _lib.ptr(out), B, _lib.stream_ptr())
+        if sample.dtype != torch.float32:
+            out = out.to(sample.dtype)
+        return out
+
+    def grad_views(self):
+        """Table-order list of the parameters' gradient tensors, creating missing ones as zero-filled views of one
+        flat fp32 buffer (the layout the fused optimizer and the RCCL gradient all-reduce work on)."""
+        named = dict(self.named_parameters())
+        plist = [named[n] for n in self._names]
+        missing = [p for p in plist if p.requires_grad and p.grad is None]
+        if missing:
+            if self._grad_flat is None or self._grad_flat.device != self.device:
+                total = sum((p.numel() + 63) // 64 * 64 for p in plist)
+                self._grad_flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+                self._grad_slices = {}
+                off = 0
+                for p in plist:
+                    self._grad_slices[id(p)] = (off, p.numel())
+                    off += (p.numel() + 63) // 64 * 64
+            if len(missing) == sum(1 for p in plist if p.requires_grad):
+                self._grad_flat.zero_()
+                for p in missing:
+                    off, n = self._grad_slices[id(p)]
+                    p.grad = self._grad_flat[off:off + n].view(p.shape)
+            else:
+                for p in missing:
+                    off, n = self._grad_slices[id(p)]
+                    v = self._grad_flat[off:off + n].view(p.shape)
+                    v.zero_()
+                    p.grad = v
+        return plist
+
+    def _native_backward(self, d_out, need_dsample: bool):
+        d_out = d_out.contiguous().float()
+        plist = self.grad_views()
+        for p in plist:
+            if p.grad is not None and (p.grad.dtype != torch.float32 or not p.grad.is_contiguous()):
+                raise _lib.DfhError("parameter gradients must be contiguous fp32 tensors")
+        arr = (C.c_void_p * len(plist))(*[(p.grad.data_ptr() if (p.requires_grad and p.grad is not None) else None)
+                                          for p in plist])
+        cfg = self.config
+        d_sample = None
+        if need_dsample:
+            d_sample = torch.empty((d_out.shape[0], int(self.conv_in.weight.shape[1]), cfg["sample_size"], cfg["sample_size"]),
+                                   dtype=torch.float32, device=d_out.device)
+        _lib.call("dfh_unet_backward", self._ctx, _lib.ptr(d_out), _lib.ptr(d_sample) if need_dsample else None, arr,
+                  len(plist), _lib.stream_ptr())
+        return d_sample
 
     # ------------------------------------------------------------------ forward
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor,
@@ -252,11 +367,9 @@ class UNet2DConditionModel(nn.Module):
         if tuple(encoder_hidden_states.shape) != (B, cfg["text_len"], cfg["cross_attention_dim"]):
             raise ValueError(f"encoder_hidden_states must be {(B, cfg['text_len'], cfg['cross_attention_dim'])}, "
                              f"got {tuple(encoder_hidden_states.shape)}")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in (sample, encoder_hidden_states)):
-            raise NotImplementedError("the HIP U-Net backward is not built yet (round 2): call under torch.no_grad()")
-        self._ensure_ctx(B)
-        if not (self.assume_static_weights and self._packed_sig is not None):
-            self.pack()
+        if torch.is_grad_enabled() and encoder_hidden_states.requires_grad:
+            raise NotImplementedError("no gradient is produced for encoder_hidden_states (frozen text states in the reference)")
+        self._ensure_ctx(min(B, self.max_batch))
         dev = sample.device
         # timestep forms of difashion.py:251 ((B,) int64) and :520 (0-d tensor) / python numbers
         if not torch.is_tensor(timestep):
@@ -273,11 +386,13 @@ class UNet2DConditionModel(nn.Module):
             raise TypeError("sample / encoder_hidden_states must be float32 or bfloat16")
         sample = sample.contiguous()
         ehs = encoder_hidden_states.contiguous()
-        out = torch.empty((B, cfg["out_channels"], H, W), dtype=torch.float32, device=dev)
-        _lib.call("dfh_unet_forward", self._ctx, _lib.ptr(sample), dt[sample.dtype], _lib.ptr(t), _lib.ptr(ehs),
-                  dt[ehs.dtype], _lib.ptr(out), B, _lib.stream_ptr())
-        if sample.dtype != torch.float32:
-            out = out.to(sample.dtype)
+        train = torch.is_grad_enabled() and (sample.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if train:
+            if self._anchor is None or self._anchor.device != dev:
+                self._anchor = torch.zeros((), device=dev, requires_grad=True)   # makes autograd call the node's backward
+            out = _UNetStep.apply(self, sample, t, ehs, self._anchor)
+        else:
+            out = self._native_forward(sample, t, ehs, train=False)
         return UNet2DConditionOutput(out) if return_dict else (out,)
 
     def debug_tap(self, name: str) -> torch.Tensor:

@@ -96,6 +96,34 @@ int dfh_unet_pack(dfh_unet* u, const float* const* master_params, int count, voi
 int dfh_unet_forward(dfh_unet* u, const void* sample, int sample_bf16, const float* timestep,
                      const void* ehs, int ehs_bf16, float* out, int batch, void* stream);
 
+/* ------------------------------------------------------------------ training step (train.py:691-716)
+ * Replaces torch autograd through the U-Net: accelerator.backward(loss) at DiFashion/train.py:699 for the module
+ * called at DiFashion/models/difashion.py:249-253.  Shares arena16/arena32 with the inference path
+ * (dfh_unet_bind + dfh_unet_pack first) and adds
+ *   arena16t  : bf16 transposed/flipped weight packs for the data-gradient GEMMs   (dfh_unet_arena16t_bytes)
+ *   grad16/32 : fp32 gradient arenas in the PACKED layouts of arena16 / arena32      (dfh_unet_grad16/32_bytes)
+ *   workspace : every activation of one step + gradient buffers                      (dfh_unet_train_workspace_bytes)
+ * All pointers 256-byte aligned device memory; arena16t must be zero-filled before the first pack. */
+size_t dfh_unet_arena16t_bytes(dfh_unet* u);
+size_t dfh_unet_grad16_bytes(const dfh_unet* u);
+size_t dfh_unet_grad32_bytes(const dfh_unet* u);
+size_t dfh_unet_train_workspace_bytes(dfh_unet* u, int batch);
+int dfh_unet_bind_train(dfh_unet* u, void* arena16t, void* grad16, void* grad32, void* workspace, size_t workspace_bytes,
+                        int max_batch);
+/* master parameters -> arena16t; call together with dfh_unet_pack after every weight update */
+int dfh_unet_pack_train(dfh_unet* u, const float* const* master_params, int count, void* stream);
+/* same arguments and result as dfh_unet_forward; keeps the activations the backward needs */
+int dfh_unet_forward_train(dfh_unet* u, const void* sample, int sample_bf16, const float* timestep,
+                           const void* ehs, int ehs_bf16, float* out, int batch, void* stream);
+/* Backward of the LAST dfh_unet_forward_train (one backward per forward).
+ *   d_out        : [B][out_channels][H][W] fp32, gradient of the loss wrt the noise prediction
+ *   d_sample     : [B][in_channels][H][W] fp32 or NULL (gradient wrt the assembled input -> MutualEncoder)
+ *   master_grads : table-order device pointers to the fp32 .grad of each parameter; gradients are ADDED
+ *                  (entries may be NULL to skip a frozen parameter).  encoder_hidden_states gets no gradient
+ *                  (frozen CLIP text states, df.py:229-247). */
+int dfh_unet_backward(dfh_unet* u, const float* d_out, float* d_sample, float* const* master_grads, int count,
+                      void* stream);
+
 /* Copies a named NHWC bf16 intermediate of the LAST forward into ``dst`` as fp32 NCHW (layer-level
  * parity tests).  Names: "conv_in", "down0".."down3", "mid", "up0".."up3". */
 int dfh_unet_debug_tap(dfh_unet* u, const char* name, float* dst, size_t dst_floats, void* stream);

@@ -10,9 +10,11 @@ from ._lib import DfhError
 from .mutual import MutualEncoder
 from .pipeline import OutfitSampler, guidance_plan, sample_outfits, sampling_tables, train_forward, training_tables
 from .schedulers import DDIMScheduler, PNDMScheduler
+from .training import EMAModel, FusedAdamW, clip_grad_norm_, train_step
 from .unet import UNet2DConditionModel, UNet2DConditionOutput
 
 __all__ = [
     "DfhError", "UNet2DConditionModel", "UNet2DConditionOutput", "DDIMScheduler", "PNDMScheduler",
     "MutualEncoder", "OutfitSampler", "sample_outfits", "train_forward", "guidance_plan", "sampling_tables", "training_tables",
+    "FusedAdamW", "EMAModel", "clip_grad_norm_", "train_step",
 ]

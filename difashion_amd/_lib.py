@@ -113,7 +113,7 @@ SIGNATURES = {
     "dfh_act_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _f, _vp]),
     "dfh_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     "dfh_transpose_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _sz, _sz, _vp]),
-    "dfh_mse_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "dfh_mse_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "dfh_assemble_bwd": (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     "dfh_sumsq": (_i, [_vp, _sz, _vp, _vp]),
     "dfh_adamw": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
@@ -174,6 +174,20 @@ def call(name: str, *args):
     if name not in _NO_STATUS and SIGNATURES[name][0] is _i and rc != 0:
         raise DfhError(f"{name} failed ({rc}): {last_error()}")
     return rc
+
+
+_WEIGHT_EPOCH = 0
+
+
+def weight_epoch() -> int:
+    """Bumped by the fused optimizer after it rewrites master weights in place (torch version counters do not see a
+    native kernel's writes); part of every pack signature."""
+    return _WEIGHT_EPOCH
+
+
+def bump_weight_epoch():
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
 
 
 def prof_begin():

@@ -228,8 +228,9 @@ int dfh_transpose_bf16(const void* in, void* out, int batch, int R, int C, int l
   return dfh::transpose_bf16_launch((const bf16_t*)in, (bf16_t*)out, batch, R, C, ld_in, ld_out, (long)in_bstride, (long)out_bstride,
                                     (hipStream_t)stream);
 }
-int dfh_mse_bwd(const float* pred, const float* target, const float* w, float* dpred, int rows, int L, float loss_scale, void* stream) {
-  return dfh::mse_bwd_launch(pred, target, w, dpred, rows, L, loss_scale, (hipStream_t)stream);
+int dfh_mse_bwd(const float* pred, const float* target, const float* w, float* dpred, int rows, int L, float loss_scale,
+                const float* scale_dev, void* stream) {
+  return dfh::mse_bwd_launch(pred, target, w, dpred, rows, L, loss_scale, scale_dev, (hipStream_t)stream);
 }
 int dfh_assemble_bwd(const float* dx, const uint8_t* mutual_real, float* dmutual, int rows, int CL, float eta, void* stream) {
   return dfh::assemble_bwd_launch(dx, mutual_real, dmutual, rows, CL, eta, (hipStream_t)stream);

@@ -19,7 +19,8 @@ int act_bwd_launch(const bf16_t* ref, const float* ref_f32, const bf16_t* dy, co
 int nhwc_to_nchw_f32_launch(const bf16_t* src, float* dst, int B, int HW, int Cp, int C, float scale, int accumulate, hipStream_t s);
 int transpose_bf16_launch(const bf16_t* in, bf16_t* out, int B, int R, int C, int ld_in, int ld_out, long in_bstride, long out_bstride,
                           hipStream_t s);
-int mse_bwd_launch(const float* pred, const float* target, const float* w, float* dpred, int rows, int L, float loss_scale, hipStream_t s);
+int mse_bwd_launch(const float* pred, const float* target, const float* w, float* dpred, int rows, int L, float loss_scale,
+                   const float* scale_dev, hipStream_t s);
 int assemble_bwd_launch(const float* dx, const unsigned char* mutual_real, float* dmutual, int rows, int CL, float eta, hipStream_t s);
 int sumsq_launch(const float* g, long n, float* out, hipStream_t s);
 int adamw_launch(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,

@@ -200,10 +200,12 @@ __global__ void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __r
 // ---- loss / glue backward -----------------------------------------------------------------------------------
 // d pred = w[row] * 2 * (pred - target) / (rows * L)     (mean over rows of per-row MSE * weight; df.py:255-265)
 __global__ void mse_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, const float* __restrict__ w,
-                               float* __restrict__ dpred, int rows, int L, float loss_scale) {
+                               float* __restrict__ dpred, int rows, int L, float loss_scale,
+                               const float* __restrict__ scale_dev) {
   const long i = gtid();
   if (i >= (long)rows * L) return;
   const int r = (int)(i / L);
+  if (scale_dev) loss_scale *= *scale_dev;      // upstream d loss (autograd) stays on the device: no host sync
   const float ww = (w ? w[r] : 1.0f) * loss_scale * 2.0f / ((float)rows * (float)L);
   dpred[i] = ww * (pred[i] - target[i]);
 }
@@ -309,8 +311,9 @@ int transpose_bf16_launch(const bf16_t* in, bf16_t* out, int B, int R, int C, in
                      in_bstride, out_bstride);
   return check_launch("transpose_bf16_kernel");
 }
-int mse_bwd_launch(const float* pred, const float* target, const float* w, float* dpred, int rows, int L, float loss_scale, hipStream_t s) {
-  EW_LAUNCH(mse_bwd_kernel, (long)rows * L, pred, target, w, dpred, rows, L, loss_scale);
+int mse_bwd_launch(const float* pred, const float* target, const float* w, float* dpred, int rows, int L, float loss_scale,
+                   const float* scale_dev, hipStream_t s) {
+  EW_LAUNCH(mse_bwd_kernel, (long)rows * L, pred, target, w, dpred, rows, L, loss_scale, scale_dev);
 }
 int assemble_bwd_launch(const float* dx, const unsigned char* mutual_real, float* dmutual, int rows, int CL, float eta, hipStream_t s) {
   EW_LAUNCH(assemble_bwd_kernel, (long)rows * CL, dx, mutual_real, dmutual, rows, CL, eta);

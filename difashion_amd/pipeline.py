@@ -197,7 +197,52 @@ def sample_outfits(unet, fashion_encoder: MutualEncoder, scheduler, *, olists: t
     return s.latents
 
 
-@torch.no_grad()
+class _AssembleInput(torch.autograd.Function):
+    """x = cat([(1 - eta) * noisy + eta * masked_mutual, masked_hist]) (difashion.py:186-216).  Only the mutual
+    condition carries a gradient (to the MutualEncoder): d mutual = eta * dx[:, :C] on rows whose condition is real."""
+
+    @staticmethod
+    def forward(ctx, noisy, mutual, hist, null_lat, m_u8, h_u8, eta):
+        n, CL = noisy.shape[0], noisy[0].numel()
+        x_in = torch.empty((n, 2 * noisy.shape[1]) + tuple(noisy.shape[2:]), dtype=torch.float32, device=noisy.device)
+        _lib.call("dfh_assemble_input", _lib.ptr(noisy), _lib.ptr(mutual), _lib.ptr(hist), _lib.ptr(null_lat),
+                  _lib.ptr(m_u8), _lib.ptr(h_u8), _lib.ptr(x_in), 1, n, CL, float(1 - eta), float(eta), 1, _lib.stream_ptr())
+        ctx.m_u8, ctx.eta, ctx.shape = m_u8, float(eta), tuple(mutual.shape)
+        return x_in
+
+    @staticmethod
+    def backward(ctx, dx):
+        dx = dx.contiguous().float()
+        n = dx.shape[0]
+        CL = dx[0].numel() // 2
+        dm = torch.empty(ctx.shape, dtype=torch.float32, device=dx.device)
+        _lib.call("dfh_assemble_bwd", _lib.ptr(dx), _lib.ptr(ctx.m_u8), _lib.ptr(dm), n, CL, ctx.eta, _lib.stream_ptr())
+        return None, dm, None, None, None, None, None
+
+
+class _WeightedMse(torch.autograd.Function):
+    """mean over rows of w[row] * mse(pred[row], target[row]) (difashion.py:255-265; w = min-SNR weights or None).
+    The upstream gradient is consumed on the device, so ``loss.backward()`` never synchronises the host."""
+
+    @staticmethod
+    def forward(ctx, pred, target, w):
+        n, L = pred.shape[0], pred[0].numel()
+        rows = torch.empty(n, dtype=torch.float32, device=pred.device)
+        _lib.call("dfh_mse_rows", _lib.ptr(pred), _lib.ptr(target), _lib.ptr(rows), n, L, _lib.stream_ptr())
+        ctx.kept = (pred, target, w)
+        return rows.mean() if w is None else (rows * w).mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, w = ctx.kept
+        n, L = pred.shape[0], pred[0].numel()
+        g = g.contiguous().float()
+        dpred = torch.empty_like(pred)
+        _lib.call("dfh_mse_bwd", _lib.ptr(pred), _lib.ptr(target), _lib.ptr(w) if w is not None else None, _lib.ptr(dpred),
+                  n, L, 1.0, _lib.ptr(g), _lib.stream_ptr())
+        return dpred, None, None
+
+
 def train_forward(unet, fashion_encoder: MutualEncoder, scheduler, *, latents: torch.Tensor, noise: torch.Tensor,
                   timesteps_outfit: torch.Tensor, null_latent: torch.Tensor, hist_latents: torch.Tensor,
                   ehs: torch.Tensor, null_prompt: torch.Tensor, random_p: Optional[torch.Tensor],
@@ -210,7 +255,11 @@ def train_forward(unet, fashion_encoder: MutualEncoder, scheduler, *, latents: t
 
     ``timesteps_outfit`` (bsz,): the draw of :154; ``random_p`` / ``random_p_cate``: the torch.rand draws
     of :188 / :236 (masks are derived from them on the host, as plain index bookkeeping);
-    ``hist_latents``: rows chosen at :177-184 before masking.  Backward / optimizer are round-2 work."""
+    ``hist_latents``: rows chosen at :177-184 before masking.
+
+    With grad enabled the returned loss carries an autograd graph of four native nodes (loss, U-Net, input assembly,
+    MutualEncoder): ``loss.backward()`` / ``accelerator.backward(loss)`` (train.py:699) runs the HIP backward and adds
+    the gradients into ``.grad`` of the U-Net and encoder parameters."""
     dev = latents.device
     if dev.type != "cuda":
         raise _lib.DfhError("train_forward runs on the HIP path only (device tensors required)")
@@ -218,11 +267,12 @@ def train_forward(unet, fashion_encoder: MutualEncoder, scheduler, *, latents: t
     n = latents.shape[0]
     CL = latents[0].numel()
     S = latents.shape[-1]
-    lat = latents.to(**f32).contiguous()
-    noi = noise.to(**f32).contiguous()
-    t = timesteps_outfit.to(dev).repeat_interleave(olen).long()
-    noisy = scheduler.add_noise(lat, noi, t)
-    null_lat = null_latent.to(**f32).contiguous()
+    with torch.no_grad():
+        lat = latents.to(**f32).contiguous()
+        noi = noise.to(**f32).contiguous()
+        t = timesteps_outfit.to(dev).repeat_interleave(olen).long()
+        noisy = scheduler.add_noise(lat, noi, t)
+        null_lat = null_latent.to(**f32).contiguous()
     sp = _lib.stream_ptr
     if use_mutual_guidance:
         tab, wt = training_tables(n, olen)
@@ -230,7 +280,7 @@ def train_forward(unet, fashion_encoder: MutualEncoder, scheduler, *, latents: t
         mb = torch.empty((n, CL), dtype=torch.bfloat16, device=dev)
         _lib.call("dfh_mutual_reduce", _lib.ptr(noisy), None, _lib.ptr(tab), _lib.ptr(wt),
                   _lib.ptr(mb), None, n, olen, CL, sp())
-        mutual = fashion_encoder.forward_bf16(mb, dropout_mask)
+        mutual = fashion_encoder.forward_bf16(mb, dropout_mask).contiguous()
     else:
         mutual = null_lat.expand(n, -1, -1, -1).contiguous()
     # condition dropout (difashion.py:186-213): per-row "is real" flags
@@ -245,12 +295,9 @@ def train_forward(unet, fashion_encoder: MutualEncoder, scheduler, *, latents: t
             hist_real = ~(rp < mask_ratio)
         elif use_mutual_guidance:
             mutual_real = ~(rp < mask_ratio)
-    x_in = torch.empty((n, 2 * latents.shape[1], S, S), **f32)
     hist = hist_latents.to(**f32).contiguous()
     m_u8, h_u8 = mutual_real.to(torch.uint8), hist_real.to(torch.uint8)
-    _lib.call("dfh_assemble_input", _lib.ptr(noisy), _lib.ptr(mutual), _lib.ptr(hist),
-              _lib.ptr(null_lat), _lib.ptr(m_u8), _lib.ptr(h_u8),
-              _lib.ptr(x_in), 1, n, CL, float(1 - eta), float(eta), 1, sp())
+    x_in = _AssembleInput.apply(noisy, mutual, hist, null_lat, m_u8, h_u8, eta)
     states = ehs.to(dev).clone()
     if cate_mask_ratio is not None:
         states[random_p_cate.to(dev) < cate_mask_ratio] = null_prompt.to(dev)[0]
@@ -262,14 +309,12 @@ def train_forward(unet, fashion_encoder: MutualEncoder, scheduler, *, latents: t
     else:
         raise ValueError(f"Unknown prediction type {ptype}")
     pred = unet(x_in, t, states, return_dict=False)[0]
-    rows = torch.empty(n, **f32)
     pred, target = pred.contiguous(), target.contiguous()
-    _lib.call("dfh_mse_rows", _lib.ptr(pred), _lib.ptr(target), _lib.ptr(rows), n, CL, sp())
     if taps is not None:
-        taps.update(x_in=x_in, timesteps=t, ehs=states, target=target, pred=pred)
-    if snr_gamma is None:
-        return rows.mean()
-    ac = scheduler.alphas_cumprod
-    snr = ((ac ** 0.5)[t.cpu()] / ((1.0 - ac) ** 0.5)[t.cpu()]) ** 2
-    w = (torch.minimum(snr, torch.full_like(snr, snr_gamma)) / snr).to(dev)
-    return (rows * w).mean()
+        taps.update(x_in=x_in.detach(), timesteps=t, ehs=states, target=target, pred=pred.detach())
+    w = None
+    if snr_gamma is not None:
+        ac = scheduler.alphas_cumprod.to(dev)          # min-SNR weights (difashion.py:258-263), looked up on the device
+        snr = ((ac ** 0.5)[t] / ((1.0 - ac) ** 0.5)[t]) ** 2
+        w = (torch.minimum(snr, torch.full_like(snr, snr_gamma)) / snr).to(**f32).contiguous()
+    return _WeightedMse.apply(pred, target, w)

@@ -1,0 +1,278 @@
+"""Optimizer side of the training step on the HIP path (reference: DiFashion/train.py:586-593 AdamW,
+:700-704 clip_grad_norm_ / optimizer.step / zero_grad, :707-711 EMAModel.step).
+
+MI355X-first: the parameters of all modules handed to ``FusedAdamW`` are re-homed into ONE flat fp32 buffer, their
+gradients into another (the native backward adds into those views), so that a step is three HBM-bound launches
+(squared-norm, AdamW with the clip coefficient read on the device, EMA) instead of ~700 x 3 small ones, and the
+data-parallel gradient exchange is a single RCCL all-reduce of one buffer (difashion_amd/dist.py).
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Iterable, List, Optional
+
+import torch
+
+from . import _lib
+
+
+def _align(n: int, a: int = 64) -> int:
+    return (n + a - 1) // a * a
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (decoupled weight decay, bias correction) with clip_grad_norm_ folded in.
+
+    ``max_grad_norm``: when set, ``step()`` first reduces the global squared gradient norm on the device and scales the
+    gradients by ``min(1, max_norm / (norm + 1e-6))`` inside the update kernel (accelerator.clip_grad_norm_, train.py:701).
+    ``param_groups`` keep working for LR schedulers; every group is a contiguous slice of the flat buffers."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 max_grad_norm: Optional[float] = None):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.max_grad_norm = max_grad_norm
+        plist = [p for g in self.param_groups for p in g["params"]]
+        if not plist:
+            raise ValueError("no parameters")
+        dev = plist[0].device
+        if dev.type != "cuda":
+            raise _lib.DfhError("FusedAdamW runs on the HIP path only: move the modules to 'cuda' first")
+        for p in plist:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise _lib.DfhError("FusedAdamW needs fp32 parameters on one device")
+        total = sum(_align(p.numel()) for p in plist)
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._slices = {}
+        self._group_ranges = []
+        off = 0
+        for g in self.param_groups:
+            start = off
+            for p in g["params"]:
+                n = p.numel()
+                view = self.flat_param[off:off + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                gv = self.flat_grad[off:off + n].view(p.shape)
+                if p.grad is not None:
+                    gv.copy_(p.grad)
+                p.grad = gv if p.requires_grad else None
+                self._slices[id(p)] = (off, n)
+                off += _align(n)
+            self._group_ranges.append((start, off))
+        self._step = 0
+
+    # the gradient views are permanent: zero_grad never drops them (the native backward accumulates in place)
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat_grad.zero_()
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.requires_grad and (p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * self._slices[id(p)][0]):
+                    off, n = self._slices[id(p)]
+                    p.grad = self.flat_grad[off:off + n].view(p.shape)
+
+    def grad_norm(self) -> torch.Tensor:
+        """Global L2 norm of the gradients at the last step() (device scalar; no host sync)."""
+        return self._sumsq.sqrt()[0]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        s = _lib.stream_ptr()
+        self._step += 1
+        n = self.flat_grad.numel()
+        self._sumsq.zero_()
+        _lib.call("dfh_sumsq", _lib.ptr(self.flat_grad), n, _lib.ptr(self._sumsq), s)
+        clip = self.max_grad_norm is not None
+        for g, (a, b) in zip(self.param_groups, self._group_ranges):
+            if b == a:
+                continue
+            b1, b2 = g["betas"]
+            _lib.call("dfh_adamw", self.flat_param.data_ptr() + 4 * a, self.flat_grad.data_ptr() + 4 * a,
+                      self.exp_avg.data_ptr() + 4 * a, self.exp_avg_sq.data_ptr() + 4 * a, b - a, float(g["lr"]), float(b1),
+                      float(b2), float(g["eps"]), float(g["weight_decay"]), self._step,
+                      _lib.ptr(self._sumsq) if clip else None, float(self.max_grad_norm or 0.0), s)
+        _lib.bump_weight_epoch()          # packed bf16 copies of these weights are stale now
+        return loss
+
+    def state_dict(self):
+        state, idx = {}, 0
+        groups = []
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                off, n = self._slices[id(p)]
+                state[idx] = dict(step=torch.tensor(float(self._step)), exp_avg=self.exp_avg[off:off + n].view(p.shape).clone(),
+                                  exp_avg_sq=self.exp_avg_sq[off:off + n].view(p.shape).clone())
+                ids.append(idx)
+                idx += 1
+            groups.append({**{k: v for k, v in g.items() if k != "params"}, "params": ids})
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        idx = 0
+        for g, sg in zip(self.param_groups, sd["param_groups"]):
+            for k, v in sg.items():
+                if k != "params":
+                    g[k] = v
+            for p in g["params"]:
+                st = sd["state"].get(idx, sd["state"].get(str(idx)))
+                if st is not None:
+                    off, n = self._slices[id(p)]
+                    self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                    self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    self._step = int(float(st["step"]))
+                idx += 1
+
+
+class EMAModel:
+    """diffusers.training_utils.EMAModel as the reference uses it (train.py:506-511, :707-711, :517-520): shadow
+    parameters updated by ``shadow -= (1 - decay) * (shadow - param)`` with the diffusers decay schedule.  When the live
+    parameters sit in a FusedAdamW flat buffer the whole update is one launch."""
+
+    def __init__(self, parameters: Iterable[torch.nn.Parameter], decay: float = 0.9999, min_decay: float = 0.0,
+                 update_after_step: int = 0, use_ema_warmup: bool = False, inv_gamma: float = 1.0, power: float = 2 / 3,
+                 model_cls=None, model_config=None):
+        parameters = list(parameters)
+        self.decay, self.min_decay, self.update_after_step = decay, min_decay, update_after_step
+        self.use_ema_warmup, self.inv_gamma, self.power = use_ema_warmup, inv_gamma, power
+        self.optimization_step = 0
+        self.model_cls, self.model_config = model_cls, model_config
+        self._sizes = [p.numel() for p in parameters]
+        self._shapes = [tuple(p.shape) for p in parameters]
+        total = sum(_align(n) for n in self._sizes)
+        dev = parameters[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.shadow_params = self._views()
+        for s, p in zip(self.shadow_params, parameters):
+            s.copy_(p.detach())
+        self.temp_stored_params = None
+
+    def _views(self) -> List[torch.Tensor]:
+        out, off = [], 0
+        for n, shape in zip(self._sizes, self._shapes):
+            out.append(self.flat[off:off + n].view(shape))
+            off += _align(n)
+        return out
+
+    def get_decay(self, optimization_step: int) -> float:
+        step = max(0, optimization_step - self.update_after_step - 1)
+        if step <= 0:
+            return 0.0
+        cur = 1 - (1 + step / self.inv_gamma) ** -self.power if self.use_ema_warmup else (1 + step) / (10 + step)
+        return max(min(cur, self.decay), self.min_decay)
+
+    def to(self, device=None, dtype=None):
+        if device is not None and torch.device(device) != self.flat.device:
+            self.flat = self.flat.to(device)
+            self.shadow_params = self._views()
+        return self
+
+    @torch.no_grad()
+    def step(self, parameters: Iterable[torch.nn.Parameter]):
+        parameters = list(parameters)
+        self.optimization_step += 1
+        decay = self.get_decay(self.optimization_step)
+        if self.flat.device.type != "cuda":
+            raise _lib.DfhError("EMAModel.step runs on the HIP path only: call .to('cuda') first")
+        s = _lib.stream_ptr()
+        # one launch when the live parameters are laid out like the shadow (FusedAdamW flat buffer, same order)
+        p0 = parameters[0]
+        base = p0.data_ptr()
+        off, contiguous = 0, all(p.requires_grad for p in parameters)
+        if contiguous:
+            for p, n in zip(parameters, self._sizes):
+                if p.data_ptr() != base + 4 * off:
+                    contiguous = False
+                    break
+                off += _align(n)
+        if contiguous:
+            _lib.call("dfh_ema", _lib.ptr(self.flat), base, self.flat.numel() - (_align(self._sizes[-1]) - self._sizes[-1]),
+                      float(decay), s)
+            return
+        for sh, p in zip(self.shadow_params, parameters):
+            if p.requires_grad:
+                _lib.call("dfh_ema", _lib.ptr(sh), _lib.ptr(p.data), p.numel(), float(decay), s)
+            else:
+                sh.copy_(p.data)
+
+    @torch.no_grad()
+    def copy_to(self, parameters: Iterable[torch.nn.Parameter]):
+        for s, p in zip(self.shadow_params, list(parameters)):
+            p.data.copy_(s)
+        _lib.bump_weight_epoch()
+
+    def store(self, parameters):
+        self.temp_stored_params = [p.detach().clone() for p in parameters]
+
+    def restore(self, parameters):
+        if self.temp_stored_params is None:
+            raise RuntimeError("This ExponentialMovingAverage has no `store()`ed weights to `restore()`")
+        for c, p in zip(self.temp_stored_params, parameters):
+            p.data.copy_(c)
+        self.temp_stored_params = None
+        _lib.bump_weight_epoch()
+
+    def state_dict(self):
+        return dict(decay=self.decay, min_decay=self.min_decay, optimization_step=self.optimization_step,
+                    update_after_step=self.update_after_step, use_ema_warmup=self.use_ema_warmup, inv_gamma=self.inv_gamma,
+                    power=self.power, shadow_params=[s.clone() for s in self.shadow_params])
+
+    def load_state_dict(self, sd):
+        for k in ("decay", "min_decay", "optimization_step", "update_after_step", "use_ema_warmup", "inv_gamma", "power"):
+            if k in sd:
+                setattr(self, k, sd[k])
+        if sd.get("shadow_params") is not None:
+            for s, v in zip(self.shadow_params, sd["shadow_params"]):
+                s.copy_(v)
+
+    def save_pretrained(self, path: str):
+        if self.model_cls is None:
+            raise ValueError("`save_pretrained` can only be used if `model_cls` was defined at __init__.")
+        model = self.model_cls(**dict(self.model_config)) if not hasattr(self.model_cls, "from_config") else self.model_cls.from_config(self.model_config)
+        for s, p in zip(self.shadow_params, model.parameters()):
+            p.data.copy_(s.cpu())
+        model.save_pretrained(path)
+        sd = {k: v for k, v in self.state_dict().items() if k != "shadow_params"}
+        import json
+        with open(os.path.join(path, "ema_state.json"), "w") as f:
+            json.dump(sd, f)
+
+
+def clip_grad_norm_(parameters, max_norm: float) -> torch.Tensor:
+    """accelerator.clip_grad_norm_ (train.py:701) for gradients that live in arbitrary tensors: device-side norm and
+    in-place scale, no host sync.  (FusedAdamW(max_grad_norm=...) folds this into the update instead.)"""
+    grads = [p.grad for p in parameters if p.grad is not None]
+    ss = torch.zeros(1, dtype=torch.float32, device=grads[0].device)
+    for g in grads:
+        _lib.call("dfh_sumsq", _lib.ptr(g), g.numel(), _lib.ptr(ss), _lib.stream_ptr())
+    norm = ss.sqrt()[0]
+    coef = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+    torch._foreach_mul_(grads, coef)
+    return norm
+
+
+def train_step(unet, fashion_encoder, scheduler, optimizer: FusedAdamW, *, lr_scheduler=None, ema_unet: Optional[EMAModel] = None,
+               ema_encoder: Optional[EMAModel] = None, **batch) -> torch.Tensor:
+    """One optimisation step of train.py:691-711 on the HIP path: loss (DiFashion.forward) -> native backward ->
+    data-parallel gradient all-reduce -> clip + AdamW -> EMA.  ``batch`` are the keyword arguments of
+    ``pipeline.train_forward``.  Returns the detached loss (device scalar; nothing here synchronises the host)."""
+    from . import dist as _dist
+    from .pipeline import train_forward
+    loss = train_forward(unet, fashion_encoder, scheduler, **batch)
+    loss.backward()
+    _dist.all_reduce_gradients(optimizer.flat_grad)
+    optimizer.step()
+    if lr_scheduler is not None:
+        lr_scheduler.step()
+    optimizer.zero_grad()
+    if ema_unet is not None:
+        ema_unet.step(unet.parameters())
+    if ema_encoder is not None:
+        ema_encoder.step(fashion_encoder.parameters())
+    return loss.detach()

@@ -270,7 +270,7 @@ class UNet2DConditionModel(nn.Module):
         self._packed_sig = None             # the transposed packs have to be (re)built
 
     def _signature(self, params):
-        return tuple((p.data_ptr(), p._version) for p in params)
+        return tuple((p.data_ptr(), p._version) for p in params) + (_lib.weight_epoch(),)
 
     def pack(self, force: bool = False):
         """fp32 master parameters -> bf16 kernel layouts (call happens automatically when they change)."""

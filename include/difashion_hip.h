@@ -212,7 +212,8 @@ int dfh_act_bwd(const void* ref_bf16, const float* ref_f32, const void* dy_bf16,
 int dfh_nhwc_to_nchw_f32(const void* src, float* dst, int batch, int HW, int Cp, int C, float scale, int accumulate, void* stream);
 int dfh_transpose_bf16(const void* in, void* out, int batch, int R, int C, int ld_in, int ld_out, size_t in_bstride,
                        size_t out_bstride, void* stream);
-int dfh_mse_bwd(const float* pred, const float* target, const float* w, float* dpred, int rows, int L, float loss_scale, void* stream);
+int dfh_mse_bwd(const float* pred, const float* target, const float* w, float* dpred, int rows, int L, float loss_scale,
+                const float* scale_dev /* optional device scalar multiplied in (upstream d loss) */, void* stream);
 int dfh_assemble_bwd(const float* dx, const uint8_t* mutual_real, float* dmutual, int rows, int CL, float eta, void* stream);
 /* optimizer: torch.optim.AdamW step with the clip_grad_norm_ coefficient derived on device from *sumsq (may be NULL),
  * squared-norm accumulation, diffusers EMAModel update */

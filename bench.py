@@ -103,6 +103,68 @@ def cpu_baseline(threads):
                        "1 warm-up + 1 timed forward")
 
 
+def train_inputs(dev, cross_dim, rank, outfits):
+    """Synthetic iFashion-shaped training batch (BASELINE configs[2]): ``outfits`` x 4 items, every tensor resident in HBM."""
+    n = outfits * 4
+    def rn(seed, *shape):
+        return torch.randn(*shape, generator=torch.Generator().manual_seed(seed + 1000 * rank)).to(dev)
+    g = torch.Generator().manual_seed(77 + rank)
+    return dict(latents=rn(1, n, 4, 64, 64) * 0.18215, noise=rn(2, n, 4, 64, 64),
+                timesteps_outfit=torch.randint(0, 1000, (outfits,), generator=g).to(dev), null_latent=rn(3, 4, 64, 64) * 0.18215,
+                hist_latents=rn(4, n, 4, 64, 64) * 0.18215, ehs=rn(5, n, 77, cross_dim), null_prompt=rn(6, 1, 77, cross_dim),
+                random_p=torch.rand(n, generator=g), random_p_cate=torch.rand(n, generator=g), snr_gamma=5.0,
+                dropout_mask=((torch.rand(n, 256, generator=g) >= 0.1).float() / 0.9).to(dev))
+
+
+def run_train(args, da, _lib, ddist, rank, world, dev):
+    """BASELINE configs[2]/[3]: one optimisation step = loss forward + native backward + RCCL gradient all-reduce + clip/AdamW
+    + EMA over a per-GPU batch of 8 outfits x 4 items (weak scaling: global batch = 32 x N items)."""
+    unet, enc = build_models(dev, args.config)
+    unet.train(); enc.train()
+    opt = da.FusedAdamW(list(unet.parameters()) + list(enc.parameters()), lr=1e-5, weight_decay=1e-2, max_grad_norm=1.0)
+    ema = da.EMAModel(unet.parameters())
+    sched = da.DDIMScheduler()
+    kw = train_inputs(dev, unet.config.cross_attention_dim, rank, args.outfits)
+    K, W = args.steps, args.warmup
+    step = lambda: da.train_step(unet, enc, sched, opt, ema_unet=ema, **kw)
+    for _ in range(W):
+        loss = step()
+    torch.cuda.synchronize(); ddist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        loss = step()
+    torch.cuda.synchronize(); ddist.barrier(); torch.cuda.synchronize()
+    elapsed = ddist.max_over_ranks(time.perf_counter() - t0)
+    assert torch.isfinite(loss), "non-finite loss"
+    classes = None
+    if not args.no_profile and rank == 0 and world == 1:
+        _lib.prof_begin()
+        for _ in range(K):
+            step()
+        classes = _lib.prof_end()
+    if world > 1:
+        ddist.barrier()
+    if rank != 0:
+        return
+    items = args.outfits * 4
+    out = {"metric": "training items/sec, fwd+bwd+AdamW, 8 outfits x 4 items per GPU @ 64x64x4 latent", "value": round(world * items * K / elapsed, 2),
+           "unit": "items/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed * 1e3 / K, 2),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"BASELINE configs[2]: training step, {args.outfits} outfits x 4 items per GPU, {args.config} shape in_channels=8, "
+                                  "min-SNR MSE loss, mutual + history conditioning, clip 1.0 + AdamW + EMA",
+                      "unet_batch": items, "parallelism": f"data-parallel x{world}, one flat-buffer RCCL all-reduce per step"},
+           "loss": round(float(loss), 5), "hbm_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
+    if classes is not None:
+        tot_f = sum(v["flops"] for v in classes.values())
+        out["kernel_classes"] = {c: dict(launches_per_step=v["launches"] // K, ms_per_step=round(v["ms"] / K, 3),
+                                         tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] > 0 else None,
+                                         algorithmic_GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None)
+                                 for c, v in classes.items() if v["launches"]}
+        out["algorithmic_tflop_per_step"] = round(tot_f / K / 1e12, 2)
+        out["mfma_frac_whole_step"] = round(tot_f / K / (elapsed / K) / 1e12 / MFMA_BF16_PEAK, 4)
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +173,9 @@ def main():
     ap.add_argument("--config", default="sd15", choices=["sd15", "sd2base"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--mode", default="sample", choices=["sample", "train"],
+                    help="sample: the headline metric (default); train: BASELINE configs[2]/[3] training step")
+    ap.add_argument("--outfits", type=int, default=8, help="--mode train: outfits per GPU per step")
     args = ap.parse_args()
 
     import difashion_amd as da
@@ -124,6 +189,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if args.mode == "train":
+        return run_train(args, da, _lib, ddist, rank, world, dev)
     unet, enc = build_models(dev, args.config)
     cross = unet.config.cross_attention_dim
     K, W = args.steps, args.warmup

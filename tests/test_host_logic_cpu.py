@@ -128,3 +128,48 @@ def test_world_size_2_gloo_sharding_and_reductions():
     expect = [float(o * 10 + j) for o in range(5) for j in range(2)]
     for r, elapsed, total, vals in res:
         assert elapsed == 1.5 and total == 5.0 and vals == expect
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, w, _ = ddist.init("gloo")
+    # data-parallel training step: every rank computes the gradient of ITS shard of the outfits on an identical replica,
+    # the flat gradient buffer is averaged with one all-reduce, then every rank applies the same update
+    torch.manual_seed(0)
+    weight = torch.randn(6, 3)                                   # replica (same seed on every rank)
+    data = torch.arange(8 * 3, dtype=torch.float32).view(8, 3) / 10.0
+    mine = ddist.shard_range(8, r, w)
+    x = data[mine.start:mine.stop]
+    flat_grad = (2.0 * (x @ weight.T)).T @ x / len(mine)          # d/dW of mean_rows ||W x||^2 over the local shard
+    flat_grad = flat_grad.reshape(-1).contiguous()
+    ddist.all_reduce_gradients(flat_grad)
+    weight = weight - 0.1 * flat_grad.view(6, 3)
+    q.put((r, flat_grad.tolist(), weight.reshape(-1).tolist()))
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_gradient_all_reduce_matches_single_process():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    weight = torch.randn(6, 3)
+    data = torch.arange(8 * 3, dtype=torch.float32).view(8, 3) / 10.0
+    full = ((2.0 * (data @ weight.T)).T @ data / 8).reshape(-1)   # equal shards: mean of shard means == global mean
+    for r, g, wnew in res:
+        torch.testing.assert_close(torch.tensor(g), full, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(torch.tensor(wnew), (weight - 0.1 * full.view(6, 3)).reshape(-1), rtol=1e-5, atol=1e-6)
+    assert res[0][2] == res[1][2]                                 # replicas stay bit-identical
+
+
+def test_all_reduce_gradients_is_identity_without_a_process_group():
+    g = torch.arange(5, dtype=torch.float32)
+    assert ddist.all_reduce_gradients(g) is g and g.tolist() == [0, 1, 2, 3, 4]

@@ -92,6 +92,7 @@ SIGNATURES = {
     "dfh_gemm_partial_floats": (_sz, [C.POINTER(GemmDesc)]),
     "dfh_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "dfh_gemm_wgrad": (_i, [C.POINTER(GemmDesc), _vp, _i, _vp, _i, _i, _vp]),
+    "dfh_gemm_wgrad_partial_floats": (_sz, [C.POINTER(GemmDesc), _i]),
     "dfh_colsum": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "dfh_groupnorm": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     "dfh_groupnorm_stats": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),

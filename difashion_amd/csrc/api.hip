@@ -112,21 +112,35 @@ int dfh_gemm(const dfh_gemm_desc* d, void* stream) {
   return dfh::gemm_launch(g, (hipStream_t)stream, d->force_tile, d->force_split, d->force_glds);
 }
 
-int dfh_gemm_wgrad(const dfh_gemm_desc* d, const void* dY, int ldy, float* dW, int ldw, int msplit, void* stream) {
+static int fill_wgrad(const dfh_gemm_desc* d, const void* dY, int ldy, float* dW, int ldw, int msplit, WgradArgs& w) {
   GemmArgs g;
-  DFH_REQUIRE(d && dY && dW, "null argument");
+  DFH_REQUIRE(d, "null argument");
   // only the A-operand description (K segments), M, N and the zero page of the descriptor are used
   dfh_gemm_desc tmp = *d;
   int dummy = 0;
   if (!tmp.W) tmp.W = &dummy;
   if (!tmp.out) tmp.out = &dummy;
   if (int rc = fill_gemm(&tmp, &g)) return rc;
-  WgradArgs w; std::memset(&w, 0, sizeof(w));
+  std::memset(&w, 0, sizeof(w));
   w.conv_src = g.conv_src; w.conv_c = g.conv_c; w.ntaps = g.ntaps;
   w.Hin = g.Hin; w.Win = g.Win; w.Hout = g.Hout; w.Wout = g.Wout; w.stride = g.stride; w.ups = g.ups;
   w.p_src[0] = g.p_src[0]; w.p_src[1] = g.p_src[1]; w.p_c[0] = g.p_c[0]; w.p_c[1] = g.p_c[1]; w.nplain = g.nplain;
   w.dY = (const bf16_t*)dY; w.ldy = ldy; w.zero = g.zero; w.M = g.M; w.N = g.N; w.dW = dW; w.ldw = ldw; w.msplit = msplit;
+  w.partial = d->partial; w.partial_cap = d->partial_floats;
+  return 0;
+}
+
+int dfh_gemm_wgrad(const dfh_gemm_desc* d, const void* dY, int ldy, float* dW, int ldw, int msplit, void* stream) {
+  DFH_REQUIRE(d && dY && dW, "null argument");
+  WgradArgs w;
+  if (int rc = fill_wgrad(d, dY, ldy, dW, ldw, msplit, w)) return rc;
   return dfh::wgrad_launch(w, (hipStream_t)stream);
+}
+
+size_t dfh_gemm_wgrad_partial_floats(const dfh_gemm_desc* d, int msplit) {
+  WgradArgs w;
+  if (!d || fill_wgrad(d, nullptr, 8, nullptr, 8, msplit, w)) return 0;
+  return dfh::wgrad_partial_floats(w);
 }
 
 int dfh_colsum(const void* Y, int ldy, int N, int groups, int rows_per_group, float* out, int ld_out, void* stream) {

@@ -92,13 +92,15 @@ struct dfh_unet::TrainRun {
   }
   // dW (packed fp32 gradient of the matrix at arena16 + w_off) += dY^T . A, A described by the forward descriptor
   void wgrad(const GemmArgs& f, const bf16_t* dY, int ldy, size_t w_off) {
-    if (rc || dry) return;
+    if (rc) return;
     WgradArgs w; std::memset(&w, 0, sizeof(w));
     w.conv_src = f.conv_src; w.conv_c = f.conv_c; w.ntaps = f.ntaps;
     w.Hin = f.Hin; w.Win = f.Win; w.Hout = f.Hout; w.Wout = f.Wout; w.stride = f.stride; w.ups = f.ups;
     w.p_src[0] = f.p_src[0]; w.p_src[1] = f.p_src[1]; w.p_c[0] = f.p_c[0]; w.p_c[1] = f.p_c[1]; w.nplain = f.nplain;
     w.dY = dY; w.ldy = ldy; w.zero = zero; w.M = f.M; w.N = f.N;
     w.dW = u->grad16 + w_off; w.ldw = f.ldw; w.msplit = 0;
+    w.partial = partial; w.partial_cap = partial_cap / sizeof(float);     // shares the split-K slab region of the GEMMs
+    if (dry) { partial_need = std::max(partial_need, dfh::wgrad_partial_floats(w) * sizeof(float)); return; }
     rc = dfh::wgrad_launch(w, s);
   }
   void colsum(const bf16_t* Y, int ldy, int N, int groups, int rows_per_group, float* out, int ld_out) {

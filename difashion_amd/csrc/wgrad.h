@@ -11,11 +11,15 @@ struct WgradArgs {
   const bf16_t* zero;
   int M, N;
   float* dW; int ldw;            // fp32 [N][ldw] in the PACKED weight layout, accumulated (+=)
+  float* partial; size_t partial_cap;   // fp32 slabs [msplit][N][ktot] when the pixels are split (wgrad_partial_floats)
+  int ktot;                      // filled by the launcher: total K of the call
   int msplit;                    // 0 = heuristic
+  int xblocks;                   // filled by the launcher: n-tiles x kcol-chunks
 };
 
 namespace dfh {
 int wgrad_launch(WgradArgs a, hipStream_t s);
+size_t wgrad_partial_floats(WgradArgs a);   // slab floats the heuristic (or a.msplit) needs; 0 = none
 // out[g][n] += sum_{m in group g} Y[m][n]   (bias gradient: groups = 1; time-embedding gradient: groups = batch)
 int colsum_launch(const bf16_t* Y, int ldy, int N, int groups, int rows_per_group, float* out, int ld_out, hipStream_t s);
 }  // namespace dfh

@@ -16,138 +16,238 @@
 
 namespace {
 
-constexpr int WBM = 64;     // m rows per pipeline stage (contraction chunk)
-constexpr int WBN = 128;    // n (output channel) tile
-constexpr int WBK = 64;     // kcol tile = one 64-wide slice of one K segment
-constexpr int Y_BYTES = WBM * WBN * 2, A_BYTES = WBM * WBK * 2, WSTAGE = Y_BYTES + A_BYTES;
+// Block tile: 160 output channels (n) x 160 packed weight columns (kcol); 4 waves as 2 x 2, each 80 x 80 (5 x 5 MFMA
+// fragments, 100 accumulator VGPRs).  160 divides every channel count of the model (320/640/960/1280/1920/2560).
+// The contraction runs over pixels m in stages of 32 rows (one 16x16x32 MFMA k-step), 3 stages in flight.
+constexpr int TN = 160, TK = 160, BM = 32, NST = 3;
+// Both operand tiles are [32 m][160 cols] bf16 with a 352-byte row stride (320 B of data + 32 B pad): one
+// ds_read_b64_tr_b16 lane group (32 lanes) touches 8 consecutive m rows x 32 B, and 352 = 96 (mod 256) spreads those
+// over all 64 banks (0,96,192,32,128,224,64,160) -- conflict-free, where 256-/128-byte rows are 8-/4-way conflicted.
+constexpr int ROWB = 352, TILE_BYTES = BM * ROWB;          // 11264 B = 11 LDS-DMA instructions of 1 KB
+constexpr int REGION = 12 * 1024;                           // per operand: 12 slots (the 12th only holds the tail padding)
+constexpr int WSTAGE = 2 * REGION;                          // every wave issues 3 dY + 3 A slots per stage
+constexpr int ISSUE = 6;
 
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+// ds_read_b64_tr_b16 through inline asm: the builtin makes hipcc wait vmcnt(0) before the first LDS read of every
+// stage (it cannot see that the LDS-DMA in flight targets another stage), which serialises the whole pipeline.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+#define TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+// wait until at most N LDS reads are outstanding; the fragments it guards are tied in as operands so that no MFMA
+// consuming them can be scheduled above the wait
+#define LGKM_WAIT5(N, f) asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]), \
+    "+v"(f[2][0]), "+v"(f[2][1]), "+v"(f[3][0]), "+v"(f[3][1]), "+v"(f[4][0]), "+v"(f[4][1]) : "n"(N))
+#define LGKM_WAIT1(N, f) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[0]), "+v"(f[1]) : "n"(N))
 
-DFH_DEVICE bf16x8_t tr_frag(const unsigned char* tile, int row_bytes, int m0, int col0, int L) {
-  // 8 consecutive m (rows m0..m0+7) of column col0 + L, as one MFMA operand fragment
-  const unsigned char* p = tile + (m0 + (L >> 2)) * row_bytes + (col0 + (L & 3) * 4) * 2;
-  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
-  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 4 * row_bytes));
-  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+DFH_DEVICE bf16x8_t frag_of(const u32x2_t lo, const u32x2_t hi) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  const u32x4_t v = {lo[0], lo[1], hi[0], hi[1]};
   return __builtin_bit_cast(bf16x8_t, v);
 }
+template <int N> DFH_DEVICE void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// x / d for 0 <= x < 2^24 through a float reciprocal (exact after one fix-up step)
+DFH_DEVICE int fdiv(int x, int d, float inv) {
+  int q = (int)((float)x * inv);
+  const int r = x - q * d;
+  q += (r >= d) - (r < 0);
+  return q;
+}
 
-__global__ __launch_bounds__(256) void gemm_wgrad_kernel(const WgradArgs a) {
+// POW2: Hout and Wout are powers of two (every level of the U-Net): pixel decode by shifts instead of divisions
+template <bool POW2>
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = lane & 15, fg = lane >> 4;
+  const int wave_n = wave & 1, wave_k = wave >> 1;
 
-  const int ntn = (a.N + WBN - 1) / WBN;
-  const int n0 = (blockIdx.x % ntn) * WBN;
-  const int chunk = blockIdx.x / ntn;
-  // locate the chunk: (segment, channel offset, packed column)
-  int seg = 0, base = 0, kc = chunk, seglen = 0;
-  const int nseg = a.ntaps + a.nplain;
-  for (;;) {
-    seglen = seg < a.ntaps ? a.conv_c : a.p_c[seg - a.ntaps];
-    const int n = (seglen + WBK - 1) / WBK;
-    if (kc < n || seg == nseg - 1) break;
-    kc -= n; base += seglen; ++seg;
+  // ---- block -> (x = n-tile + ntn * chunk, z = m-slice), XCD-aware.  Workgroups go round-robin over the 8 XCDs
+  // (linear id % 8), each with its own L2.  Blocks of one m-slice read the SAME rows of dY and A, so a whole slice is
+  // placed on one XCD (its re-reads become L2 hits instead of 8 fabric fetches); with a single slice the x range is cut
+  // into 8 contiguous chunk ranges instead (an A chunk is then fetched by one XCD only).
+  const int ntn = (a.N + TN - 1) / TN;
+  const int X = a.xblocks;
+  int bx, bz;
+  {
+    const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    if ((a.msplit & 7) == 0) { const int zi = j / X; bx = j - zi * X; bz = zi * 8 + xcd; }
+    else if (a.msplit == 1 && (X & 7) == 0) { bx = xcd * (X >> 3) + j; bz = 0; }
+    else { bz = id / X; bx = id - bz * X; }
   }
-  const int c0 = kc * WBK, wcol = base + c0;
+  const int n0 = (bx % ntn) * TN;
+  const int chunk = bx / ntn;
+  // locate the chunk: (segment, channel offset, packed column).  Conv chunks are enumerated channel-major
+  // (chunk = channel_chunk * 9 + tap): a contiguous chunk range -- what one XCD gets when there is a single m-slice --
+  // then re-reads ONE 160-channel slice of the activation under nine shifts (L2-resident) instead of all channels.
+  int seg, base, kc = chunk, seglen;
+  const int cchunks = (a.conv_c + TK - 1) / TK;
+  if (kc < a.ntaps * cchunks) {
+    seg = kc % a.ntaps; kc /= a.ntaps; seglen = a.conv_c; base = seg * a.conv_c;
+  } else {
+    kc -= a.ntaps * cchunks; seg = a.ntaps; base = a.ntaps * a.conv_c; seglen = a.p_c[0];
+    const int n0c = (seglen + TK - 1) / TK;
+    if (a.nplain > 1 && kc >= n0c) { kc -= n0c; base += seglen; seglen = a.p_c[1]; seg = a.ntaps + 1; }
+  }
+  const int c0 = kc * TK, wcol = base + c0;
   const bool conv = seg < a.ntaps;
   const int ky = conv ? seg / 3 : 0, kx = conv ? seg - ky * 3 : 0;
+  const bf16_t* psrc = conv ? a.conv_src : (seg == a.ntaps ? a.p_src[0] : a.p_src[1]);
+  const int pc = seglen;
 
-  const int m_per = (((a.M + a.msplit - 1) / a.msplit) + WBM - 1) / WBM * WBM;
-  const int m_begin = blockIdx.z * m_per, m_end = min(a.M, m_begin + m_per);
-  const int nsteps = m_end > m_begin ? (m_end - m_begin + WBM - 1) / WBM : 0;
+  const int m_per = (((a.M + a.msplit - 1) / a.msplit) + BM - 1) / BM * BM;
+  const int m_begin = bz * m_per, m_end = min(a.M, m_begin + m_per);
+  const int nsteps = m_end > m_begin ? (m_end - m_begin + BM - 1) / BM : 0;
 
   const int HWo = a.Hout * a.Wout;
+  const float inv_hw = 1.0f / (float)HWo, inv_w = 1.0f / (float)a.Wout;
+  const int lw = 31 - __builtin_clz(a.Wout), lhw = 31 - __builtin_clz(HWo);
   const int Hv = a.ups ? a.Hin * 2 : a.Hin, Wv = a.ups ? a.Win * 2 : a.Win;
-  // staging roles: dY pieces = 4 rows x 256 B (lane -> row lane/16, slot lane%16), 16 pieces per stage;
-  //                A  pieces = 8 rows x 128 B (lane -> row lane/8,  slot lane%8),   8 pieces per stage
+
+  // per-lane geometry of this wave's LDS-DMA slots: i = 0..2 -> dY slot i*4 + wave, i = 3..5 -> A slot (i-3)*4 + wave;
+  // byte p of an operand region is (row p / 352, column (p % 352) / 2); columns >= 160 and rows >= 32 are padding
+  int s_row[ISSUE], s_off[ISSUE]; bool s_ok[ISSUE];
+#pragma unroll
+  for (int i = 0; i < ISSUE; ++i) {
+    const int p = ((i % 3) * 4 + wave) * 1024 + lane * 16;
+    const int row = p / ROWB, col = (p - row * ROWB) >> 1;
+    s_row[i] = row;
+    if (i < 3) { s_ok[i] = (row < BM) & (col < TN) & (n0 + col < a.N); s_off[i] = n0 + col; }
+    else { s_ok[i] = (row < BM) & (col < TK) & (c0 + col < seglen); s_off[i] = c0 + col; }
+  }
   auto glds = [&](const bf16_t* src, unsigned char* dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
+  // straight-line, select-only address generation (a branch per slot costs more than the masked math)
   auto issue = [&](int step, int buf) {
-    unsigned char* Ys = smem + buf * WSTAGE;
-    unsigned char* As = Ys + Y_BYTES;
-    const int mb = m_begin + step * WBM;
+    unsigned char* st = smem + buf * WSTAGE + wave * 1024;
+    const int mb = m_begin + step * BM;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int p = i * 4 + wave;
-      const int m = mb + p * 4 + (lane >> 4);
-      const int n = n0 + (lane & 15) * 8;
-      const bool ok = (m < m_end) & (n < a.N);
-      glds(ok ? a.dY + ((long)m * a.ldy + n) : a.zero, Ys + p * 1024);
+    for (int i = 0; i < 3; ++i) {
+      const int m = mb + s_row[i];
+      const bool ok = s_ok[i] & (m < m_end);
+      const long off = (long)m * a.ldy + s_off[i];
+      glds(ok ? a.dY + off : a.zero, st + i * 4096);
     }
+    if (conv) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int p = i * 4 + wave;
-      const int m = mb + p * 8 + (lane >> 3);
-      const int ch = c0 + (lane & 7) * 8;
-      bool ok = (m < m_end) & (ch < seglen);
-      const bf16_t* src = a.zero;
-      if (conv) {
+      for (int i = 3; i < ISSUE; ++i) {
+        const int m = mb + s_row[i];
         const int mm = min(m, a.M - 1);
-        const int b = mm / HWo, rem = mm - b * HWo;
-        const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+        int b, oy, ox;
+        if (POW2) { b = mm >> lhw; oy = (mm >> lw) & (a.Hout - 1); ox = mm & (a.Wout - 1); }
+        else { b = fdiv(mm, HWo, inv_hw); const int rem = mm - b * HWo; oy = fdiv(rem, a.Wout, inv_w); ox = rem - oy * a.Wout; }
         const int yy = oy * a.stride - 1 + ky, xx = ox * a.stride - 1 + kx;
-        ok = ok & ((unsigned)yy < (unsigned)Hv) & ((unsigned)xx < (unsigned)Wv);
+        const bool ok = s_ok[i] & (m < m_end) & ((unsigned)yy < (unsigned)Hv) & ((unsigned)xx < (unsigned)Wv);
         const int sy = a.ups ? (yy >> 1) : yy, sx = a.ups ? (xx >> 1) : xx;
-        if (ok) src = a.conv_src + ((long)((b * a.Hin + sy) * a.Win + sx) * a.conv_c + ch);
-      } else {
-        const int ps = seg - a.ntaps;
-        if (ok) src = a.p_src[ps] + ((long)m * a.p_c[ps] + ch);
+        const long off = (long)((b * a.Hin + sy) * a.Win + sx) * pc + s_off[i];
+        glds(ok ? psrc + off : a.zero, st + REGION + (i - 3) * 4096);
       }
-      glds(src, As + p * 1024);
+    } else {
+#pragma unroll
+      for (int i = 3; i < ISSUE; ++i) {
+        const int m = mb + s_row[i];
+        const bool ok = s_ok[i] & (m < m_end);
+        const long off = (long)m * pc + s_off[i];
+        glds(ok ? psrc + off : a.zero, st + REGION + (i - 3) * 4096);
+      }
     }
   };
 
-  f32x4_t acc[4][2];
+  f32x4_t acc[5][5];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment address of this lane inside a stage: row fg*4 + L/4, 4 columns starting at (L%4)*4 of the wave's 80-column
+  // slice.  MFMA k index (fg, j): j < 4 -> row fg*4 + j, j >= 4 -> row 16 + fg*4 + (j - 4) -- the same map for both
+  // operands, chosen so that a 32-lane LDS group reads 8 CONSECUTIVE rows.
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned ylane = lds0 + (fg * 4 + (L >> 2)) * ROWB + (wave_n * 80 + (L & 3) * 4) * 2;
+  const unsigned alane = lds0 + REGION + (fg * 4 + (L >> 2)) * ROWB + (wave_k * 80 + (L & 3) * 4) * 2;
 
   if (nsteps > 0) {
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    int issued = 0;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+      if (s < nsteps) { issue(s, s); ++issued; }
+    int buf = 0;
     for (int t = 0; t < nsteps; ++t) {
-      const int cur = t & 1;
-      if (t + 1 < nsteps) issue(t + 1, cur ^ 1);
-      const unsigned char* Ys = smem + cur * WSTAGE;
-      const unsigned char* As = Ys + Y_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int m0 = ks * 32 + fg * 8;
-        bf16x8_t yf[2], af[4];
-#pragma unroll
-        for (int nf = 0; nf < 2; ++nf) yf[nf] = tr_frag(Ys, WBN * 2, m0, wave * 32 + nf * 16, L);
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf) af[kf] = tr_frag(As, WBK * 2, m0, kf * 16, L);
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-          for (int nf = 0; nf < 2; ++nf)
-            // D^T[row = kcol (fg*4+r)][col = n (L)]
-            acc[kf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kf], yf[nf], acc[kf][nf], 0, 0, 0);
+      const int ahead = issued - 1 - t;               // stages younger than t still in flight (block-uniform)
+      if (ahead == 0) wg_wait_vmcnt<0>();
+      else if (ahead == 1) wg_wait_vmcnt<ISSUE>();
+      else wg_wait_vmcnt<2 * ISSUE>();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();                   // stage t visible to all waves; everyone is done with stage t-1
+      asm volatile("" ::: "memory");
+      if (issued < nsteps) {
+        int nb = buf - 1; if (nb < 0) nb += NST;
+        issue(issued, nb);
+        ++issued;
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      const unsigned ya = ylane + buf * WSTAGE, aa = alane + buf * WSTAGE;
+      u32x2_t y[5][2], x[5][2];
+#define TR_PAIR(dst, addr, nf) TR_READ(dst[nf][0], addr, nf * 32); TR_READ(dst[nf][1], addr, nf * 32 + 16 * ROWB)
+      TR_PAIR(y, ya, 0); TR_PAIR(y, ya, 1); TR_PAIR(y, ya, 2); TR_PAIR(y, ya, 3); TR_PAIR(y, ya, 4);
+      TR_PAIR(x, aa, 0); TR_PAIR(x, aa, 1); TR_PAIR(x, aa, 2); TR_PAIR(x, aa, 3); TR_PAIR(x, aa, 4);
+#undef TR_PAIR
+      LGKM_WAIT5(10, y);                              // the ten dY reads are back (LDS returns in order)
+      bf16x8_t yf[5];
+#pragma unroll
+      for (int nf = 0; nf < 5; ++nf) yf[nf] = frag_of(y[nf][0], y[nf][1]);
+#define WG_ROW(kf, N)                                                                                        \
+      LGKM_WAIT1(N, x[kf]);                                                                                  \
+      { const bf16x8_t af = frag_of(x[kf][0], x[kf][1]);                                                      \
+        _Pragma("unroll") for (int nf = 0; nf < 5; ++nf)                                                      \
+          acc[kf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, yf[nf], acc[kf][nf], 0, 0, 0); }
+      // D^T[row = kcol (fg*4+r)][col = n (L)]
+      WG_ROW(0, 8) WG_ROW(1, 6) WG_ROW(2, 4) WG_ROW(3, 2) WG_ROW(4, 0)
+#undef WG_ROW
+      if (++buf == NST) buf = 0;
     }
   }
 
+  // a lane ends with 4 consecutive packed columns of one output channel: one 16-byte access.  A single m-slice adds
+  // straight into dW (each element belongs to exactly one block); several slices write fp32 slabs that
+  // wgrad_reduce_kernel sums in a fixed order (deterministic; scalar fp32 atomics cap out near 70 G/s on this part)
 #pragma unroll
-  for (int nf = 0; nf < 2; ++nf) {
-    const int n = n0 + wave * 32 + nf * 16 + L;
+  for (int nf = 0; nf < 5; ++nf) {
+    const int n = n0 + wave_n * 80 + nf * 16 + L;
     if (n >= a.N) continue;
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf) {
-      const int kcol = kf * 16 + fg * 4;
-      float* dst = a.dW + (long)n * a.ldw + wcol + kcol;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (c0 + kcol + r < seglen) atomicAdd(dst + r, acc[kf][nf][r]);
+    for (int kf = 0; kf < 5; ++kf) {
+      const int kcol = wave_k * 80 + kf * 16 + fg * 4;
+      if (c0 + kcol >= seglen) continue;               // segment lengths are multiples of 8: all four or none
+      const float4 v = float4{acc[kf][nf][0], acc[kf][nf][1], acc[kf][nf][2], acc[kf][nf][3]};
+      if (a.msplit > 1) {
+        *(float4*)(a.partial + ((long)bz * a.N + n) * a.ktot + wcol + kcol) = v;
+      } else {
+        float4* dst = (float4*)(a.dW + (long)n * a.ldw + wcol + kcol);
+        float4 o = *dst;
+        o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+        *dst = o;
+      }
     }
   }
+}
+
+// dW[n][k] += sum_z slab[z][n][k]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int N, int ktot,
+                                                           int ldw, int msplit) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long total = (long)N * ktot;
+  if (i >= total) return;
+  const int n = (int)(i / ktot), k = (int)(i - (long)n * ktot);
+  float4 s = *(const float4*)(partial + i);
+  for (int z = 1; z < msplit; ++z) {
+    const float4 p = *(const float4*)(partial + (long)z * total + i);
+    s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+  }
+  float4* dst = (float4*)(dW + (long)n * ldw + k);
+  float4 o = *dst;
+  o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+  *dst = o;
 }
 
 // out[g][n] (+)= sum over rows m of group g (rows_per_group consecutive rows) of Y[m][n]; fp32 atomics over row blocks
@@ -182,24 +282,64 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 
 namespace dfh {
 
+static int wgrad_plan(WgradArgs& a) {
+  int chunks = a.ntaps * ((a.conv_c + TK - 1) / TK);
+  for (int i = 0; i < a.nplain; ++i) chunks += (a.p_c[i] + TK - 1) / TK;
+  const int ntn = (a.N + TN - 1) / TN;
+  a.ktot = a.ntaps * a.conv_c;
+  for (int i = 0; i < a.nplain; ++i) a.ktot += a.p_c[i];
+  if (a.msplit <= 0) {
+    // fill 256 CUs x 2 blocks with some slack, but keep >= 512 contraction rows per block so that the fp32-atomic
+    // epilogue (100 KB per block) stays small next to the 20 KB per 32 rows the pipeline streams
+    // m-slices come in multiples of 8 (one per XCD, see the kernel) or not at all
+    const int blocks = ntn * chunks;
+    int ms = std::min((640 + blocks - 1) / blocks, a.M / 512);
+    ms = blocks >= 384 ? 1 : (ms + 7) / 8 * 8;
+    while (ms > 8 && a.M / ms < 512) ms -= 8;
+    a.msplit = (ms >= 8 && a.M / ms >= 128) ? ms : 1;
+  }
+  a.xblocks = ntn * chunks;
+  return 0;
+}
+
+size_t wgrad_partial_floats(WgradArgs a) {
+  wgrad_plan(a);
+  return a.msplit > 1 ? (size_t)a.msplit * a.N * a.ktot : 0;
+}
+
 int wgrad_launch(WgradArgs a, hipStream_t s) {
   DFH_REQUIRE(a.M > 0 && a.N > 0 && a.N % 4 == 0 && a.ldy % 8 == 0 && a.ldy >= ((a.N + 7) & ~7),
               "wgrad: N must be a positive multiple of 4, dY rows padded to a multiple of 8 columns");
+  DFH_REQUIRE(a.M < (1 << 24), "wgrad: M must be below 2^24");
   DFH_REQUIRE(a.ntaps == 0 || a.ntaps == 9, "ntaps must be 0 or 9");
   DFH_REQUIRE(a.ntaps + a.nplain >= 1 && a.zero && a.dY && a.dW, "wgrad: missing operand");
-  int chunks = a.ntaps * ((a.conv_c + WBK - 1) / WBK);
-  for (int i = 0; i < a.nplain; ++i) chunks += (a.p_c[i] + WBK - 1) / WBK;
-  const int ntn = (a.N + WBN - 1) / WBN;
-  if (a.msplit <= 0) {
-    const int blocks = ntn * chunks;
-    a.msplit = std::max(1, std::min((512 + blocks - 1) / blocks, (a.M + 4 * WBM - 1) / (4 * WBM)));
+  DFH_REQUIRE(a.ldw % 4 == 0 && ((uintptr_t)a.dW & 15) == 0, "wgrad: dW rows must be 16-byte aligned");
+  wgrad_plan(a);
+  if (a.msplit > 1 && (a.partial == nullptr || a.partial_cap < (size_t)a.msplit * a.N * a.ktot)) {
+    set_error("wgrad: slab buffer missing or smaller than wgrad_partial_floats()");
+    return -1;
   }
-  constexpr int lds = 2 * WSTAGE;
+  constexpr int lds = NST * WSTAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
   double kreal = (double)a.ntaps * a.conv_c;
   for (int i = 0; i < a.nplain; ++i) kreal += a.p_c[i];
   ProfScope ps(PC_WGRAD, 2.0 * a.M * a.N * kreal, 2.0 * a.M * (a.N + kreal) + 4.0 * a.N * kreal, s);
-  hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(ntn * chunks, 1, a.msplit), dim3(256), lds, s, a);
-  return check_launch("gemm_wgrad_kernel");
+  const bool pow2 = a.ntaps == 0 || (((a.Hout & (a.Hout - 1)) | (a.Wout & (a.Wout - 1))) == 0);
+  if (pow2) hipLaunchKernelGGL(gemm_wgrad_kernel<true>, dim3(a.xblocks * a.msplit), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(gemm_wgrad_kernel<false>, dim3(a.xblocks * a.msplit), dim3(256), lds, s, a);
+  if (int rc = check_launch("gemm_wgrad_kernel")) return rc;
+  if (a.msplit > 1) {
+    const long quads = (long)a.N * a.ktot / 4;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a.partial, a.dW, a.N, a.ktot, a.ldw,
+                       a.msplit);
+    return check_launch("wgrad_reduce_kernel");
+  }
+  return 0;
 }
 
 int colsum_launch(const bf16_t* Y, int ldy, int N, int groups, int rows_per_group, float* out, int ld_out, hipStream_t s) {

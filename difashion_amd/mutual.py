@@ -125,7 +125,7 @@ class MutualEncoder(nn.Module):
                 return
             d = _lib.GemmDesc()
             d.a0, d.a0_c, d.M, d.N, d.zero_page = a.data_ptr(), K, n, N, zero.data_ptr()
-            _lib.call("dfh_gemm_wgrad", C.byref(d), _lib.ptr(dY), N, _lib.ptr(p.grad), K, 0, s)
+            _lib.call("dfh_gemm_wgrad", C.byref(d), _lib.ptr(dY), N, _lib.ptr(p.grad), K, 1, s)     # few rows: one m-slice
 
         def colsum(dY, N, p):
             if p.requires_grad:

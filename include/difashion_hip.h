@@ -152,6 +152,8 @@ int dfh_gemm(const dfh_gemm_desc* d, void* stream);
  * forward operand described by d (conv_src / a0 / a1 segments, M, N, zero_page; W / out / epilogue fields unused).
  * dW: fp32 [N][ldw] in the PACKED weight layout, accumulated with atomics (zero it first).  msplit 0 = heuristic. */
 int dfh_gemm_wgrad(const dfh_gemm_desc* d, const void* dY, int ldy, float* dW, int ldw, int msplit, void* stream);
+/* fp32 slab floats (d->partial / d->partial_floats) that call needs when it splits the pixel range; 0 = none */
+size_t dfh_gemm_wgrad_partial_floats(const dfh_gemm_desc* d, int msplit);
 /* out[g][n] += sum over the rows of group g of Y[m][n] (bias gradient: groups = 1; time-embedding gradient:
  * groups = batch, rows_per_group = H*W). */
 int dfh_colsum(const void* Y, int ldy, int N, int groups, int rows_per_group, float* out, int ld_out, void* stream);

@@ -27,6 +27,9 @@ def wgrad(*, M, N, dY, conv_src=None, conv_c=0, batch=0, Hin=0, stride=1, upsamp
     z = gu.zero_page()
     d.zero_page = z.data_ptr()
     dW = torch.zeros((N, ldw), dtype=torch.float32, device=DEV)
+    need = _lib.raw().dfh_gemm_wgrad_partial_floats(C.byref(d), msplit)
+    part = torch.empty(max(need, 1), dtype=torch.float32, device=DEV)
+    d.partial, d.partial_floats = part.data_ptr(), need
     _lib.call("dfh_gemm_wgrad", C.byref(d), _lib.ptr(dY), dY.shape[-1], _lib.ptr(dW), ldw, msplit, gu.stream())
     torch.cuda.synchronize()
     return dW

@@ -112,7 +112,7 @@ def train_inputs(dev, cross_dim, rank, outfits):
     return dict(latents=rn(1, n, 4, 64, 64) * 0.18215, noise=rn(2, n, 4, 64, 64),
                 timesteps_outfit=torch.randint(0, 1000, (outfits,), generator=g).to(dev), null_latent=rn(3, 4, 64, 64) * 0.18215,
                 hist_latents=rn(4, n, 4, 64, 64) * 0.18215, ehs=rn(5, n, 77, cross_dim), null_prompt=rn(6, 1, 77, cross_dim),
-                random_p=torch.rand(n, generator=g), random_p_cate=torch.rand(n, generator=g), snr_gamma=5.0,
+                random_p=torch.rand(n, generator=g).to(dev), random_p_cate=torch.rand(n, generator=g).to(dev), snr_gamma=5.0,
                 dropout_mask=((torch.rand(n, 256, generator=g) >= 0.1).float() / 0.9).to(dev))
 
 

@@ -1,0 +1,26 @@
+// Table-driven weight packing / gradient un-packing: every PackOp of the model in ONE launch.
+// (pack() used to be ~1100 launches of tiny kernels per optimizer step, the gradient un-pack ~700 per backward: host launch
+// time, not HBM time, set their cost.)
+#pragma once
+#include "dfh_common.h"
+
+enum TabKind {
+  TAB_PACK_VEC = 0, TAB_PACK_MAT = 1, TAB_PACK_CONV = 2,      // master fp32 -> arena32 / arena16
+  TAB_PACKT_MAT = 3, TAB_PACKT_CONV = 4,                      // master fp32 -> arena16t (transposed packs)
+  TAB_UNPACK_VEC = 5, TAB_UNPACK_MAT = 6, TAB_UNPACK_CONV = 7 // grad32 / grad16 (packed fp32) -> master .grad (+=)
+};
+
+struct TabOp {
+  void* master;            // fp32 parameter (pack: read) or its gradient (unpack: +=)
+  long dst;                // element offset inside the arena
+  int kind, N, K, ld, p0, p1, p2, p3;   // per kind: see packtab.hip
+  unsigned first_block;    // first block of this op in the fused grid
+};
+
+constexpr int TAB_ELEMS_PER_BLOCK = 2048;
+
+namespace dfh {
+unsigned tab_blocks(int kind, int N, int K);   // blocks one op occupies in the fused grid
+// arena: arena32 (VEC) / arena16 / arena16t / grad32 / grad16 according to the op kinds in the table
+int table_launch(const TabOp* dev_ops, int nops, unsigned total_blocks, void* arena_vec, void* arena_mat, hipStream_t s);
+}

@@ -14,6 +14,7 @@
 #include "elementwise.h"
 #include "gemm.h"
 #include "norm.h"
+#include "packtab.h"
 
 namespace dfhm {
 
@@ -57,6 +58,37 @@ struct Bump {
     if (off > peak) peak = off;
     return p;
   }
+};
+
+// host copy + device copy of a TabOp table; re-uploaded only when an entry (e.g. a master pointer) changed
+struct OpTable {
+  std::vector<TabOp> host, uploaded; TabOp* dev = nullptr; size_t cap = 0; unsigned blocks = 0;
+  void clear() { host.clear(); blocks = 0; }
+  void add(void* master, int kind, long dst, int N, int K, int ld, int p0, int p1, int p2, int p3, long /*elems*/) {
+    TabOp op; std::memset(&op, 0, sizeof(op));
+    op.master = master; op.dst = dst; op.kind = kind; op.N = N; op.K = K; op.ld = ld; op.p0 = p0; op.p1 = p1; op.p2 = p2; op.p3 = p3;
+    op.first_block = blocks;
+    blocks += dfh::tab_blocks(kind, N, K);
+    host.push_back(op);
+  }
+  int launch(void* arena_vec, void* arena_mat, hipStream_t s) {
+    if (host.empty()) return 0;
+    const size_t bytes = host.size() * sizeof(TabOp);
+    if (host.size() != uploaded.size() || std::memcmp(host.data(), uploaded.data(), bytes) != 0) {
+      if (host.size() > cap) {
+        if (dev) (void)hipFree(dev);
+        if (hipMalloc((void**)&dev, bytes) != hipSuccess) { dfh::set_error("hipMalloc of an op table failed"); return -1; }
+        cap = host.size();
+      }
+      // rare (first use / parameters re-homed): stream-ordered with respect to earlier launches that read the old table
+      if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(dev, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        dfh::set_error("uploading an op table failed"); return -1;
+      }
+      uploaded = host;
+    }
+    return dfh::table_launch(dev, (int)host.size(), blocks, arena_vec, arena_mat, s);
+  }
+  ~OpTable() { if (dev) (void)hipFree(dev); }
 };
 
 }  // namespace dfhm
@@ -542,18 +574,20 @@ struct dfh_unet {
     return r.rc;
   }
 
+  OpTable tab_pack, tab_pack_acc, tab_packt, tab_unpack;
+  // every PackOp in one launch (plus one for the few biases that ADD onto an already packed vector)
   int pack(const float* const* master, int count, hipStream_t s) {
     DFH_REQUIRE(count == (int)params.size(), "parameter count mismatch");
     DFH_REQUIRE(arena16 && arena32, "arenas not bound");
+    tab_pack.clear(); tab_pack_acc.clear();
     for (const PackOp& op : packs) {
-      const float* src = master[op.param];
+      void* src = (void*)master[op.param];
       DFH_REQUIRE(src != nullptr, "null master parameter: " + params[op.param].name);
-      int rc = 0;
-      if (op.kind == PK_VEC) rc = dfh::pack_vector_launch(src, arena32, op.N, (int)op.dst, op.geglu, op.accumulate, s);
-      else if (op.kind == PK_MAT) rc = dfh::pack_matrix_launch(src, arena16 + op.dst, op.N, op.K, op.ldw, op.row_off, op.col_off, op.geglu, s);
-      else rc = dfh::pack_conv3x3_launch(src, arena16 + op.dst, op.N, op.K, op.ldw, op.col_off, s, op.cin_pad);
-      if (rc) return rc;
+      if (op.kind == PK_VEC) (op.accumulate ? tab_pack_acc : tab_pack).add(src, TAB_PACK_VEC, (long)op.dst, op.N, 0, 0, op.geglu, op.accumulate, 0, 0, op.N);
+      else if (op.kind == PK_MAT) tab_pack.add(src, TAB_PACK_MAT, (long)op.dst, op.N, op.K, op.ldw, op.row_off, op.col_off, op.geglu, 0, (long)op.N * op.K);
+      else tab_pack.add(src, TAB_PACK_CONV, (long)op.dst, op.N, op.K, op.ldw, 0, op.col_off, 0, op.cin_pad, (long)op.N * op.K * 9);
     }
-    return 0;
+    if (int rc = tab_pack.launch(arena32, arena16, s)) return rc;
+    return tab_pack_acc.launch(arena32, arena16, s);
   }
 };

@@ -592,30 +592,29 @@ int dfh_unet::backward(const float* d_out, float* d_sample, float* const* master
   for (auto it = r.tape.rbegin(); it != r.tape.rend() && !r.rc; ++it) (*it)();
   r.tape.clear();           // one backward per forward
   if (r.rc) return r.rc;
-  // packed fp32 gradients -> master-layout .grad (+=)
+  // packed fp32 gradients -> master-layout .grad (+=), one launch over the op table
+  tab_unpack.clear();
   for (const PackOp& op : packs) {
     float* g = master_grads ? master_grads[op.param] : nullptr;
     if (!g) continue;
-    int rc = 0;
-    if (op.kind == PK_VEC) rc = dfh::unpack_vector_launch(grad32, g, op.N, (int)op.dst, op.geglu, s);
-    else if (op.kind == PK_MAT) rc = dfh::unpack_matrix_launch(grad16 + op.dst, g, op.N, op.K, op.ldw, op.row_off, op.col_off, op.geglu, s);
-    else rc = dfh::unpack_conv3x3_launch(grad16 + op.dst, g, op.N, op.K, op.ldw, op.col_off, op.cin_pad, s);
-    if (rc) return rc;
+    if (op.kind == PK_VEC) tab_unpack.add(g, TAB_UNPACK_VEC, (long)op.dst, op.N, 0, 0, op.geglu, 0, 0, 0, op.N);
+    else if (op.kind == PK_MAT) tab_unpack.add(g, TAB_UNPACK_MAT, (long)op.dst, op.N, op.K, op.ldw, op.row_off, op.col_off, op.geglu, 0, (long)op.N * op.K);
+    else tab_unpack.add(g, TAB_UNPACK_CONV, (long)op.dst, op.N, op.K, op.ldw, 0, op.col_off, 0, op.cin_pad, (long)op.N * op.K * 9);
   }
-  return 0;
+  return tab_unpack.launch(grad32, grad16, s);
 }
 
 int dfh_unet::pack_train(const float* const* master, int count, hipStream_t s) {
   DFH_REQUIRE(count == (int)params.size(), "parameter count mismatch");
   DFH_REQUIRE(arena16t != nullptr, "training arenas not bound");
+  tab_packt.clear();
   for (const TPackOp& op : tpacks) {
-    const float* src = master[op.param];
+    void* src = (void*)master[op.param];
     DFH_REQUIRE(src != nullptr, "null master parameter: " + params[op.param].name);
-    const int rc = op.conv ? dfh::pack_conv3x3_t_launch(src, arena16t + op.dst, op.N, op.K, op.ldt, op.t_col_off, op.o_pad, s)
-                           : dfh::pack_matrix_t_launch(src, arena16t + op.dst, op.N, op.K, op.ldt, op.t_row_off, op.t_col_off, op.geglu, s);
-    if (rc) return rc;
+    if (op.conv) tab_packt.add(src, TAB_PACKT_CONV, (long)op.dst, op.N, op.K, op.ldt, 0, op.t_col_off, 0, op.o_pad, (long)op.N * op.K * 9);
+    else tab_packt.add(src, TAB_PACKT_MAT, (long)op.dst, op.N, op.K, op.ldt, op.t_row_off, op.t_col_off, op.geglu, 0, (long)op.N * op.K);
   }
-  return 0;
+  return tab_packt.launch(nullptr, arena16t, s);
 }
 
 // ------------------------------------------------------------------------------------------- C ABI

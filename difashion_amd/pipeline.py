@@ -78,6 +78,18 @@ def training_tables(n_items: int, olen: int) -> Tuple[torch.Tensor, torch.Tensor
     return torch.tensor(tab, dtype=torch.int32), torch.tensor(wt, dtype=torch.float32)
 
 
+_TABLE_CACHE = {}
+
+
+def _training_tables_on(n_items: int, olen: int, dev):
+    """Device-resident copy of training_tables (a pageable host->device copy every step would synchronise the host)."""
+    key = (n_items, olen, str(dev))
+    if key not in _TABLE_CACHE:
+        tab, wt = training_tables(n_items, olen)
+        _TABLE_CACHE[key] = (tab.to(dev), wt.to(dev))
+    return _TABLE_CACHE[key]
+
+
 def _u8(flags, dev):
     return torch.tensor(flags, dtype=torch.uint8, device=dev)
 
@@ -275,8 +287,7 @@ def train_forward(unet, fashion_encoder: MutualEncoder, scheduler, *, latents: t
         null_lat = null_latent.to(**f32).contiguous()
     sp = _lib.stream_ptr
     if use_mutual_guidance:
-        tab, wt = training_tables(n, olen)
-        tab, wt = tab.to(dev), wt.to(dev)      # named: a pointer taken from a temporary could be recycled
+        tab, wt = _training_tables_on(n, olen, dev)
         mb = torch.empty((n, CL), dtype=torch.bfloat16, device=dev)
         _lib.call("dfh_mutual_reduce", _lib.ptr(noisy), None, _lib.ptr(tab), _lib.ptr(wt),
                   _lib.ptr(mb), None, n, olen, CL, sp())
@@ -298,9 +309,11 @@ def train_forward(unet, fashion_encoder: MutualEncoder, scheduler, *, latents: t
     hist = hist_latents.to(**f32).contiguous()
     m_u8, h_u8 = mutual_real.to(torch.uint8), hist_real.to(torch.uint8)
     x_in = _AssembleInput.apply(noisy, mutual, hist, null_lat, m_u8, h_u8, eta)
-    states = ehs.to(dev).clone()
-    if cate_mask_ratio is not None:
-        states[random_p_cate.to(dev) < cate_mask_ratio] = null_prompt.to(dev)[0]
+    states = ehs.to(dev)
+    if cate_mask_ratio is not None:     # torch.where, not boolean-mask assignment: the latter synchronises the host (nonzero)
+        drop = (random_p_cate.to(dev) < cate_mask_ratio)[:, None, None]
+        states = torch.where(drop, null_prompt.to(dev)[0].to(states.dtype), states)
+    states = states.contiguous()
     ptype = scheduler.config.prediction_type
     if ptype == "epsilon":
         target = noi
@@ -314,7 +327,9 @@ def train_forward(unet, fashion_encoder: MutualEncoder, scheduler, *, latents: t
         taps.update(x_in=x_in.detach(), timesteps=t, ehs=states, target=target, pred=pred.detach())
     w = None
     if snr_gamma is not None:
-        ac = scheduler.alphas_cumprod.to(dev)          # min-SNR weights (difashion.py:258-263), looked up on the device
+        if getattr(scheduler, "_ac_dev", None) is None or scheduler._ac_dev.device != dev:
+            scheduler._ac_dev = scheduler.alphas_cumprod.to(dev)
+        ac = scheduler._ac_dev                         # min-SNR weights (difashion.py:258-263), looked up on the device
         snr = ((ac ** 0.5)[t] / ((1.0 - ac) ** 0.5)[t]) ** 2
         w = (torch.minimum(snr, torch.full_like(snr, snr_gamma)) / snr).to(**f32).contiguous()
     return _WeightedMse.apply(pred, target, w)

@@ -259,9 +259,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   if (col >= N) return;
   __shared__ float red[8][32][8];
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int r = r0 + (threadIdx.x >> 5); r < r1; r += 8) {
+  const bf16_t* base = Y + (long)g * rows_per_group * ldy + col;
+  int r = r0 + (threadIdx.x >> 5);
+  for (; r + 56 < r1; r += 64) {          // eight independent 16-byte loads in flight per thread
+    uint4 q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] = *(const uint4*)(base + (long)(r + 8 * u) * ldy);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float f[8];
+      unpack8(q[u], f);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += f[k];
+    }
+  }
+  for (; r < r1; r += 8) {
     float f[8];
-    unpack8(*(const uint4*)(Y + ((long)g * rows_per_group + r) * ldy + col), f);
+    unpack8(*(const uint4*)(base + (long)r * ldy), f);
 #pragma unroll
     for (int k = 0; k < 8; ++k) s[k] += f[k];
   }
@@ -344,8 +358,11 @@ int wgrad_launch(WgradArgs a, hipStream_t s) {
 
 int colsum_launch(const bf16_t* Y, int ldy, int N, int groups, int rows_per_group, float* out, int ld_out, hipStream_t s) {
   DFH_REQUIRE(N % 8 == 0 && ldy % 8 == 0, "colsum: N and ldy must be multiples of 8");
-  int rpb = std::max(64, (rows_per_group + 63) / 64);     // <= 64 row blocks per group
-  rpb = (rpb + 7) / 8 * 8;
+  // about two blocks per CU: more row blocks only add same-address atomics (they serialise in L2)
+  const int xb = (N / 8 + 31) / 32;
+  const int want_y = std::max(1, 512 / (xb * groups));
+  int rpb = std::max(64, (rows_per_group + want_y - 1) / want_y);
+  rpb = (rpb + 63) / 64 * 64;
   const dim3 grid((N / 8 + 31) / 32, (rows_per_group + rpb - 1) / rpb, groups);
   ProfScope ps(PC_OTHER, 0.0, 2.0 * groups * rows_per_group * N, s);
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, Y, ldy, N, rows_per_group, rpb, out, ld_out);

@@ -39,7 +39,8 @@ struct KIter {                    // which 64-deep slice of which K segment a k-
 DFH_DEVICE int cdiv64(int x) { return (x + BK - 1) / BK; }
 
 DFH_DEVICE int seg_len(const GemmArgs& a, int seg) {
-  return seg < a.ntaps ? a.conv_c : a.p_c[seg - a.ntaps];
+  // selects, not a[] indexing: a runtime index into the kernel arguments becomes an s_load + lgkmcnt(0) stall in the k-loop
+  return seg < a.ntaps ? a.conv_c : (seg == a.ntaps ? a.p_c[0] : a.p_c[1]);
 }
 
 DFH_DEVICE KIter kiter_at(const GemmArgs& a, int kstep) {
@@ -132,6 +133,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a
   const bool hi_wave = wave < PB_REM;
 
   const unsigned cc = (unsigned)a.conv_c;
+  // Plain-segment pointers pinned in SGPRs: left to itself hipcc re-loads them from the kernel-argument segment with an
+  // s_load + s_waitcnt lgkmcnt(0) in EVERY k-step of a linear layer (it selects the argument offset, not the value).
+  const bf16_t* psrc0 = a.p_src[0];
+  const bf16_t* psrc1 = a.p_src[1];
+  asm volatile("" : "+s"(psrc0), "+s"(psrc1));
   auto glds = [&](const bf16_t* src, unsigned char* dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -158,8 +164,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a
       }
     } else {
       const int ps = it.seg - a.ntaps;
-      const bf16_t* base = a.p_src[ps];
-      const unsigned pc = (unsigned)a.p_c[ps];
+      const bf16_t* base = ps == 0 ? psrc0 : psrc1;
+      const unsigned pc = (unsigned)it.seglen;
 #pragma unroll
       for (int i = 0; i < IA; ++i) {
         const bool ok = kin & (a_pix[i] >= 0);

@@ -197,6 +197,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a
   constexpr int RS = BN * 2 + 16;                  // LDS row stride of the staged output tile (bytes)
   static_assert(BM * RS <= 2 * STAGE, "staged output tile must fit the pipeline buffers");
   const bool staged = a.ksplit == 1 && a.out_mode == OUT_BF16 && a.act != ACT_GEGLU && (a.N & 7) == 0 && (a.ld_out & 7) == 0;
+  const bool staged_geglu = a.ksplit == 1 && a.act == ACT_GEGLU && (a.ld_out & 7) == 0;
   uint2 rpre[FM][FN];
   if (staged && a.resid) {
 #pragma unroll
@@ -309,6 +310,36 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a
       const int m = m0 + row, n = n0 + cc * 8;
       if (m < a.M && n < a.N)
         *(uint4*)((bf16_t*)a.out + (long)m * a.ld_out + n) = *(const uint4*)(smem + row * RS + cc * 16);
+    }
+    return;
+  }
+  if (staged_geglu) {
+    // value * gelu(gate) on 16-column value/gate blocks: the tile's BN packed columns give BN/2 outputs per row
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int row = wm * TM + i * 16 + fr;
+#pragma unroll
+      for (int j = 0; j + 1 < FN; j += 2) {
+        const int n = n0 + wn * TN + j * 16 + fg * 4;      // packed column of the "value" half
+        float4 bv = float4{0, 0, 0, 0}, bg = float4{0, 0, 0, 0};
+        if (a.bias && n + 16 < a.N) { bv = *(const float4*)(a.bias + n); bg = *(const float4*)(a.bias + n + 16); }
+        const float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+        const float g[4] = {acc[i][j + 1][0] + bg.x, acc[i][j + 1][1] + bg.y, acc[i][j + 1][2] + bg.z, acc[i][j + 1][3] + bg.w};
+        const int ocl = ((wn * TN) >> 1) + (j >> 1) * 16 + fg * 4;      // output column inside the tile
+        uint2 o;
+        o.x = pack2bf(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1]));
+        o.y = pack2bf(v[2] * gelu_erf_f(g[2]), v[3] * gelu_erf_f(g[3]));
+        *(uint2*)(smem + row * RS + ocl * 2) = o;
+      }
+    }
+    __syncthreads();
+    constexpr int CPRG = BN / 16;                    // 16-byte chunks per output row of the tile
+    for (int c = tid; c < BM * CPRG; c += NWV * 64) {
+      const int row = c / CPRG, cc = c - row * CPRG;
+      const int m = m0 + row, oc = (n0 >> 1) + cc * 8;
+      if (m < a.M && oc < (a.N >> 1))
+        *(uint4*)((bf16_t*)a.out + (long)m * a.ld_out + oc) = *(const uint4*)(smem + row * RS + cc * 16);
     }
     return;
   }

@@ -91,7 +91,7 @@ struct dfh_unet::TrainRun {
     return g;
   }
   // dW (packed fp32 gradient of the matrix at arena16 + w_off) += dY^T . A, A described by the forward descriptor
-  void wgrad(const GemmArgs& f, const bf16_t* dY, int ldy, size_t w_off) {
+  void wgrad(const GemmArgs& f, const bf16_t* dY, int ldy, size_t w_off, const Vec* bias = nullptr) {
     if (rc) return;
     WgradArgs w; std::memset(&w, 0, sizeof(w));
     w.conv_src = f.conv_src; w.conv_c = f.conv_c; w.ntaps = f.ntaps;
@@ -99,6 +99,7 @@ struct dfh_unet::TrainRun {
     w.p_src[0] = f.p_src[0]; w.p_src[1] = f.p_src[1]; w.p_c[0] = f.p_c[0]; w.p_c[1] = f.p_c[1]; w.nplain = f.nplain;
     w.dY = dY; w.ldy = ldy; w.zero = zero; w.M = f.M; w.N = f.N;
     w.dW = u->grad16 + w_off; w.ldw = f.ldw; w.msplit = 0;
+    w.dbias = bias ? g32(*bias) : nullptr;
     w.partial = partial; w.partial_cap = partial_cap / sizeof(float);     // shares the split-K slab region of the GEMMs
     if (dry) { partial_need = std::max(partial_need, dfh::wgrad_partial_floats(w) * sizeof(float)); return; }
     rc = dfh::wgrad_launch(w, s);
@@ -197,8 +198,7 @@ struct dfh_unet::TrainRun {
     const ConvL* cp = &c;
     tape.push_back([=] {
       const int M = B * Ho * Wo;
-      wgrad(f, o.g, cp->cout, cp->w.off);
-      colsum(o.g, cp->cout, cp->cout, 1, M, g32(cp->b), cp->cout);
+      wgrad(f, o.g, cp->cout, cp->w.off, &cp->b);
       if (ups) {
         dgrad_conv(o.g, cp->cout, Ho, Wo, 0, cp->wt, x.C, full, false);
         const bool a = acc(x);
@@ -245,8 +245,7 @@ struct dfh_unet::TrainRun {
     tape.push_back([=] {
       const ResL& r = *rp;
       // out = conv2(g2) + shortcut(x)  |  conv2(g2) + x
-      wgrad(f2, out.g, r.cout, r.w2.off);
-      colsum(out.g, r.cout, r.cout, 1, M, g32(r.b2), r.cout);          // conv2.bias and conv_shortcut.bias share this sum
+      wgrad(f2, out.g, r.cout, r.w2.off, &r.b2);
       dgrad_conv(out.g, r.cout, H, W, 0, r.w2t, r.cout, g2.g, false);
       if (r.shortcut) {
         dgrad_linear(out.g, M, r.cout, w16t(r.wst), r.cout, x0.C, x0.g, acc(x0));
@@ -257,8 +256,7 @@ struct dfh_unet::TrainRun {
       }
       groupnorm_bwd(h1, nullptr, g2.g, r.n2w, r.n2b, st2, 1);
       // h1 = conv1(g1) + b1 + temb[b]
-      wgrad(f1, h1.g, r.cout, r.w1.off);
-      colsum(h1.g, r.cout, r.cout, 1, M, g32(r.b1), r.cout);
+      wgrad(f1, h1.g, r.cout, r.w1.off, &r.b1);
       colsum(h1.g, r.cout, r.cout, B, H * W, dtemb_all + r.temb_off, u->temb_total);
       dgrad_conv(h1.g, r.cout, H, W, 0, r.w1t, r.cin, g1.g, false);
       groupnorm_bwd(x0, has1 ? &x1 : nullptr, g1.g, r.n1w, r.n1b, st1, 1);
@@ -317,22 +315,18 @@ struct dfh_unet::TrainRun {
     tape.push_back([=] {
       const AttL& a = *ap;
       // out = proj_out(h3) + x
-      wgrad(f_pout, out.g, C, a.pout.off);
-      colsum(out.g, C, C, 1, M, g32(a.poutb), C);
+      wgrad(f_pout, out.g, C, a.pout.off, &a.poutb);
       dgrad_linear(out.g, M, C, w16t(a.poutt), C, C, gh, false);                     // gh = d h3
       { const bool ax = acc(x); TR_OP(dfh::add_bf16_launch(x.g, out.g, (long)MC, ax, s)); }
       // h3 = ff2(ff) + h2
-      wgrad(f_ff2, gh, C, a.ff2.off);
-      colsum(gh, C, C, 1, M, g32(a.ff2b), C);
+      wgrad(f_ff2, gh, C, a.ff2.off, &a.ff2b);
       dgrad_linear(gh, M, C, w16t(a.ff2t), C, 4 * C, ff.g, false);
       TR_OP(dfh::geglu_bwd_launch(ffpre.p, ff.g, ffpre.g, M, 8 * C, s));
-      wgrad(f_ff1, ffpre.g, 8 * C, a.ff1.off);
-      colsum(ffpre.g, 8 * C, 8 * C, 1, M, g32(a.ff1b), 8 * C);
+      wgrad(f_ff1, ffpre.g, 8 * C, a.ff1.off, &a.ff1b);
       dgrad_linear(ffpre.g, M, 8 * C, w16t(a.ff1t), 8 * C, C, n3.g, false);
       layernorm_bwd(h2, n3.g, a.l3w, a.l3b, gh, 1, M, C);                             // gh = d h2
       // h2 = o2(at2) + h1
-      wgrad(f_o2, gh, C, a.o2.off);
-      colsum(gh, C, C, 1, M, g32(a.o2b), C);
+      wgrad(f_o2, gh, C, a.o2.off, &a.o2b);
       dgrad_linear(gh, M, C, w16t(a.o2t), C, C, at2.g, false);
       attention_bwd(q2.p, C, kx + a.x_off, XT, vx + a.x_off, XT, at2.p, at2.g, C, lse2, delta, q2.g, C, dkx + a.x_off, XT,
                     dvx + a.x_off, XT, heads, N, T);
@@ -340,8 +334,7 @@ struct dfh_unet::TrainRun {
       dgrad_linear(q2.g, M, C, w16t(a.q2t), C, C, n2.g, false);
       layernorm_bwd(h1, n2.g, a.l2w, a.l2b, gh, 1, M, C);                             // gh = d h1
       // h1 = o1(at) + h0
-      wgrad(f_o1, gh, C, a.o1.off);
-      colsum(gh, C, C, 1, M, g32(a.o1b), C);
+      wgrad(f_o1, gh, C, a.o1.off, &a.o1b);
       dgrad_linear(gh, M, C, w16t(a.o1t), C, C, at.g, false);
       attention_bwd(qk.p, 2 * C, qk.p + C, 2 * C, v.p, C, at.p, at.g, C, lse1, delta, qk.g, 2 * C, qk.g + C, 2 * C, v.g, C,
                     heads, N, N);
@@ -350,8 +343,7 @@ struct dfh_unet::TrainRun {
       dgrad_linear(qk.g, M, 2 * C, w16t(a.qkvt), 3 * C, C, n1.g, false, v.g, C);      // [dQ dK | dV] . [Wq; Wk; Wv]
       layernorm_bwd(h0, n1.g, a.l1w, a.l1b, gh, 1, M, C);                             // gh = d h0
       // h0 = proj_in(gn)
-      wgrad(f_pin, gh, C, a.pin.off);
-      colsum(gh, C, C, 1, M, g32(a.pinb), C);
+      wgrad(f_pin, gh, C, a.pin.off, &a.pinb);
       dgrad_linear(gh, M, C, w16t(a.pint), C, C, gn.g, false);
       groupnorm_bwd(x, nullptr, gn.g, a.nw, a.nb, st, 0);
     });
@@ -381,16 +373,13 @@ struct dfh_unet::TrainRun {
     tape.push_back([=] {      // runs LAST: every resnet has added its slice of d temb by then
       dfh_unet& U = *u;
       TR_OP(dfh::cast_f32_to_bf16_launch(dtemb_all, dtemb16, (long)B * TT, s));
-      wgrad(f_tp, dtemb16, TT, U.tproj.off);
-      colsum(dtemb16, TT, TT, 1, B, g32(U.tprojb), TT);
+      wgrad(f_tp, dtemb16, TT, U.tproj.off, &U.tprojb);
       dgrad_linear(dtemb16, B, TT, w16t(U.tprojt), TT, temb, de2, false);
       TR_OP(dfh::act_bwd_launch(pre2, nullptr, de2, nullptr, dpre2, (long)B * temb, 1, 1.0f, s));
-      wgrad(f_te2, dpre2, temb, U.te2.off);
-      colsum(dpre2, temb, temb, 1, B, g32(U.te2b), temb);
+      wgrad(f_te2, dpre2, temb, U.te2.off, &U.te2b);
       dgrad_linear(dpre2, B, temb, w16t(U.te2t), temb, temb, de1, false);
       TR_OP(dfh::act_bwd_launch(pre1, nullptr, de1, nullptr, dpre1, (long)B * temb, 1, 1.0f, s));
-      wgrad(f_te1, dpre1, temb, U.te1.off);
-      colsum(dpre1, temb, temb, 1, B, g32(U.te1b), temb);
+      wgrad(f_te1, dpre1, temb, U.te1.off, &U.te1b);
     });
 
     // ---- text K / V of every transformer layer (row-major kept for the backward, V^T for the forward kernel)
@@ -423,8 +412,7 @@ struct dfh_unet::TrainRun {
       tape.push_back([=] {
         dfh_unet& U = *u;
         const int M = B * S * S, C0 = U.conv_in.cout;
-        wgrad(f, h0.g, C0, U.conv_in.w.off);
-        colsum(h0.g, C0, C0, 1, M, g32(U.conv_in.b), C0);
+        wgrad(f, h0.g, C0, U.conv_in.w.off, &U.conv_in.b);
         if (dry || d_sample) {
           dgrad_conv(h0.g, C0, S, S, 0, U.conv_in.wt, x.C, x.g, false);
           if (d_sample) TR_OP(dfh::nhwc_to_nchw_f32_launch(x.g, d_sample, B, S * S, x.C, U.cfg.in_channels, 1.0f, 0, s));
@@ -466,8 +454,7 @@ struct dfh_unet::TrainRun {
       tape.push_back([=] {     // runs FIRST
         dfh_unet& U = *u;
         TR_OP(dfh::nchw_to_nhwc_launch(d_out, 0, dy, B, Co, S * S, s));             // pads the channels to Cop with zeros
-        wgrad(f, dy, Cop, U.conv_out.w.off);
-        colsum(dy, Cop, Cop, 1, M, g32(U.conv_out.b), Cop);                        // tail lands in the vector's padding
+        wgrad(f, dy, Cop, U.conv_out.w.off, &U.conv_out.b);
         dgrad_conv(dy, Cop, S, S, 0, U.conv_out.wt, g.C, g.g, false);
         groupnorm_bwd(hl, nullptr, g.g, U.cnw, U.cnb, st, 1);
       });

@@ -167,6 +167,14 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradArgs a) {
   const unsigned ylane = lds0 + (fg * 4 + (L >> 2)) * ROWB + (wave_n * 80 + (L & 3) * 4) * 2;
   const unsigned alane = lds0 + REGION + (fg * 4 + (L >> 2)) * ROWB + (wave_k * 80 + (L & 3) * 4) * 2;
 
+  // bias gradient (optional): the blocks of the first kcol chunk also reduce their dY tile over the pixels
+  const bool do_bias = a.dbias != nullptr && chunk == 0 && wave_k == 0;
+  f32x4_t accb[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) accb[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((ext_vector_type(8))) unsigned short u16x8_t;
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, u16x8_t{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
+
   if (nsteps > 0) {
     int issued = 0;
 #pragma unroll
@@ -196,6 +204,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradArgs a) {
       bf16x8_t yf[5];
 #pragma unroll
       for (int nf = 0; nf < 5; ++nf) yf[nf] = frag_of(y[nf][0], y[nf][1]);
+      if (do_bias) {                                  // column sums of dY = a row of ones as the A operand
+#pragma unroll
+        for (int nf = 0; nf < 5; ++nf) accb[nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[nf], accb[nf], 0, 0, 0);
+      }
 #define WG_ROW(kf, N)                                                                                        \
       LGKM_WAIT1(N, x[kf]);                                                                                  \
       { const bf16x8_t af = frag_of(x[kf][0], x[kf][1]);                                                      \
@@ -208,6 +220,13 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradArgs a) {
     }
   }
 
+  if (do_bias && fg == 0) {
+#pragma unroll
+    for (int nf = 0; nf < 5; ++nf) {
+      const int n = n0 + wave_n * 80 + nf * 16 + L;
+      if (n < a.N) atomicAdd(a.dbias + n, accb[nf][0]);      // N x msplit atomics per layer: negligible
+    }
+  }
   // a lane ends with 4 consecutive packed columns of one output channel: one 16-byte access.  A single m-slice adds
   // straight into dW (each element belongs to exactly one block); several slices write fp32 slabs that
   // wgrad_reduce_kernel sums in a fixed order (deterministic; scalar fp32 atomics cap out near 70 G/s on this part)

@@ -1,0 +1,12 @@
+#!/usr/bin/env python3
+"""One GEMM shape a few times (PMC target): python scripts/gemm_one.py conv320|lin320|conv1280"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gemm_microbench import run
+which = sys.argv[1] if len(sys.argv) > 1 else "conv320"
+if which == "conv320":
+    run("conv 320->320 @64", 65536, 320, 0, conv=(16, 64, 320, 1, 0), resid=False)
+elif which == "conv1280":
+    run("conv 1280->1280 @16", 4096, 1280, 0, conv=(16, 16, 1280, 1, 0), resid=False)
+else:
+    run("linear 64^2 C320 K1280", 65536, 320, 1280)

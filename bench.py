@@ -165,6 +165,21 @@ def run_train(args, da, _lib, ddist, rank, world, dev):
     print(json.dumps(out), flush=True)
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/rNN/pmc_traffic.json,
+    written by scripts/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command,
+    FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md).  PMC counters cannot be read from inside the timed process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return float(d["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,9 +239,12 @@ def main():
         prof_ms = (time.perf_counter() - t1) * 1e3 / K
         gemm = {k: sum(classes[c][k] for c in ("gemm_conv3x3", "gemm_linear")) for k in ("launches", "ms", "flops", "bytes")}
         achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic()
         roofline = dict(bound="mfma", kernel="gemm_bf16_kernel (conv3x3 + 1x1 + linear, implicit GEMM)",
                         achieved=round(achieved, 1), peak=MFMA_BF16_PEAK, unit="TFLOP/s", frac=round(achieved / MFMA_BF16_PEAK, 4),
-                        traffic=None, launches_per_step=gemm["launches"] // K,
+                        traffic=traffic, traffic_unit="HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", traffic_source=traffic_src,
+                        algorithmic_bytes_per_launch=round(gemm["bytes"] / max(1, gemm["launches"])),
+                        launches_per_step=gemm["launches"] // K,
                         avg_launch_us=round(gemm["ms"] * 1e3 / max(1, gemm["launches"]), 2),
                         algorithmic_tflop_per_step=round(gemm["flops"] / K / 1e12, 3))
 

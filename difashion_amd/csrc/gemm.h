@@ -45,4 +45,7 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile = 0, int force_sp
 int gemm_pick_split(const GemmArgs& a, int* tile_out);
 size_t gemm_partial_floats(const GemmArgs& a);
 int gemm_count_ksteps(const GemmArgs& a);
+// 256 x 160 wide-tile variant (gemm_wide.hip): higher arithmetic intensity against the LDS staging path
+bool gemm_wide_eligible(const GemmArgs& a);
+int gemm_wide_launch(GemmArgs a, hipStream_t stream);
 }  // namespace dfh

@@ -547,6 +547,8 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
   a.ksteps = gemm_count_ksteps(a);
   int tile;
   int split = gemm_pick_split(a, &tile);
+  const bool force_wide = force_tile == kNumTiles + 1;       // microbench: tile id 6 = the 256 x 160 wide kernel
+  if (force_wide) force_tile = 0;
   if (force_tile > 0) { DFH_REQUIRE(force_tile <= kNumTiles, "unknown tile variant"); tile = force_tile - 1; }
   if (force_split > 0) split = force_split;
   if (a.act == ACT_GEGLU) {
@@ -565,7 +567,10 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     for (int i = 0; i < a.nplain; ++i) { kreal += a.p_c[i]; abytes += (double)a.M * a.p_c[i] * 2.0; }
     const double obytes = (double)a.M * (a.act == ACT_GEGLU ? a.N / 2 : a.N) * ((a.out_mode == OUT_F32 || a.out_mode == OUT_F32_T) ? 4.0 : 2.0);
     ProfScope ps(a.ntaps ? PC_CONV3 : PC_LINEAR, 2.0 * a.M * a.N * kreal, abytes + (double)a.N * kreal * 2.0 + obytes, stream);
-    rc = launch_variant(tile, a, stream);
+    const bool wide_ok = split == 1 && a.out_mode == OUT_BF16 && a.act != ACT_GEGLU && (a.N & 7) == 0 && (a.ld_out & 7) == 0 &&
+                         (!a.resid || (a.ld_res & 7) == 0);
+    if (wide_ok && (force_wide || (force_tile == 0 && force_split == 0 && gemm_wide_eligible(a)))) rc = gemm_wide_launch(a, stream);
+    else rc = launch_variant(tile, a, stream);
   }
   if (rc) return rc;
   if (split > 1) {

@@ -1,0 +1,309 @@
+// Wide-tile variant of the implicit GEMM (same GemmArgs / K-segment semantics as gemm.hip).
+//
+// Why it exists: on MI355X the 128 x {64,128,160} tiles of gemm.hip run at a throughput PROPORTIONAL to their
+// arithmetic intensity against the global->LDS staging path (43 / 64 / 71 flop per staged byte -> 527 / 792 / 852
+// TFLOP/s on a 65536 x 1280 x 1280 GEMM, scripts/gemm_tiles_probe.py): the LDS-DMA path, not the MFMA pipe, is the
+// limiter.  This kernel raises the intensity to 98 flop/B while keeping two workgroups per CU:
+//   * 256 x 160 block tile, 4 waves as 2 x 2, each 128 x 80 (8 x 5 MFMA fragments, 160 accumulator VGPRs);
+//   * 32-deep k-steps (one v_mfma_f32_16x16x32_bf16 per fragment pair), 26 KB per stage, 3 stages in flight
+//     (78 KB), one barrier per 40 MFMAs;
+//   * 64-byte LDS rows, 16-byte slots swizzled by (row >> 1) & 3 on the SOURCE address and on the fragment read
+//     (conflict-free for the ds_read_b128 lane groups; linear rows are 2-way conflicted);
+//   * epilogue in four 64-row passes through an fp32 LDS tile: bias / time-embedding row / activation / residual are
+//     applied on full rows, so residual reads and output writes are 16-byte pieces of contiguous rows and the result is
+//     rounded to bf16 exactly once.
+// Used for bf16-output launches without GEGLU / split-K whose grid fills the chip (gemm_wide_eligible).
+#include "gemm.h"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int BKW = 32;
+
+struct KIterW { int seg, c0, wcol, seglen; };
+
+DFH_DEVICE int seg_len_w(const GemmArgs& a, int seg) {
+  return seg < a.ntaps ? a.conv_c : (seg == a.ntaps ? a.p_c[0] : a.p_c[1]);
+}
+DFH_DEVICE KIterW kiterw_at(const GemmArgs& a, int kstep) {
+  KIterW it;
+  int seg = 0, base = 0;
+  const int nseg = a.ntaps + a.nplain;
+  for (;;) {
+    const int len = seg_len_w(a, seg);
+    const int n = (len + BKW - 1) / BKW;
+    if (kstep < n || seg == nseg - 1) { it.seglen = len; break; }
+    kstep -= n; base += len; ++seg;
+  }
+  it.seg = seg; it.c0 = kstep * BKW; it.wcol = base + it.c0;
+  return it;
+}
+DFH_DEVICE void kiterw_next(const GemmArgs& a, KIterW& it) {
+  it.c0 += BKW; it.wcol += BKW;
+  if (it.c0 >= it.seglen) {
+    it.wcol -= it.c0 - it.seglen;
+    it.c0 = 0; ++it.seg;
+    if (it.seg < a.ntaps + a.nplain) it.seglen = seg_len_w(a, it.seg);
+  }
+}
+template <int N> DFH_DEVICE void ww_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+#define WRD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs a) {
+  constexpr int NWV = 4, WN = 2;
+  constexpr int TM = BM / 2, TN = BN / 2;            // per-wave output tile
+  constexpr int FM = TM / 16, FN = TN / 16;
+  constexpr int PA = BM / 16, PB = BN / 16;          // 1-KiB staging pieces (16 rows x 64 B) per stage
+  constexpr int IA = PA / NWV, IB = (PB + NWV - 1) / NWV;
+  constexpr int A_BYTES = BM * BKW * 2, B_BYTES = BN * BKW * 2, STAGE = A_BYTES + B_BYTES, NSTAGE = 3;
+  static_assert(PA % NWV == 0 && TM % 16 == 0 && TN % 16 == 0, "tile");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+  const int nk = a.ksteps;                           // 32-deep steps (filled by the launcher)
+
+  // staging geometry: piece p = i*4 + wave holds tile rows p*16 + lane/4; the LDS image is lane-linear, the SOURCE
+  // 16-byte chunk is swizzled: slot s of row r holds channel chunk s ^ ((r >> 1) & 3)
+  const int srow = lane >> 2;
+  const int schunk = (lane & 3) ^ ((lane >> 3) & 3);
+  int a_pix[IA], a_y[IA], a_x[IA], a_bbase[IA];
+  const int HWo = a.Hout * a.Wout;
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    const int m = m0 + (i * NWV + wave) * 16 + srow;
+    a_pix[i] = -1; a_y[i] = 0; a_x[i] = 0; a_bbase[i] = 0;
+    if (m < a.M) {
+      a_pix[i] = m;
+      if (a.ntaps) {
+        const int b = m / HWo, rem = m - b * HWo;
+        const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+        a_y[i] = oy * a.stride - 1; a_x[i] = ox * a.stride - 1;
+        a_bbase[i] = b * a.Hin * a.Win;
+      }
+    }
+  }
+  int w_row[IB];
+#pragma unroll
+  for (int i = 0; i < IB; ++i) {
+    const int n = n0 + (i * NWV + wave) * 16 + srow;
+    w_row[i] = (n < a.N) ? n * a.ldw : -1;
+  }
+  const int Hv = a.ups ? a.Hin * 2 : a.Hin, Wv = a.ups ? a.Win * 2 : a.Win;
+  constexpr int N_LO = IA + PB / NWV, N_HI = N_LO + 1, PB_REM = PB % NWV;
+  const bool hi_wave = wave < PB_REM;
+
+  const unsigned cc = (unsigned)a.conv_c;
+  const bf16_t* psrc0 = a.p_src[0];
+  const bf16_t* psrc1 = a.p_src[1];
+  asm volatile("" : "+s"(psrc0), "+s"(psrc1));      // keep them in SGPRs (see gemm.hip)
+  auto glds = [&](const bf16_t* src, unsigned char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto issue_stage = [&](const KIterW& it, int buf) {
+    unsigned char* As = smem + buf * STAGE + wave * 1024;
+    unsigned char* Bs = As + A_BYTES;
+    const int ch = it.c0 + schunk * 8;
+    const bool kin = ch < it.seglen;
+    if (it.seg < a.ntaps) {
+      const int ky = it.seg / 3, kx = it.seg - ky * 3;
+#pragma unroll
+      for (int i = 0; i < IA; ++i) {
+        const int yy = a_y[i] + ky, xx = a_x[i] + kx;
+        const bool ok = kin & (a_pix[i] >= 0) & ((unsigned)yy < (unsigned)Hv) & ((unsigned)xx < (unsigned)Wv) &
+                        ((a.ups != 2) | (((yy | xx) & 1) == 0));
+        const int sy = a.ups ? (yy >> 1) : yy, sx = a.ups ? (xx >> 1) : xx;
+        const unsigned off = (unsigned)(a_bbase[i] + sy * a.Win + sx) * cc + (unsigned)ch;
+        glds(ok ? a.conv_src + off : a.zero, As + i * NWV * 1024);
+      }
+    } else {
+      const bf16_t* base = it.seg == a.ntaps ? psrc0 : psrc1;
+      const unsigned pc = (unsigned)it.seglen;
+#pragma unroll
+      for (int i = 0; i < IA; ++i) {
+        const bool ok = kin & (a_pix[i] >= 0);
+        const unsigned off = (unsigned)a_pix[i] * pc + (unsigned)ch;
+        glds(ok ? base + off : a.zero, As + i * NWV * 1024);
+      }
+    }
+    const unsigned wc = (unsigned)(it.wcol + schunk * 8);
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      if (i * NWV + wave >= PB) continue;             // wave-uniform
+      const bool ok = kin & (w_row[i] >= 0);
+      glds(ok ? a.W + ((unsigned)w_row[i] + wc) : a.zero, Bs + i * NWV * 1024);
+    }
+  };
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  // fragment read offsets inside a stage: row * 64 + ((fg ^ ((row >> 1) & 3)) << 4); (row >> 1) & 3 depends on fr only
+  const int fslot = (fg ^ ((fr >> 1) & 3)) << 4;
+  const unsigned a_off = (wm * TM + fr) * 64 + fslot;
+  const unsigned b_off = A_BYTES + (wn * TN + fr) * 64 + fslot;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  static_assert(FM == 8 && FN == 5, "the hand-scheduled k-step is written for 8 x 5 fragments");
+
+  if (nk > 0) {
+    KIterW it = kiterw_at(a, 0);
+    int issued = 0;
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s) {
+      if (s < nk) {
+        if (s) kiterw_next(a, it);
+        issue_stage(it, s);
+        ++issued;
+      }
+    }
+    int buf = 0;
+    for (int t = 0; t < nk; ++t) {
+      const int ahead = issued - 1 - t;
+      if (ahead == 0) ww_vmcnt<0>();
+      else if (ahead == 1) { if (hi_wave) ww_vmcnt<N_HI>(); else ww_vmcnt<N_LO>(); }
+      else { if (hi_wave) ww_vmcnt<2 * N_HI>(); else ww_vmcnt<2 * N_LO>(); }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (issued < nk) {
+        kiterw_next(a, it);
+        int nb = buf - 1; if (nb < 0) nb += NSTAGE;
+        issue_stage(it, nb);
+        ++issued;
+      }
+      // Fragment reads software-pipelined by hand (inline asm + counted lgkmcnt): the A fragment of row i+2 is in
+      // flight while row i's five MFMAs run, so no MFMA group waits for a full LDS round trip (left to hipcc the reads
+      // are issued right in front of an s_waitcnt lgkmcnt(0) five times per step).
+      const unsigned sa = lds0 + buf * STAGE + a_off, sb = lds0 + buf * STAGE + b_off;
+      u32x4_t b[FN], a0, a1, a2;
+      __builtin_amdgcn_sched_barrier(0);
+      WRD(b[0], sb, 0); WRD(b[1], sb, 1024); WRD(b[2], sb, 2048); WRD(b[3], sb, 3072); WRD(b[4], sb, 4096);
+      WRD(a0, sa, 0); WRD(a1, sa, 1024);
+      asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(a0));
+#define WROW(i, ar)                                                                                                    \
+      _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                                   \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b[j]), __builtin_bit_cast(bf16x8_t, ar), \
+                                                            acc[i][j], 0, 0, 0);
+#define WNEXT(rd, off, wt) WRD(rd, sa, off); asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wt));
+      // weights as MFMA-A: D[row = channel (fg*4+r)][col = pixel (fr)]
+      WROW(0, a0) WNEXT(a2, 2048, a1)
+      WROW(1, a1) WNEXT(a0, 3072, a2)
+      WROW(2, a2) WNEXT(a1, 4096, a0)
+      WROW(3, a0) WNEXT(a2, 5120, a1)
+      WROW(4, a1) WNEXT(a0, 6144, a2)
+      WROW(5, a2) WNEXT(a1, 7168, a0)
+      WROW(6, a0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1));
+      WROW(7, a1)
+#undef WROW
+#undef WNEXT
+      __builtin_amdgcn_sched_barrier(0);
+      if (++buf == NSTAGE) buf = 0;
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue: four 64-row passes through fp32 LDS
+  constexpr int RSF = BN * 4 + 16;                 // fp32 row stride (bytes); 64 rows = 42 KB
+  constexpr int CPR = BN / 8;                      // 8-column chunks per row
+  static_assert(64 * RSF <= NSTAGE * STAGE, "epilogue tile must fit the pipeline buffers");
+#pragma unroll
+  for (int q = 0; q < BM / 64; ++q) {
+    __syncthreads();                               // pipeline buffers / previous pass no longer read
+    if (wm == q / 2) {
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = (q & 1) * 4 + ii;
+        const int row = ii * 16 + fr;              // row inside the 64-row pass
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          *(f32x4_t*)(smem + row * RSF + (wn * TN + j * 16 + fg * 4) * 4) = acc[i][j];
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < 64 * CPR; c += 256) {
+      const int row = c / CPR, cchunk = c - row * CPR;
+      const int m = m0 + q * 64 + row, n = n0 + cchunk * 8;
+      if (m >= a.M || n >= a.N) continue;
+      float v[8];
+      {
+        const float4 lo = *(const float4*)(smem + row * RSF + cchunk * 32);
+        const float4 hi = *(const float4*)(smem + row * RSF + cchunk * 32 + 16);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+      }
+      if (a.bias) {
+        const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (a.rowvec) {
+        const float* rv = a.rowvec + (long)(m / a.rows_per_b) * a.rv_ld + a.rv_off + n;
+        const float4 r0 = *(const float4*)rv, r1 = *(const float4*)(rv + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      }
+      if (a.act == ACT_SILU) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+      } else if (a.act == ACT_LEAKY) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.01f * v[r];
+      } else if (a.act == ACT_TANH) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = tanhf(v[r]);
+      }
+      if (a.resid) {
+        float f[8];
+        unpack8(*(const uint4*)(a.resid + (long)m * a.ld_res + n), f);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += f[r];
+      }
+      *(uint4*)((bf16_t*)a.out + (long)m * a.ld_out + n) = pack8(v);
+    }
+  }
+}
+
+}  // namespace
+
+namespace dfh {
+
+int gemm_wide_ksteps(const GemmArgs& a) {
+  int n = a.ntaps * ((a.conv_c + BKW - 1) / BKW);
+  for (int i = 0; i < a.nplain; ++i) n += (a.p_c[i] + BKW - 1) / BKW;
+  return n;
+}
+
+// bf16 row-major output, no GEGLU / split-K, 16-byte aligned rows, and enough tiles to give every CU its two workgroups
+bool gemm_wide_eligible(const GemmArgs& a) {
+  if (a.out_mode != OUT_BF16 || a.act == ACT_GEGLU) return false;
+  if ((a.N & 7) || (a.ld_out & 7) || (a.resid && (a.ld_res & 7))) return false;
+  if (a.N % 160 != 0 && a.N < 640) return false;
+  const long tiles = (long)((a.M + 255) / 256) * ((a.N + 159) / 160);
+  return tiles >= 448;
+}
+
+int gemm_wide_launch(GemmArgs a, hipStream_t s) {
+  constexpr int BM = 256, BN = 160;
+  constexpr int lds = 3 * (BM + BN) * BKW * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  a.ksteps = gemm_wide_ksteps(a);
+  a.ksplit = 1;
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  hipLaunchKernelGGL((gemm_wide_kernel<BM, BN>), dim3(tiles), dim3(256), lds, s, a);
+  return check_launch("gemm_wide_kernel");
+}
+
+}  // namespace dfh

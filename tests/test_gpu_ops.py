@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 # ----------------------------------------------------------------------------- GEMM (linear / 1x1 conv)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])     # every tile / pipeline-depth variant of gemm.hip
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])  # every tile / pipeline-depth variant of gemm.hip; 6 = gemm_wide.hip
 @pytest.mark.parametrize("glds", [1])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (128, 160, 64), (77 * 3, 64, 768), (16, 1280, 200), (4, 256, 2048)])
 def test_gemm_plain(tile, glds, M, N, K):
@@ -50,14 +50,15 @@ def test_gemm_two_sources_is_channel_concat():
     gu.assert_close_bf16(out, ref, "concat")
 
 
+@pytest.mark.parametrize("tile", [0, 6])
 @pytest.mark.parametrize("act,fn", [(1, F.silu), (2, lambda x: F.leaky_relu(x, 0.01)), (3, torch.tanh)])
-def test_gemm_activations_and_rowvec(act, fn):
+def test_gemm_activations_and_rowvec(act, fn, tile):
     B, rows, N, K = 3, 40, 128, 96
     M = B * rows
     a, w = bf(rnd(M, K, seed=11)), bf(rnd(N, K, seed=12, scale=0.1))
     bias = rnd(N, seed=13)
     rv = rnd(B, 3 * N, seed=14)
-    out = gu.gemm(M=M, N=N, W=w, ldw=K, a0=a, a0_c=K, bias=bias, rowvec=rv, rv_ld=3 * N, rv_off=N, rows_per_b=rows, act=act)
+    out = gu.gemm(M=M, N=N, W=w, ldw=K, a0=a, a0_c=K, bias=bias, rowvec=rv, rv_ld=3 * N, rv_off=N, rows_per_b=rows, act=act, force_tile=tile)
     ref = fn(a.float() @ w.float().T + bias + rv[:, N:2 * N].repeat_interleave(rows, 0))
     gu.assert_close_bf16(out, ref, f"act{act}")
 
@@ -99,7 +100,7 @@ def test_gemm_transposed_outputs():
     (64, 4, 16, 1, 0),      # conv_out shape class
     (128, 128, 2, 1, 0),    # 2x2 level of the tiny configs: every tap hits padding somewhere
 ])
-@pytest.mark.parametrize("glds", [0, 1, 4])   # here: forced tile variant (0 = heuristic, 1 = 256x160 ring, 4 = 128x160 2-stage)
+@pytest.mark.parametrize("glds", [0, 1, 4, 6])   # here: forced tile variant (0 = heuristic, 1 = 256x160 ring, 4 = 128x160 2-stage, 6 = wide)
 def test_conv3x3(cin, cout, H, stride, ups, glds):
     B = 2
     x = bf(rnd(B, cin, H, H, seed=20))
@@ -113,7 +114,8 @@ def test_conv3x3(cin, cout, H, stride, ups, glds):
     gu.assert_close_bf16(gu.nchw(out.view(B, Ho, Ho, cout)), ref, f"conv {cin}->{cout}@{H} s{stride} u{ups}")
 
 
-def test_conv3x3_with_fused_shortcut_and_temb():
+@pytest.mark.parametrize("tile", [0, 6])
+def test_conv3x3_with_fused_shortcut_and_temb(tile):
     """ResnetBlock2D tail: conv2(h) + conv_shortcut(cat(x, skip)) + biases, and conv1 + time embedding."""
     B, H, c0, c1, cout = 2, 8, 64, 32, 96
     h = bf(rnd(B, cout, H, H, seed=23))
@@ -130,12 +132,12 @@ def test_conv3x3_with_fused_shortcut_and_temb():
     _lib.call("dfh_pack_vector", _lib.ptr(bs), _lib.ptr(bias), cout, 0, 0, 1, gu.stream())
     M = B * H * H
     out = gu.gemm(M=M, N=cout, W=W, ldw=K, conv_src=gu.nhwc(h), conv_c=cout, batch=B, Hin=H, Win=H,
-                  a0=gu.nhwc(x0).view(M, c0), a0_c=c0, a1=gu.nhwc(x1).view(M, c1), a1_c=c1, bias=bias)
+                  a0=gu.nhwc(x0).view(M, c0), a0_c=c0, a1=gu.nhwc(x1).view(M, c1), a1_c=c1, bias=bias, force_tile=tile)
     ref = F.conv2d(h.float(), bf(w2).float(), b2, padding=1) + F.conv2d(torch.cat([x0, x1], 1).float(), bf(ws).float(), bs)
     gu.assert_close_bf16(gu.nchw(out.view(B, H, H, cout)), ref, "conv2+shortcut")
     temb = rnd(B, 2 * cout, seed=30)
     out = gu.gemm(M=M, N=cout, W=gu.pack_conv(w2), ldw=9 * cout, conv_src=gu.nhwc(h), conv_c=cout, batch=B, Hin=H, Win=H,
-                  bias=b2, rowvec=temb, rv_ld=2 * cout, rv_off=cout, rows_per_b=H * H)
+                  bias=b2, rowvec=temb, rv_ld=2 * cout, rv_off=cout, rows_per_b=H * H, force_tile=tile)
     ref = F.conv2d(h.float(), bf(w2).float(), b2, padding=1) + temb[:, cout:, None, None]
     gu.assert_close_bf16(gu.nchw(out.view(B, H, H, cout)), ref, "conv1+temb")
 

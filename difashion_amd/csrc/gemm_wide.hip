@@ -232,6 +232,34 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs a) {
       }
     }
     __syncthreads();
+    if (a.act == ACT_GEGLU) {
+      // packed columns come in 32-blocks (16 values | 16 gates): out[m][16 k + i] = (v_i + bv_i) * gelu(g_i + bg_i)
+      constexpr int GPR = BN / 16;                 // 8-output chunks per row: two per 32-block
+      for (int c = tid; c < 64 * GPR; c += 256) {
+        const int row = c / GPR, gc = c - row * GPR;
+        const int colv = (gc >> 1) * 32 + (gc & 1) * 8;        // value columns of this chunk; gates at +16
+        const int m = m0 + q * 64 + row, n = n0 + colv;
+        if (m >= a.M || n + 16 >= a.N) continue;
+        float v[8], g[8];
+        {
+          const float* src = (const float*)(smem + row * RSF) + colv;
+          const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 4);
+          const float4 g0 = *(const float4*)(src + 16), g1 = *(const float4*)(src + 20);
+          v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+          g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+        }
+        if (a.bias) {
+          const float4 bv0 = *(const float4*)(a.bias + n), bv1 = *(const float4*)(a.bias + n + 4);
+          const float4 bg0 = *(const float4*)(a.bias + n + 16), bg1 = *(const float4*)(a.bias + n + 20);
+          v[0] += bv0.x; v[1] += bv0.y; v[2] += bv0.z; v[3] += bv0.w; v[4] += bv1.x; v[5] += bv1.y; v[6] += bv1.z; v[7] += bv1.w;
+          g[0] += bg0.x; g[1] += bg0.y; g[2] += bg0.z; g[3] += bg0.w; g[4] += bg1.x; g[5] += bg1.y; g[6] += bg1.z; g[7] += bg1.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] *= gelu_erf_f(g[r]);
+        *(uint4*)((bf16_t*)a.out + (long)m * a.ld_out + ((n0 + (gc >> 1) * 32) >> 1) + (gc & 1) * 8) = pack8(v);
+      }
+      continue;
+    }
     for (int c = tid; c < 64 * CPR; c += 256) {
       const int row = c / CPR, cchunk = c - row * CPR;
       const int m = m0 + q * 64 + row, n = n0 + cchunk * 8;
@@ -284,7 +312,8 @@ int gemm_wide_ksteps(const GemmArgs& a) {
 
 // bf16 row-major output, no GEGLU / split-K, 16-byte aligned rows, and enough tiles to give every CU its two workgroups
 bool gemm_wide_eligible(const GemmArgs& a) {
-  if (a.out_mode != OUT_BF16 || a.act == ACT_GEGLU) return false;
+  if (a.out_mode != OUT_BF16) return false;
+  if (a.act == ACT_GEGLU && (a.N % 160 != 0 || a.resid || a.rowvec)) return false;
   if ((a.N & 7) || (a.ld_out & 7) || (a.resid && (a.ld_res & 7))) return false;
   if (a.N % 160 != 0 && a.N < 640) return false;
   const long tiles = (long)((a.M + 255) / 256) * ((a.N + 159) / 160);

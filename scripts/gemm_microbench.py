@@ -76,6 +76,8 @@ if __name__ == "__main__":
             run(f"{name} [{tag}]", tile=tile, **kw)
     run("geglu 64^2 N2560 [auto]", 65536, 2560, 320, act=4)
     run("geglu 64^2 N2560 [128x128s2]", 65536, 2560, 320, act=4, tile=5)
+    run("geglu 64^2 N2560 [wide]", 65536, 2560, 320, act=4, tile=6)
+    run("geglu 32^2 N5120 [128x128s2]", 16384, 5120, 640, act=4, tile=5)
     run("geglu 32^2 N5120 [auto]", 16384, 5120, 640, act=4)
     run("temb 16x20480x1280", 16, 20480, 1280, resid=False, out_mode=2)
     run("conv 8->320 @64 (conv_in)", 65536, 320, 0, conv=(16, 64, 8, 1, 0), resid=False)

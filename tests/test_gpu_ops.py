@@ -63,9 +63,9 @@ def test_gemm_activations_and_rowvec(act, fn, tile):
     gu.assert_close_bf16(out, ref, f"act{act}")
 
 
-def test_gemm_geglu_epilogue():
+@pytest.mark.parametrize("M,C,tile", [(200, 64, 0), (300, 40, 0), (300, 40, 6), (520, 80, 6)])
+def test_gemm_geglu_epilogue(M, C, tile):
     """FeedForward GEGLU: proj -> chunk(2) -> a * gelu(gate); weights/bias interleaved by dfh_pack_*."""
-    M, C = 200, 64
     x = bf(rnd(M, C, seed=15))
     w = rnd(8 * C, C, seed=16, scale=0.1)
     b = rnd(8 * C, seed=17, scale=0.5)
@@ -73,7 +73,7 @@ def test_gemm_geglu_epilogue():
     bp = torch.empty(8 * C, dtype=torch.float32, device=DEV)
     _lib.call("dfh_pack_matrix", _lib.ptr(w), _lib.ptr(wp), 8 * C, C, C, 0, 0, 1, gu.stream())
     _lib.call("dfh_pack_vector", _lib.ptr(b), _lib.ptr(bp), 8 * C, 0, 1, 0, gu.stream())
-    out = gu.gemm(M=M, N=8 * C, W=wp, ldw=C, a0=x, a0_c=C, bias=bp, act=4)
+    out = gu.gemm(M=M, N=8 * C, W=wp, ldw=C, a0=x, a0_c=C, bias=bp, act=4, force_tile=tile)
     h = x.float() @ bf(w).float().T + b
     a, gate = h.chunk(2, -1)
     gu.assert_close_bf16(out, a * F.gelu(gate), "geglu")

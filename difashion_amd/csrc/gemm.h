@@ -47,5 +47,6 @@ size_t gemm_partial_floats(const GemmArgs& a);
 int gemm_count_ksteps(const GemmArgs& a);
 // 256 x 160 wide-tile variant (gemm_wide.hip): higher arithmetic intensity against the LDS staging path
 bool gemm_wide_eligible(const GemmArgs& a);
-int gemm_wide_launch(GemmArgs a, hipStream_t stream);
+int gemm_wide_pick(const GemmArgs& a);                       // 0 none, 1 = 256 x 160, 2 = 128 x 160
+int gemm_wide_launch(GemmArgs a, hipStream_t stream, int variant = 1);
 }  // namespace dfh

@@ -547,7 +547,8 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
   a.ksteps = gemm_count_ksteps(a);
   int tile;
   int split = gemm_pick_split(a, &tile);
-  const bool force_wide = force_tile == kNumTiles + 1;       // microbench: tile id 6 = the 256 x 160 wide kernel
+  // microbench / tests: tile id 6 = the 256 x 160 wide kernel, 7 = its 128 x 160 sibling
+  const int force_wide = force_tile > kNumTiles ? force_tile - kNumTiles : 0;
   if (force_wide) force_tile = 0;
   if (force_tile > 0) { DFH_REQUIRE(force_tile <= kNumTiles, "unknown tile variant"); tile = force_tile - 1; }
   if (force_split > 0) split = force_split;
@@ -569,7 +570,8 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     ProfScope ps(a.ntaps ? PC_CONV3 : PC_LINEAR, 2.0 * a.M * a.N * kreal, abytes + (double)a.N * kreal * 2.0 + obytes, stream);
     const bool wide_ok = split == 1 && a.out_mode == OUT_BF16 && (a.act != ACT_GEGLU || a.N % 160 == 0) && (a.N & 7) == 0 &&
                          (a.ld_out & 7) == 0 && (!a.resid || (a.ld_res & 7) == 0);
-    if (wide_ok && (force_wide || (force_tile == 0 && force_split == 0 && gemm_wide_eligible(a)))) rc = gemm_wide_launch(a, stream);
+    const int wide = !wide_ok ? 0 : (force_wide ? force_wide : ((force_tile == 0 && force_split == 0) ? gemm_wide_pick(a) : 0));
+    if (wide) rc = gemm_wide_launch(a, stream, wide);
     else rc = launch_variant(tile, a, stream);
   }
   if (rc) return rc;

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs a) {
   const unsigned a_off = (wm * TM + fr) * 64 + fslot;
   const unsigned b_off = A_BYTES + (wn * TN + fr) * 64 + fslot;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  static_assert(FM == 8 && FN == 5, "the hand-scheduled k-step is written for 8 x 5 fragments");
+  static_assert((FM == 8 || FM == 4) && FN == 5, "the hand-scheduled k-step is written for {8,4} x 5 fragments");
 
   if (nk > 0) {
     KIterW it = kiterw_at(a, 0);
@@ -199,14 +199,21 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs a) {
                                                             acc[i][j], 0, 0, 0);
 #define WNEXT(rd, off, wt) WRD(rd, sa, off); asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wt));
       // weights as MFMA-A: D[row = channel (fg*4+r)][col = pixel (fr)]
-      WROW(0, a0) WNEXT(a2, 2048, a1)
-      WROW(1, a1) WNEXT(a0, 3072, a2)
-      WROW(2, a2) WNEXT(a1, 4096, a0)
-      WROW(3, a0) WNEXT(a2, 5120, a1)
-      WROW(4, a1) WNEXT(a0, 6144, a2)
-      WROW(5, a2) WNEXT(a1, 7168, a0)
-      WROW(6, a0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1));
-      WROW(7, a1)
+      if constexpr (FM == 8) {
+        WROW(0, a0) WNEXT(a2, 2048, a1)
+        WROW(1, a1) WNEXT(a0, 3072, a2)
+        WROW(2, a2) WNEXT(a1, 4096, a0)
+        WROW(3, a0) WNEXT(a2, 5120, a1)
+        WROW(4, a1) WNEXT(a0, 6144, a2)
+        WROW(5, a2) WNEXT(a1, 7168, a0)
+        WROW(6, a0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1));
+        WROW(7, a1)
+      } else {
+        WROW(0, a0) WNEXT(a2, 2048, a1)
+        WROW(1, a1) WNEXT(a0, 3072, a2)
+        WROW(2, a2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0));
+        WROW(3, a0)
+      }
 #undef WROW
 #undef WNEXT
       __builtin_amdgcn_sched_barrier(0);
@@ -221,10 +228,10 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs a) {
 #pragma unroll
   for (int q = 0; q < BM / 64; ++q) {
     __syncthreads();                               // pipeline buffers / previous pass no longer read
-    if (wm == q / 2) {
+    if (wm == (q * 64) / TM) {
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii) {
-        const int i = (q & 1) * 4 + ii;
+        const int i = ((q * 64) % TM) / 16 + ii;
         const int row = ii * 16 + fr;              // row inside the 64-row pass
 #pragma unroll
         for (int j = 0; j < FN; ++j)
@@ -311,6 +318,18 @@ int gemm_wide_ksteps(const GemmArgs& a) {
 }
 
 // bf16 row-major output, no GEGLU / split-K, 16-byte aligned rows, and enough tiles to give every CU its two workgroups
+// 1 = 256 x 160, 2 = 128 x 160 (same pipeline, for grids the 256-row tile cannot fill), 0 = not eligible
+int gemm_wide_pick(const GemmArgs& a) {
+  if (a.out_mode != OUT_BF16) return 0;
+  if (a.act == ACT_GEGLU && (a.N % 160 != 0 || a.resid || a.rowvec)) return 0;
+  if ((a.N & 7) || (a.ld_out & 7) || (a.resid && (a.ld_res & 7))) return 0;
+  if (a.N % 160 != 0 && a.N < 640) return 0;
+  const long nt = (a.N + 159) / 160;
+  // the 128-row sibling (variant 2) is kept for experiments only: at equal tile size the 64-deep two-stage kernel of
+  // gemm.hip wins (848 vs 724 TFLOP/s on conv 320->320 @64): the gain of this file is the larger tile
+  return (long)((a.M + 255) / 256) * nt >= 448 ? 1 : 0;
+}
+
 bool gemm_wide_eligible(const GemmArgs& a) {
   if (a.out_mode != OUT_BF16) return false;
   if (a.act == ACT_GEGLU && (a.N % 160 != 0 || a.resid || a.rowvec)) return false;
@@ -320,8 +339,8 @@ bool gemm_wide_eligible(const GemmArgs& a) {
   return tiles >= 448;
 }
 
-int gemm_wide_launch(GemmArgs a, hipStream_t s) {
-  constexpr int BM = 256, BN = 160;
+template <int BM, int BN>
+static int wide_launch_t(GemmArgs a, hipStream_t s) {
   constexpr int lds = 3 * (BM + BN) * BKW * 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -333,6 +352,10 @@ int gemm_wide_launch(GemmArgs a, hipStream_t s) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   hipLaunchKernelGGL((gemm_wide_kernel<BM, BN>), dim3(tiles), dim3(256), lds, s, a);
   return check_launch("gemm_wide_kernel");
+}
+
+int gemm_wide_launch(GemmArgs a, hipStream_t s, int variant) {
+  return variant == 2 ? wide_launch_t<128, 160>(a, s) : wide_launch_t<256, 160>(a, s);
 }
 
 }  // namespace dfh

@@ -72,7 +72,7 @@ if __name__ == "__main__":
         ("conv 1280->1280 @8", dict(M=1024, N=1280, K=0, conv=(16, 8, 1280, 1, 0), resid=False)),
     ]
     for name, kw in shapes:
-        for tile, tag in ((0, "auto"), (4, "128x160s2"), (6, "256x160wide")):
+        for tile, tag in ((0, "auto"), (4, "128x160s2"), (6, "256x160wide"), (7, "128x160wide")):
             run(f"{name} [{tag}]", tile=tile, **kw)
     run("geglu 64^2 N2560 [auto]", 65536, 2560, 320, act=4)
     run("geglu 64^2 N2560 [128x128s2]", 65536, 2560, 320, act=4, tile=5)

@@ -523,6 +523,11 @@ int gemm_pick_split(const GemmArgs& a, int* tile_out) {
   if (!geglu && blocks < 160 && ksteps >= 16) {
     split = std::min({(256 + blocks - 1) / blocks, ksteps / 8, 64});
     if (split < 1) split = 1;
+  } else if (!geglu && blocks < 384 && ksteps >= 64) {
+    // about one workgroup per CU (the 16x16 level at batch 16: 256 tiles): a second K-slice doubles the resident waves
+    // and pays for its slab round trip on the deep-K convs (205 -> 149 us, 369 -> 249 us; scripts/gemm_split_probe.py);
+    // the shallow 1x1 / linear shapes lose (29 -> 35 us) and stay single-pass
+    split = 2;
   }
   if (tile_out) *tile_out = tile;
   return split;

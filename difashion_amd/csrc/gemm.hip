@@ -520,14 +520,15 @@ int gemm_pick_split(const GemmArgs& a, int* tile_out) {
   const int blocks = ((a.M + ti.bm - 1) / ti.bm) * ((a.N + ti.bn - 1) / ti.bn);
   const int ksteps = gemm_count_ksteps(a);
   int split = 1;
-  if (!geglu && blocks < 160 && ksteps >= 16) {
+  if (!geglu && blocks < 384 && ksteps >= 64) {
+    // deep-K launches that leave CUs idle or at one workgroup each (16x16 level at batch 16: 256 tiles; 8x8 level: 64-128):
+    // split K until about 512 workgroups are resident.  The slab round trip pays for itself on the 3x3 convs
+    // (M=4096: 205 -> 149 us with 2 slices; M=2048: 111 -> 78 us with 4; scripts/gemm_split_probe*.py)
+    split = std::max(1, std::min((512 + blocks / 2) / blocks, ksteps / 16));
+  } else if (!geglu && blocks < 160 && ksteps >= 16) {
+    // shallow K (1x1 / linear): more than two slices cost more in slab traffic than they win
     split = std::min({(256 + blocks - 1) / blocks, ksteps / 8, 64});
     if (split < 1) split = 1;
-  } else if (!geglu && blocks < 384 && ksteps >= 64) {
-    // about one workgroup per CU (the 16x16 level at batch 16: 256 tiles): a second K-slice doubles the resident waves
-    // and pays for its slab round trip on the deep-K convs (205 -> 149 us, 369 -> 249 us; scripts/gemm_split_probe.py);
-    // the shallow 1x1 / linear shapes lose (29 -> 35 us) and stay single-pass
-    split = 2;
   }
   if (tile_out) *tile_out = tile;
   return split;

@@ -43,6 +43,8 @@ def run(name, M, N, K, conv=None, bias=True, resid=True, out_mode=0, act=0, tile
         r = torch.randn(M, N, device=DEV).bfloat16(); keep.append(r); d.resid, d.ld_res = r.data_ptr(), N
     out = torch.empty(M, n_out, device=DEV, dtype=torch.float32 if out_mode == 2 else torch.bfloat16); keep.append(out)
     d.out, d.ld_out, d.out_mode, d.act = out.data_ptr(), n_out, out_mode, act
+    if out_mode in (1, 3):            # transposed per batch: [b][n][rows_per_b], 16 batches
+        d.rows_per_b, d.ld_out = M // 16, M // 16
     z = torch.zeros(256, dtype=torch.uint8, device=DEV); keep.append(z); d.zero_page = z.data_ptr()
     d.force_tile, d.force_split, d.force_glds = tile, split, glds
     need = _lib.raw().dfh_gemm_partial_floats(C.byref(d))

@@ -88,7 +88,7 @@ SIGNATURES = {
     "dfh_unet_bind_train": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
     "dfh_unet_pack_train": (_i, [_vp, C.POINTER(_vp), _i, _vp]),
     "dfh_unet_forward_train": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
-    "dfh_unet_backward": (_i, [_vp, _vp, _vp, C.POINTER(_vp), _i, _vp]),
+    "dfh_unet_backward": (_i, [_vp, _vp, _vp, C.POINTER(_vp), _i, _i, _vp]),
     "dfh_gemm_partial_floats": (_sz, [C.POINTER(GemmDesc)]),
     "dfh_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "dfh_gemm_wgrad": (_i, [C.POINTER(GemmDesc), _vp, _i, _vp, _i, _i, _vp]),
@@ -119,6 +119,7 @@ SIGNATURES = {
     "dfh_sumsq": (_i, [_vp, _sz, _vp, _vp]),
     "dfh_adamw": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
     "dfh_ema": (_i, [_vp, _vp, _sz, _f, _vp]),
+    "dfh_adamw_ema": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp]),
     "dfh_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "dfh_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "dfh_timestep_embedding": (_i, [_vp, _vp, _i, _i, _vp]),

@@ -254,6 +254,12 @@ int dfh_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, 
               float weight_decay, int step, const float* sumsq, float max_norm, void* stream) {
   return dfh::adamw_launch(p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, step, sumsq, max_norm, (hipStream_t)stream);
 }
+int dfh_adamw_ema(float* p, const float* g, float* m, float* v, float* shadow, size_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, const float* sumsq, float max_norm, float ema_decay, void* stream) {
+  DFH_REQUIRE(shadow != nullptr, "null shadow");
+  return dfh::adamw_launch(p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, step, sumsq, max_norm, (hipStream_t)stream, shadow,
+                           ema_decay);
+}
 int dfh_ema(float* shadow, const float* p, size_t n, float decay, void* stream) {
   return dfh::ema_launch(shadow, p, (long)n, decay, (hipStream_t)stream);
 }

@@ -24,6 +24,6 @@ int mse_bwd_launch(const float* pred, const float* target, const float* w, float
 int assemble_bwd_launch(const float* dx, const unsigned char* mutual_real, float* dmutual, int rows, int CL, float eta, hipStream_t s);
 int sumsq_launch(const float* g, long n, float* out, hipStream_t s);
 int adamw_launch(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
-                 int step, const float* sumsq, float max_norm, hipStream_t s);
+                 int step, const float* sumsq, float max_norm, hipStream_t s, float* shadow = nullptr, float ema_decay = 0.f);
 int ema_launch(float* shadow, const float* p, long n, float decay, hipStream_t s);
 }  // namespace dfh

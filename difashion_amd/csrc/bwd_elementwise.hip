@@ -232,7 +232,7 @@ __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restr
 // read from device memory so the clip needs no host synchronisation
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              long n, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2,
-                             const float* __restrict__ sumsq, float max_norm) {
+                             const float* __restrict__ sumsq, float max_norm, float* __restrict__ shadow, float ema_omd) {
   const long i = gtid();
   if (i >= n) return;
   float clip = 1.0f;
@@ -245,6 +245,10 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
   pi -= (lr / bc1) * (mi / denom);
   p[i] = pi;
+  if (shadow) {                  // diffusers EMAModel.step folded into the same pass: shadow -= (1 - decay) * (shadow - p)
+    const float sh = shadow[i];
+    shadow[i] = sh - ema_omd * (sh - pi);
+  }
 }
 // diffusers EMAModel.step: shadow -= (1 - decay) * (shadow - param)
 __global__ void ema_kernel(float* __restrict__ shadow, const float* __restrict__ p, long n, float one_minus_decay) {
@@ -325,10 +329,10 @@ int sumsq_launch(const float* g, long n, float* out, hipStream_t s) {
   return check_launch("sumsq_kernel");
 }
 int adamw_launch(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
-                 int step, const float* sumsq, float max_norm, hipStream_t s) {
+                 int step, const float* sumsq, float max_norm, hipStream_t s, float* shadow, float ema_decay) {
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
-  ProfScope ps(PC_OPTIM, 0.0, 28.0 * n, s);      // p r+w, g r, m r+w, v r+w
-  EW_LAUNCH(adamw_kernel, n, p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2, sumsq, max_norm);
+  ProfScope ps(PC_OPTIM, 0.0, (shadow ? 36.0 : 28.0) * n, s);      // p r+w, g r, m r+w, v r+w (+ shadow r+w)
+  EW_LAUNCH(adamw_kernel, n, p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2, sumsq, max_norm, shadow, 1.0f - ema_decay);
 }
 int ema_launch(float* shadow, const float* p, long n, float decay, hipStream_t s) {
   ProfScope ps(PC_OPTIM, 0.0, 12.0 * n, s);

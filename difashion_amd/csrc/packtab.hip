@@ -43,16 +43,17 @@ __global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ op
       }
       break;
     }
-    case TAB_UNPACK_VEC: {      // p0 = geglu
+    case TAB_UNPACK_VEC: {      // p0 = geglu, p1 = overwrite
       for (int j = 0; j < TAB_ELEMS_PER_BLOCK / 256; ++j) {
         const long i = blk * TAB_ELEMS_PER_BLOCK + j * 256 + tid;
         if (i >= N) break;
         const int r = op.p0 ? tab_geglu_row((int)i, N) : (int)i;
-        ((float*)op.master)[i] += ((const float*)arena_vec)[op.dst + r];
+        const float gv = ((const float*)arena_vec)[op.dst + r];
+        ((float*)op.master)[i] = op.p1 ? gv : ((float*)op.master)[i] + gv;      // p1 = overwrite
       }
       break;
     }
-    case TAB_PACK_MAT: case TAB_UNPACK_MAT: {        // p0 = row_off, p1 = col_off, p2 = geglu
+    case TAB_PACK_MAT: case TAB_UNPACK_MAT: {        // p0 = row_off, p1 = col_off, p2 = geglu, p3 = overwrite (unpack)
       for (int j = 0; j < TAB_ELEMS_PER_BLOCK / 256; ++j) {
         const long i = blk * TAB_ELEMS_PER_BLOCK + j * 256 + tid;
         if (i >= (long)N * K) break;
@@ -60,11 +61,11 @@ __global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ op
         const int r = op.p2 ? tab_geglu_row(n, N) : n;
         const long at = op.dst + (long)(op.p0 + r) * ld + op.p1 + k;
         if (op.kind == TAB_PACK_MAT) ((bf16_t*)arena_mat)[at] = f2bf(((const float*)op.master)[i]);
-        else ((float*)op.master)[i] += ((const float*)arena_mat)[at];
+        else ((float*)op.master)[i] = op.p3 ? ((const float*)arena_mat)[at] : ((float*)op.master)[i] + ((const float*)arena_mat)[at];
       }
       break;
     }
-    case TAB_PACK_CONV: case TAB_UNPACK_CONV: {      // N = Cout, K = Cin, p1 = col_off, p3 = cin_pad
+    case TAB_PACK_CONV: case TAB_UNPACK_CONV: {      // N = Cout, K = Cin, p1 = col_off, p3 = cin_pad, p0 = overwrite (unpack)
       const long oc = blk * 256 + tid;
       if (oc >= (long)N * K) break;
       const int c = (int)(oc % K), o = (int)(oc / K);
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ op
       } else {
         float* g = (float*)op.master + oc * 9;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) g[t] += ((const float*)arena_mat)[at + t * op.p3];
+        for (int t = 0; t < 9; ++t) g[t] = op.p0 ? ((const float*)arena_mat)[at + t * op.p3] : g[t] + ((const float*)arena_mat)[at + t * op.p3];
       }
       break;
     }

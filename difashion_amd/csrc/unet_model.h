@@ -125,7 +125,7 @@ struct dfh_unet {
   size_t plan_train(int B);
   int forward_train(const void* sample, int sample_bf16, const float* timestep, const void* ehs, int ehs_bf16, float* out, int B,
                     hipStream_t s);
-  int backward(const float* d_out, float* d_sample, float* const* master_grads, int count, hipStream_t s);
+  int backward(const float* d_out, float* d_sample, float* const* master_grads, int count, hipStream_t s, int overwrite);
   int pack_train(const float* const* master, int count, hipStream_t s);
   ~dfh_unet();
 

@@ -100,6 +100,7 @@ struct dfh_unet::TrainRun {
     w.dY = dY; w.ldy = ldy; w.zero = zero; w.M = f.M; w.N = f.N;
     w.dW = u->grad16 + w_off; w.ldw = f.ldw; w.msplit = 0;
     w.dbias = bias ? g32(*bias) : nullptr;
+    w.overwrite = 1;          // every packed matrix has exactly one weight-gradient launch per backward: no memset, no RMW
     w.partial = partial; w.partial_cap = partial_cap / sizeof(float);     // shares the split-K slab region of the GEMMs
     if (dry) { partial_need = std::max(partial_need, dfh::wgrad_partial_floats(w) * sizeof(float)); return; }
     rc = dfh::wgrad_launch(w, s);
@@ -567,14 +568,13 @@ int dfh_unet::forward_train(const void* sample, int sample_bf16, const float* ti
   return r.rc;
 }
 
-int dfh_unet::backward(const float* d_out, float* d_sample, float* const* master_grads, int count, hipStream_t s) {
+int dfh_unet::backward(const float* d_out, float* d_sample, float* const* master_grads, int count, hipStream_t s, int overwrite) {
   DFH_REQUIRE(tr != nullptr && !tr->tape.empty(), "dfh_unet_backward needs a preceding dfh_unet_forward_train");
   DFH_REQUIRE(count == (int)params.size(), "parameter count mismatch");
   TrainRun& r = *tr;
   r.s = s; r.d_out = d_out; r.d_sample = d_sample;
   std::fill(r.gstate.begin(), r.gstate.end(), 0);
-  (void)hipMemsetAsync(grad16, 0, a16 * sizeof(float), s);
-  (void)hipMemsetAsync(grad32, 0, a32 * sizeof(float), s);
+  (void)hipMemsetAsync(grad32, 0, a32 * sizeof(float), s);     // bias / affine gradients accumulate with atomics
   (void)hipMemsetAsync(r.dtemb_all, 0, r.dtemb_bytes, s);
   for (auto it = r.tape.rbegin(); it != r.tape.rend() && !r.rc; ++it) (*it)();
   r.tape.clear();           // one backward per forward
@@ -584,9 +584,10 @@ int dfh_unet::backward(const float* d_out, float* d_sample, float* const* master
   for (const PackOp& op : packs) {
     float* g = master_grads ? master_grads[op.param] : nullptr;
     if (!g) continue;
-    if (op.kind == PK_VEC) tab_unpack.add(g, TAB_UNPACK_VEC, (long)op.dst, op.N, 0, 0, op.geglu, 0, 0, 0, op.N);
-    else if (op.kind == PK_MAT) tab_unpack.add(g, TAB_UNPACK_MAT, (long)op.dst, op.N, op.K, op.ldw, op.row_off, op.col_off, op.geglu, 0, (long)op.N * op.K);
-    else tab_unpack.add(g, TAB_UNPACK_CONV, (long)op.dst, op.N, op.K, op.ldw, 0, op.col_off, 0, op.cin_pad, (long)op.N * op.K * 9);
+    // overwrite: the caller states that the gradients hold nothing yet (first micro-batch after zero_grad): plain stores
+    if (op.kind == PK_VEC) tab_unpack.add(g, TAB_UNPACK_VEC, (long)op.dst, op.N, 0, 0, op.geglu, overwrite, 0, 0, op.N);
+    else if (op.kind == PK_MAT) tab_unpack.add(g, TAB_UNPACK_MAT, (long)op.dst, op.N, op.K, op.ldw, op.row_off, op.col_off, op.geglu, overwrite, (long)op.N * op.K);
+    else tab_unpack.add(g, TAB_UNPACK_CONV, (long)op.dst, op.N, op.K, op.ldw, overwrite, op.col_off, 0, op.cin_pad, (long)op.N * op.K * 9);
   }
   return tab_unpack.launch(grad32, grad16, s);
 }
@@ -641,9 +642,10 @@ int dfh_unet_forward_train(dfh_unet* u, const void* sample, int sample_bf16, con
   return u->forward_train(sample, sample_bf16, timestep, ehs, ehs_bf16, out, batch, (hipStream_t)stream);
 }
 
-int dfh_unet_backward(dfh_unet* u, const float* d_out, float* d_sample, float* const* master_grads, int count, void* stream) {
+int dfh_unet_backward(dfh_unet* u, const float* d_out, float* d_sample, float* const* master_grads, int count, int overwrite,
+                      void* stream) {
   DFH_REQUIRE(u && d_out, "null argument");
-  return u->backward(d_out, d_sample, master_grads, count, (hipStream_t)stream);
+  return u->backward(d_out, d_sample, master_grads, count, (hipStream_t)stream, overwrite ? 1 : 0);
 }
 
 }  // extern "C"

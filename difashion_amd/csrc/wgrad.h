@@ -13,6 +13,7 @@ struct WgradArgs {
   float* dW; int ldw;            // fp32 [N][ldw] in the PACKED weight layout, accumulated (+=)
   float* partial; size_t partial_cap;   // fp32 slabs [msplit][N][ktot] when the pixels are split (wgrad_partial_floats)
   int ktot;                      // filled by the launcher: total K of the call
+  int overwrite;                 // 1: dW = ... instead of += (the caller guarantees this launch is the only writer)
   float* dbias;                  // optional fp32 [N]: += column sums of dY (bias gradient), fused into the same pass
   int msplit;                    // 0 = heuristic
   int xblocks;                   // filled by the launcher: n-tiles x kcol-chunks

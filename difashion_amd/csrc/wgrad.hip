@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradArgs a) {
         *(float4*)(a.partial + ((long)bz * a.N + n) * a.ktot + wcol + kcol) = v;
       } else {
         float4* dst = (float4*)(a.dW + (long)n * a.ldw + wcol + kcol);
+        if (a.overwrite) { *dst = v; continue; }
         float4 o = *dst;
         o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
         *dst = o;
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradArgs a) {
 
 // dW[n][k] += sum_z slab[z][n][k]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int N, int ktot,
-                                                           int ldw, int msplit) {
+                                                           int ldw, int msplit, int overwrite) {
   const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const long total = (long)N * ktot;
   if (i >= total) return;
@@ -264,6 +265,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
   }
   float4* dst = (float4*)(dW + (long)n * ldw + k);
+  if (overwrite) { *dst = s; return; }
   float4 o = *dst;
   o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
   *dst = o;
@@ -369,7 +371,7 @@ int wgrad_launch(WgradArgs a, hipStream_t s) {
   if (a.msplit > 1) {
     const long quads = (long)a.N * a.ktot / 4;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a.partial, a.dW, a.N, a.ktot, a.ldw,
-                       a.msplit);
+                       a.msplit, a.overwrite);
     return check_launch("wgrad_reduce_kernel");
   }
   return 0;

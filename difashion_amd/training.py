@@ -68,8 +68,30 @@ class FusedAdamW(torch.optim.Optimizer):
         self._step = 0
 
     # the gradient views are permanent: zero_grad never drops them (the native backward accumulates in place)
-    def zero_grad(self, set_to_none: bool = False):
-        self.flat_grad.zero_()
+    def zero_grad(self, set_to_none: bool = False, lazy_modules=()):
+        """``lazy_modules``: modules whose native backward can OVERWRITE its gradients (UNet2DConditionModel): their slices
+        are not zero-filled here, the module is told that its gradient views hold stale values (``grads_cleared``) and the
+        next backward stores instead of accumulating -- 3.4 GB less memset and 3.4 GB less read-modify-write per step."""
+        lazy = set()
+        for mod in lazy_modules:
+            if all(p.grad is not None and id(p) in self._slices for p in mod.parameters() if p.requires_grad):
+                lazy.update(id(p) for p in mod.parameters())
+                mod.grads_cleared = True
+        if not lazy:
+            self.flat_grad.zero_()
+        else:
+            run = None                      # maximal runs of non-lazy parameters
+            for g in self.param_groups:
+                for p in g["params"]:
+                    off, n = self._slices[id(p)]
+                    if id(p) in lazy:
+                        if run:
+                            self.flat_grad[run[0]:run[1]].zero_()
+                            run = None
+                    else:
+                        run = (run[0] if run else off, off + _align(n))
+            if run:
+                self.flat_grad[run[0]:run[1]].zero_()
         for g in self.param_groups:
             for p in g["params"]:
                 if p.requires_grad and (p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * self._slices[id(p)][0]):
@@ -81,8 +103,20 @@ class FusedAdamW(torch.optim.Optimizer):
         return self._sumsq.sqrt()[0]
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, ema: Optional["EMAModel"] = None):
+        """``ema``: an EMAModel over a prefix of this optimizer's parameters (same order): its update is folded into the
+        AdamW launch for that range (the caller must then NOT call ema.step())."""
         loss = closure() if closure is not None else None
+        ema_end, ema_decay = 0, 0.0
+        if ema is not None:
+            plist = [p for g in self.param_groups for p in g["params"]][:len(ema._sizes)]
+            if (ema.flat.device == self.flat_param.device and [p.numel() for p in plist] == ema._sizes
+                    and all(p.requires_grad for p in plist)):
+                ema.optimization_step += 1
+                ema_decay = ema.get_decay(ema.optimization_step)
+                ema_end = ema.flat.numel()
+            else:
+                raise _lib.DfhError("FusedAdamW.step(ema=...): the EMA must cover a prefix of the optimizer's parameters")
         s = _lib.stream_ptr()
         self._step += 1
         n = self.flat_grad.numel()
@@ -93,10 +127,17 @@ class FusedAdamW(torch.optim.Optimizer):
             if b == a:
                 continue
             b1, b2 = g["betas"]
-            _lib.call("dfh_adamw", self.flat_param.data_ptr() + 4 * a, self.flat_grad.data_ptr() + 4 * a,
-                      self.exp_avg.data_ptr() + 4 * a, self.exp_avg_sq.data_ptr() + 4 * a, b - a, float(g["lr"]), float(b1),
-                      float(b2), float(g["eps"]), float(g["weight_decay"]), self._step,
-                      _lib.ptr(self._sumsq) if clip else None, float(self.max_grad_norm or 0.0), s)
+            hyper = (float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), self._step,
+                     _lib.ptr(self._sumsq) if clip else None, float(self.max_grad_norm or 0.0))
+            fe = min(b, ema_end)                   # [a, fe): fused with the EMA update, [fe, b): plain
+            if fe > a:
+                _lib.call("dfh_adamw_ema", self.flat_param.data_ptr() + 4 * a, self.flat_grad.data_ptr() + 4 * a,
+                          self.exp_avg.data_ptr() + 4 * a, self.exp_avg_sq.data_ptr() + 4 * a, ema.flat.data_ptr() + 4 * a,
+                          fe - a, *hyper, float(ema_decay), s)
+            lo = max(a, fe)
+            if b > lo:
+                _lib.call("dfh_adamw", self.flat_param.data_ptr() + 4 * lo, self.flat_grad.data_ptr() + 4 * lo,
+                          self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo, b - lo, *hyper, s)
         _lib.bump_weight_epoch()          # packed bf16 copies of these weights are stale now
         return loss
 
@@ -267,11 +308,15 @@ def train_step(unet, fashion_encoder, scheduler, optimizer: FusedAdamW, *, lr_sc
     loss = train_forward(unet, fashion_encoder, scheduler, **batch)
     loss.backward()
     _dist.all_reduce_gradients(optimizer.flat_grad)
-    optimizer.step()
+    # EMA of the U-Net folded into the AdamW launch when it covers the head of the flat parameter buffer
+    first = next(iter(unet.parameters()))
+    fuse_ema = (ema_unet is not None and ema_unet.flat.device.type == "cuda"
+                and first.data_ptr() == optimizer.flat_param.data_ptr() and all(p.requires_grad for p in unet.parameters()))
+    optimizer.step(ema=ema_unet if fuse_ema else None)
     if lr_scheduler is not None:
         lr_scheduler.step()
-    optimizer.zero_grad()
-    if ema_unet is not None:
+    optimizer.zero_grad(lazy_modules=(unet,))
+    if ema_unet is not None and not fuse_ema:
         ema_unet.step(unet.parameters())
     if ema_encoder is not None:
         ema_encoder.step(fashion_encoder.parameters())

@@ -120,8 +120,10 @@ int dfh_unet_forward_train(dfh_unet* u, const void* sample, int sample_bf16, con
  *   d_sample     : [B][in_channels][H][W] fp32 or NULL (gradient wrt the assembled input -> MutualEncoder)
  *   master_grads : table-order device pointers to the fp32 .grad of each parameter; gradients are ADDED
  *                  (entries may be NULL to skip a frozen parameter).  encoder_hidden_states gets no gradient
- *                  (frozen CLIP text states, df.py:229-247). */
-int dfh_unet_backward(dfh_unet* u, const float* d_out, float* d_sample, float* const* master_grads, int count,
+ *                  (frozen CLIP text states, df.py:229-247).
+ *   overwrite    : 1 = the gradients hold nothing yet (first backward after zero_grad): they are STORED, which saves
+ *                  zero-filling and re-reading 3.4 GB; 0 = added (gradient accumulation over micro-batches). */
+int dfh_unet_backward(dfh_unet* u, const float* d_out, float* d_sample, float* const* master_grads, int count, int overwrite,
                       void* stream);
 
 /* Copies a named NHWC bf16 intermediate of the LAST forward into ``dst`` as fp32 NCHW (layer-level
@@ -222,6 +224,9 @@ int dfh_assemble_bwd(const float* dx, const uint8_t* mutual_real, float* dmutual
 int dfh_sumsq(const float* g, size_t n, float* out, void* stream);
 int dfh_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
               float weight_decay, int step, const float* sumsq, float max_norm, void* stream);
+/* dfh_adamw with the EMA update of the same elements folded in (one pass over the parameters instead of two) */
+int dfh_adamw_ema(float* p, const float* g, float* m, float* v, float* shadow, size_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, const float* sumsq, float max_norm, float ema_decay, void* stream);
 int dfh_ema(float* shadow, const float* p, size_t n, float decay, void* stream);
 
 /* ------------------------------------------------------------------ DiFashion glue (reference-owned arithmetic)

@@ -241,3 +241,50 @@ def test_training_loop_reduces_the_loss_on_a_fixed_batch():
     print("losses", [f"{v:.4f}" for v in losses])
     assert losses[-1] < 0.8 * losses[0] and all(np.isfinite(losses))
     assert float(opt.grad_norm()) > 0
+
+
+def test_adamw_with_folded_ema_equals_separate_updates():
+    torch.manual_seed(2)
+    shapes = [(40, 24), (130,), (7, 9)]
+    ps = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt_a, opt_b = da.FusedAdamW(ps, lr=1e-2, max_grad_norm=1.0), da.FusedAdamW(qs, lr=1e-2, max_grad_norm=1.0)
+    ema_a, ema_b = da.EMAModel(ps[:2], decay=0.9), da.EMAModel(qs[:2], decay=0.9)      # a prefix of the parameters
+    for it in range(4):
+        for p, q in zip(ps, qs):
+            g = torch.randn_like(p)
+            p.grad.copy_(g)
+            q.grad.copy_(g)
+        opt_a.step(ema=ema_a)          # one launch for the covered range
+        opt_b.step()
+        ema_b.step(qs[:2])
+        for p, q in zip(ps, qs):
+            assert torch.equal(p.data, q.data)
+        for a, b in zip(ema_a.shadow_params, ema_b.shadow_params):
+            torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+    assert ema_a.optimization_step == ema_b.optimization_step == 4
+
+
+def test_lazy_zero_grad_overwrites_instead_of_accumulating():
+    """train_step's fast path: zero_grad(lazy_modules=[unet]) leaves stale values in the U-Net gradient views and the next
+    native backward stores over them; the result must equal a backward into zero-filled gradients."""
+    cfg = unet_ref.TINY
+    m = hip_unet(cfg, unet_ref.init_params(cfg, seed=4, w_std=0.05)).train()
+    opt = da.FusedAdamW(list(m.parameters()), lr=0.0)
+    x, e = inputs(cfg, 2, 12)
+    x, e = x.to(DEV), e.to(DEV)
+    t = torch.tensor([10, 700], device=DEV)
+    dout = torch.randn(2, cfg.out_channels, cfg.sample_size, cfg.sample_size, device=DEV)
+    m(x, t, e).sample.backward(dout)
+    ref = opt.flat_grad.clone()
+    opt.flat_grad.fill_(123.0)                      # stale garbage
+    opt.zero_grad(lazy_modules=(m,))
+    assert m.grads_cleared and float(opt.flat_grad.max()) == 123.0      # nothing was memset
+    m(x, t, e).sample.backward(dout)
+    assert not m.grads_cleared
+    live = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    want = torch.cat([ref[opt._slices[id(p)][0]:opt._slices[id(p)][0] + p.numel()] for p in m.parameters()])
+    assert rel_err(live, want) < 1e-3
+    m(x, t, e).sample.backward(dout)                # not cleared any more: accumulates
+    live2 = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    assert rel_err(live2, 2 * want) < 1e-3

@@ -240,7 +240,7 @@ def main():
         gemm = {k: sum(classes[c][k] for c in ("gemm_conv3x3", "gemm_linear")) for k in ("launches", "ms", "flops", "bytes")}
         achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic()
-        roofline = dict(bound="mfma", kernel="gemm_bf16_kernel (conv3x3 + 1x1 + linear, implicit GEMM)",
+        roofline = dict(bound="mfma", kernel="gemm_bf16_kernel + gemm_wide_kernel (conv3x3 + 1x1 + linear: one implicit GEMM, all tile variants)",
                         achieved=round(achieved, 1), peak=MFMA_BF16_PEAK, unit="TFLOP/s", frac=round(achieved / MFMA_BF16_PEAK, 4),
                         traffic=traffic, traffic_unit="HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", traffic_source=traffic_src,
                         algorithmic_bytes_per_launch=round(gemm["bytes"] / max(1, gemm["launches"])),

@@ -258,10 +258,10 @@ def test_adamw_with_folded_ema_equals_separate_updates():
         opt_a.step(ema=ema_a)          # one launch for the covered range
         opt_b.step()
         ema_b.step(qs[:2])
-        for p, q in zip(ps, qs):
-            assert torch.equal(p.data, q.data)
+        for p, q in zip(ps, qs):     # not bit-equal: the clip norm is reduced with fp32 atomics (order varies run to run)
+            torch.testing.assert_close(p.data, q.data, rtol=1e-5, atol=1e-7)
         for a, b in zip(ema_a.shadow_params, ema_b.shadow_params):
-            torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
     assert ema_a.optimization_step == ema_b.optimization_step == 4
 
 

@@ -29,6 +29,7 @@ struct GemmArgs {
   int M, N;
   int ksteps;      // total 64-deep k-steps over all segments
   int ksplit;      // grid.z; each z handles a contiguous range of k-steps
+  int n_major;     // tile ids enumerate column tiles slowest (set by the launcher when the weights outweigh the pixels)
   // --- epilogue:  v = acc + bias[n] + rowvec[m / rows_per_b][rv_off + n];  v = act(v);  v += resid[m][n]
   const float* bias;
   const float* rowvec; int rv_ld; int rv_off; int rows_per_b;

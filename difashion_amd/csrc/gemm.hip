@@ -90,9 +90,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a
 
   const int ntn = (a.N + BN - 1) / BN;
   const int ntm = (a.M + BM - 1) / BM;
+  // xcd_remap hands each XCD (own L2) a contiguous range of tile ids.  Which operand should that range share?
+  // m-major ids (default): an XCD owns a few pixel tiles x ALL column tiles -> it streams every weight row once per
+  // group of pixel tiles: fine while the activations are the big operand (64x64 / 32x32 levels).  At the deep levels the
+  // WEIGHTS are the big operand (1280 x 11520 bf16 = 29 MB against 10 MB of pixels): n-major ids give an XCD whole column
+  // tiles, so each weight row is fetched by one XCD only (a.n_major, set by the launcher).
   const int tile = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (tile / ntn) * BM;
-  const int n0 = (tile % ntn) * BN;
+  const int m0 = (a.n_major ? tile % ntm : tile / ntn) * BM;
+  const int n0 = (a.n_major ? tile / ntm : tile % ntn) * BN;
 
   // k-step range of this split
   const int per = (a.ksteps + a.ksplit - 1) / a.ksplit;
@@ -565,6 +570,14 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
   }
   split = std::min(split, a.ksteps);
   a.ksplit = split;
+  {
+    double kk = (double)a.ntaps * a.conv_c;
+    for (int i = 0; i < a.nplain; ++i) kk += a.p_c[i];
+    const double w_bytes = (double)a.N * kk, a_bytes = (double)a.M * (a.ntaps ? (double)a.conv_c : kk);
+    // measured (scripts/gemm_nmajor_probe.py): +12 % / +6 % on the 16x16-level 3x3 convs, -4 % on the linear shapes -> convs only
+    a.n_major = (force_glds == 2 || (force_glds < 0 && a.ntaps && w_bytes > a_bytes && a.N > 160)) ? 1 : 0;   // force_glds 2 / 3 pin it (probe)
+    if (force_glds == 3) a.n_major = 0;
+  }
   if (split > 1) DFH_REQUIRE(a.partial != nullptr, "split-K needs a partial buffer");
   int rc;
   {

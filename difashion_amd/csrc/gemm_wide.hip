@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs a) {
 
   const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
   const int tile = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+  const int m0 = (a.n_major ? tile % ntm : tile / ntn) * BM, n0 = (a.n_major ? tile / ntm : tile % ntn) * BN;   // see gemm.hip
   const int nk = a.ksteps;                           // 32-deep steps (filled by the launcher)
 
   // staging geometry: piece p = i*4 + wave holds tile rows p*16 + lane/4; the LDS image is lane-linear, the SOURCE

@@ -525,7 +525,7 @@ int gemm_pick_split(const GemmArgs& a, int* tile_out) {
   const int blocks = ((a.M + ti.bm - 1) / ti.bm) * ((a.N + ti.bn - 1) / ti.bn);
   const int ksteps = gemm_count_ksteps(a);
   int split = 1;
-  if (!geglu && blocks < 384 && ksteps >= 64) {
+  if (!geglu && blocks < 384 && ksteps >= (a.ntaps ? 64 : 160)) {     // plain K = 5120 (80 k-steps) loses: 67 -> 72 us
     // deep-K launches that leave CUs idle or at one workgroup each (16x16 level at batch 16: 256 tiles; 8x8 level: 64-128):
     // split K until about 512 workgroups are resident.  The slab round trip pays for itself on the 3x3 convs
     // (M=4096: 205 -> 149 us with 2 slices; M=2048: 111 -> 78 us with 4; scripts/gemm_split_probe*.py)

@@ -43,9 +43,20 @@ DFH_DEVICE int seg_len(const GemmArgs& a, int seg) {
   return seg < a.ntaps ? a.conv_c : (seg == a.ntaps ? a.p_c[0] : a.p_c[1]);
 }
 
+// K is walked CHANNEL-CHUNK-major over the conv taps: the nine taps of one 64-channel slice are consecutive k-steps, so
+// the shifted re-reads of a pixel tile (eight of nine taps touch rows the previous taps already fetched) come back within
+// ~1 MB of L2 traffic per XCD instead of after the whole tile x all channels (10 MB at the 64x64 level: they missed).
+// W columns stay tap-major (column = tap * Cin + c): any k order works as long as A slice and W column agree.
 DFH_DEVICE KIter kiter_at(const GemmArgs& a, int kstep) {
   KIter it;
-  int seg = 0, base = 0;
+  const int conv_steps = a.ntaps * cdiv64(a.conv_c);
+  if (kstep < conv_steps) {
+    const int cc = kstep / a.ntaps;
+    it.seg = kstep - cc * a.ntaps; it.c0 = cc * BK; it.seglen = a.conv_c; it.wcol = it.seg * a.conv_c + it.c0;
+    return it;
+  }
+  kstep -= conv_steps;
+  int seg = a.ntaps, base = a.ntaps * a.conv_c;
   const int nseg = a.ntaps + a.nplain;
   for (;;) {
     const int len = seg_len(a, seg);
@@ -58,6 +69,15 @@ DFH_DEVICE KIter kiter_at(const GemmArgs& a, int kstep) {
 }
 
 DFH_DEVICE void kiter_next(const GemmArgs& a, KIter& it) {
+  if (it.seg < a.ntaps) {                  // inside the conv part: next tap of the same channel slice
+    ++it.seg; it.wcol += a.conv_c;
+    if (it.seg < a.ntaps) return;
+    it.seg = 0; it.c0 += BK; it.wcol = it.c0;
+    if (it.c0 < a.conv_c) return;
+    it.seg = a.ntaps; it.c0 = 0; it.wcol = a.ntaps * a.conv_c;     // conv part done: first plain segment
+    if (a.nplain > 0) it.seglen = seg_len(a, it.seg);
+    return;
+  }
   it.c0 += BK; it.wcol += BK;
   if (it.c0 >= it.seglen) {
     it.wcol -= it.c0 - it.seglen;        // next segment starts right after this one's real length
@@ -529,7 +549,8 @@ int gemm_pick_split(const GemmArgs& a, int* tile_out) {
     // deep-K launches that leave CUs idle or at one workgroup each (16x16 level at batch 16: 256 tiles; 8x8 level: 64-128):
     // split K until about 512 workgroups are resident.  The slab round trip pays for itself on the 3x3 convs
     // (M=4096: 205 -> 149 us with 2 slices; M=2048: 111 -> 78 us with 4; scripts/gemm_split_probe*.py)
-    split = std::max(1, std::min((512 + blocks / 2) / blocks, ksteps / 16));
+    const int target = ti.bm == 256 ? 256 : 512;        // the 8-wave 256-row tiles run one workgroup per CU
+    split = std::max(1, std::min((target + blocks / 2) / blocks, ksteps / 16));
   } else if (!geglu && blocks < 160 && ksteps >= 16) {
     // shallow K (1x1 / linear): more than two slices cost more in slab traffic than they win
     split = std::min({(256 + blocks - 1) / blocks, ksteps / 8, 64});

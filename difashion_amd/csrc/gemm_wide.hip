@@ -26,9 +26,17 @@ struct KIterW { int seg, c0, wcol, seglen; };
 DFH_DEVICE int seg_len_w(const GemmArgs& a, int seg) {
   return seg < a.ntaps ? a.conv_c : (seg == a.ntaps ? a.p_c[0] : a.p_c[1]);
 }
+// channel-chunk-major over the conv taps, see gemm.hip
 DFH_DEVICE KIterW kiterw_at(const GemmArgs& a, int kstep) {
   KIterW it;
-  int seg = 0, base = 0;
+  const int conv_steps = a.ntaps * ((a.conv_c + BKW - 1) / BKW);
+  if (kstep < conv_steps) {
+    const int cc = kstep / a.ntaps;
+    it.seg = kstep - cc * a.ntaps; it.c0 = cc * BKW; it.seglen = a.conv_c; it.wcol = it.seg * a.conv_c + it.c0;
+    return it;
+  }
+  kstep -= conv_steps;
+  int seg = a.ntaps, base = a.ntaps * a.conv_c;
   const int nseg = a.ntaps + a.nplain;
   for (;;) {
     const int len = seg_len_w(a, seg);
@@ -40,6 +48,15 @@ DFH_DEVICE KIterW kiterw_at(const GemmArgs& a, int kstep) {
   return it;
 }
 DFH_DEVICE void kiterw_next(const GemmArgs& a, KIterW& it) {
+  if (it.seg < a.ntaps) {
+    ++it.seg; it.wcol += a.conv_c;
+    if (it.seg < a.ntaps) return;
+    it.seg = 0; it.c0 += BKW; it.wcol = it.c0;
+    if (it.c0 < a.conv_c) return;
+    it.seg = a.ntaps; it.c0 = 0; it.wcol = a.ntaps * a.conv_c;
+    if (a.nplain > 0) it.seglen = seg_len_w(a, it.seg);
+    return;
+  }
   it.c0 += BKW; it.wcol += BKW;
   if (it.c0 >= it.seglen) {
     it.wcol -= it.c0 - it.seglen;

@@ -68,14 +68,16 @@ template <int N> DFH_DEVICE void ww_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)"
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 #define WRD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs a) {
-  constexpr int NWV = 4, WN = 2;
-  constexpr int TM = BM / 2, TN = BN / 2;            // per-wave output tile
+// WN = 2: four waves (2 x 2), two workgroups per CU, 3 stages.  WN = 4: eight waves (2 x 4) on a 256 x 320 tile, ONE workgroup
+// per CU, 4 stages (144 KB): 142 flop per staged byte.
+template <int BM, int BN, int WN, int NSTAGE>
+__global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(const GemmArgs a) {
+  constexpr int NWV = 2 * WN;
+  constexpr int TM = BM / 2, TN = BN / WN;           // per-wave output tile
   constexpr int FM = TM / 16, FN = TN / 16;
   constexpr int PA = BM / 16, PB = BN / 16;          // 1-KiB staging pieces (16 rows x 64 B) per stage
   constexpr int IA = PA / NWV, IB = (PB + NWV - 1) / NWV;
-  constexpr int A_BYTES = BM * BKW * 2, B_BYTES = BN * BKW * 2, STAGE = A_BYTES + B_BYTES, NSTAGE = 3;
+  constexpr int A_BYTES = BM * BKW * 2, B_BYTES = BN * BKW * 2, STAGE = A_BYTES + B_BYTES;
   static_assert(PA % NWV == 0 && TM % 16 == 0 && TN % 16 == 0, "tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -191,7 +193,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs a) {
       const int ahead = issued - 1 - t;
       if (ahead == 0) ww_vmcnt<0>();
       else if (ahead == 1) { if (hi_wave) ww_vmcnt<N_HI>(); else ww_vmcnt<N_LO>(); }
-      else { if (hi_wave) ww_vmcnt<2 * N_HI>(); else ww_vmcnt<2 * N_LO>(); }
+      else if (ahead == 2 || NSTAGE == 3) { if (hi_wave) ww_vmcnt<2 * N_HI>(); else ww_vmcnt<2 * N_LO>(); }
+      else { if (hi_wave) ww_vmcnt<3 * N_HI>(); else ww_vmcnt<3 * N_LO>(); }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs a) {
     if (a.act == ACT_GEGLU) {
       // packed columns come in 32-blocks (16 values | 16 gates): out[m][16 k + i] = (v_i + bv_i) * gelu(g_i + bg_i)
       constexpr int GPR = BN / 16;                 // 8-output chunks per row: two per 32-block
-      for (int c = tid; c < 64 * GPR; c += 256) {
+      for (int c = tid; c < 64 * GPR; c += NWV * 64) {
         const int row = c / GPR, gc = c - row * GPR;
         const int colv = (gc >> 1) * 32 + (gc & 1) * 8;        // value columns of this chunk; gates at +16
         const int m = m0 + q * 64 + row, n = n0 + colv;
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const GemmArgs a) {
       }
       continue;
     }
-    for (int c = tid; c < 64 * CPR; c += 256) {
+    for (int c = tid; c < 64 * CPR; c += NWV * 64) {
       const int row = c / CPR, cchunk = c - row * CPR;
       const int m = m0 + q * 64 + row, n = n0 + cchunk * 8;
       if (m >= a.M || n >= a.N) continue;
@@ -356,23 +359,24 @@ bool gemm_wide_eligible(const GemmArgs& a) {
   return tiles >= 448;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WN, int NSTAGE>
 static int wide_launch_t(GemmArgs a, hipStream_t s) {
-  constexpr int lds = 3 * (BM + BN) * BKW * 2;
+  constexpr int lds = NSTAGE * (BM + BN) * BKW * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<BM, BN, WN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   a.ksteps = gemm_wide_ksteps(a);
   a.ksplit = 1;
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_wide_kernel<BM, BN>), dim3(tiles), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((gemm_wide_kernel<BM, BN, WN, NSTAGE>), dim3(tiles), dim3(WN * 128), lds, s, a);
   return check_launch("gemm_wide_kernel");
 }
 
 int gemm_wide_launch(GemmArgs a, hipStream_t s, int variant) {
-  return variant == 2 ? wide_launch_t<128, 160>(a, s) : wide_launch_t<256, 160>(a, s);
+  if (variant == 3) return wide_launch_t<256, 320, 4, 4>(a, s);
+  return variant == 2 ? wide_launch_t<128, 160, 2, 3>(a, s) : wide_launch_t<256, 160, 2, 3>(a, s);
 }
 
 }  // namespace dfh

@@ -22,19 +22,22 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters * 1e3   # us
 
 
-def run(name, M, N, K, conv=None, bias=True, resid=True, out_mode=0, act=0, tile=0, split=0, glds=-1):
+def run(name, M, N, K, conv=None, bias=True, resid=True, out_mode=0, act=0, tile=0, split=0, glds=-1, zeros=False):
     d = _lib.GemmDesc()
     keep = []
     if conv:
         B, H, cin, stride, ups = conv
         x = torch.randn(B, H, H, cin, device=DEV).bfloat16(); keep.append(x)
+        if zeros: x.zero_()
         d.conv_src, d.conv_c, d.conv, d.batch, d.Hin, d.Win, d.stride, d.upsample = x.data_ptr(), cin, 1, B, H, H, stride, ups
         Kt = 9 * cin
     else:
         a = torch.randn(M, K, device=DEV).bfloat16(); keep.append(a)
+        if zeros: a.zero_()
         d.a0, d.a0_c = a.data_ptr(), K
         Kt = K
     w = (torch.randn(N, Kt, device=DEV) * 0.05).bfloat16(); keep.append(w)
+    if zeros: w.zero_()
     d.W, d.ldw, d.M, d.N = w.data_ptr(), Kt, M, N
     if bias:
         b = torch.randn(N, device=DEV); keep.append(b); d.bias = b.data_ptr()
@@ -74,7 +77,7 @@ if __name__ == "__main__":
         ("conv 1280->1280 @8", dict(M=1024, N=1280, K=0, conv=(16, 8, 1280, 1, 0), resid=False)),
     ]
     for name, kw in shapes:
-        for tile, tag in ((0, "auto"), (4, "128x160s2"), (6, "256x160wide"), (7, "128x160wide")):
+        for tile, tag in ((0, "auto"), (4, "128x160s2"), (6, "256x160wide"), (8, "256x320x8w")):
             run(f"{name} [{tag}]", tile=tile, **kw)
     run("geglu 64^2 N2560 [auto]", 65536, 2560, 320, act=4)
     run("geglu 64^2 N2560 [128x128s2]", 65536, 2560, 320, act=4, tile=5)

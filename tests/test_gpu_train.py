@@ -288,3 +288,40 @@ def test_lazy_zero_grad_overwrites_instead_of_accumulating():
     m(x, t, e).sample.backward(dout)                # not cleared any more: accumulates
     live2 = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
     assert rel_err(live2, 2 * want) < 1e-3
+
+
+@pytest.mark.timeout(1500)
+def test_sd15_full_size_backward_matches_oracle_autograd():
+    """SD-1.5 shape (859.5 M parameters), B = 2 items: every parameter gradient and d loss / d sample of the HIP backward
+    against torch autograd through the fp32 oracle on the host (this exercises the C = 1280 levels, the d = 40 / 80 / 160
+    attention backward and the 160-wide weight-gradient tiles at their real sizes)."""
+    cfg = unet_ref.SD15
+    params = unet_ref.init_params(cfg, seed=0)
+    x, e = inputs(cfg, 2, 123)
+    t = torch.tensor([481, 37])
+    g = torch.Generator().manual_seed(9)
+    dout = torch.randn(2, cfg.out_channels, cfg.sample_size, cfg.sample_size, generator=g)
+    ref_out, ref_g, ref_dx = oracle_grads(cfg, params, x, t, e, dout)
+    m = hip_unet(cfg, params, max_batch=2).train()
+    del params
+    xd = x.to(DEV).requires_grad_(True)
+    out = m(xd, t.to(DEV), e.to(DEV)).sample
+    out.backward(dout.to(DEV))
+    torch.cuda.synchronize()
+    assert rel_err(out.detach().cpu(), ref_out) <= 3e-2
+    scale = max(float(v.norm()) for v in ref_g.values())
+    worst, num, den = ("", 0.0), 0.0, 0.0
+    for k, p in m.named_parameters():
+        got, ref = p.grad.cpu(), ref_g[k]
+        d = float((got - ref).norm())
+        err = d / max(float(ref.norm()), FLOOR * scale)
+        num += d * d
+        den += float(ref.norm()) ** 2
+        if err > worst[1]:
+            worst = (k, err)
+        p.grad = None
+        ref_g[k] = None
+    tot = (num / den) ** 0.5
+    dx_err = rel_err(xd.grad.cpu(), ref_dx)
+    print(f"sd15 backward: worst={worst[0]}:{worst[1]:.2e} overall={tot:.2e} dx={dx_err:.2e}")
+    assert worst[1] <= GRAD_TOL and tot <= ALL_TOL and dx_err <= GRAD_TOL, (worst, tot, dx_err)

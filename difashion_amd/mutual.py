@@ -9,6 +9,8 @@ GEMV-like problem (16.8 MB of bf16 weights): both linears go through dfh_gemm (s
 from __future__ import annotations
 
 import ctypes as C
+import json
+import os
 from typing import Optional
 
 import torch
@@ -37,11 +39,24 @@ class _MutualStep(torch.autograd.Function):
         return None, None, None, None
 
 
+class _Config(dict):
+    """diffusers-style config: attribute and mapping access (the reference reads ``fashion_encoder.config`` both ways)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
 class MutualEncoder(nn.Module):
-    def __init__(self, cate_num: int, cate_emb_size: int, latent_channels: int, latent_size: int, hid_dim: int):
+    config_name = "config.json"
+    weights_name = "diffusion_pytorch_model.safetensors"
+
+    def __init__(self, cate_num: int, cate_emb_size: int, latent_channels: int, latent_size: int, hid_dim: int, **unused):
         super().__init__()
-        self.config = dict(cate_num=cate_num, cate_emb_size=cate_emb_size, latent_channels=latent_channels,
-                           latent_size=latent_size, hid_dim=hid_dim)
+        self.config = _Config(cate_num=cate_num, cate_emb_size=cate_emb_size, latent_channels=latent_channels,
+                              latent_size=latent_size, hid_dim=hid_dim)
         self.category_embedding = nn.Embedding(cate_num, cate_emb_size)  # unused in forward (difashion.py:28)
         self.latent_channels = latent_channels
         self.latent_size = latent_size
@@ -53,6 +68,32 @@ class MutualEncoder(nn.Module):
         self._packed = None
         self._sig = None
         self._anchor = None
+
+    # ---- checkpoint directory layout of the reference (ModelMixin: train.py:516-554) ---------------------------------
+    def register_to_config(self, **kwargs):
+        self.config.update(kwargs)
+
+    def save_pretrained(self, save_directory: str, **unused):
+        from safetensors.torch import save_file
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = dict(self.config)
+        cfg["_class_name"] = "MutualEncoder"
+        with open(os.path.join(save_directory, self.config_name), "w") as f:
+            json.dump(cfg, f, indent=2)
+        save_file({k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()},
+                  os.path.join(save_directory, self.weights_name))
+
+    @classmethod
+    def from_pretrained(cls, path: str, subfolder: Optional[str] = None, **unused):
+        from safetensors.torch import load_file
+        d = os.path.join(path, subfolder) if subfolder else path
+        with open(os.path.join(d, cls.config_name)) as f:
+            cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        ctor = {k: cfg[k] for k in ("cate_num", "cate_emb_size", "latent_channels", "latent_size", "hid_dim")}
+        model = cls(**ctor)
+        model.register_to_config(**cfg)          # extra keys (e.g. EMA state written by EMAModel.save_pretrained) survive
+        model.load_state_dict(load_file(os.path.join(d, cls.weights_name)))
+        return model
 
     def _pack(self):
         w1, b1, w2, b2 = self.mlp[0].weight, self.mlp[0].bias, self.mlp[3].weight, self.mlp[3].bias

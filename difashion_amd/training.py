@@ -275,14 +275,23 @@ class EMAModel:
     def save_pretrained(self, path: str):
         if self.model_cls is None:
             raise ValueError("`save_pretrained` can only be used if `model_cls` was defined at __init__.")
-        model = self.model_cls(**dict(self.model_config)) if not hasattr(self.model_cls, "from_config") else self.model_cls.from_config(self.model_config)
+        # diffusers layout: the EMA weights as an ordinary model directory, the EMA hyper-state as extra config keys
+        cfg = {k: v for k, v in dict(self.model_config).items() if k not in self._STATE_KEYS}
+        model = self.model_cls.from_config(cfg) if hasattr(self.model_cls, "from_config") else self.model_cls(init_seed=None, **cfg)
         for s, p in zip(self.shadow_params, model.parameters()):
             p.data.copy_(s.cpu())
+        model.register_to_config(**{k: v for k, v in self.state_dict().items() if k != "shadow_params"})
         model.save_pretrained(path)
-        sd = {k: v for k, v in self.state_dict().items() if k != "shadow_params"}
-        import json
-        with open(os.path.join(path, "ema_state.json"), "w") as f:
-            json.dump(sd, f)
+
+    _STATE_KEYS = ("decay", "min_decay", "optimization_step", "update_after_step", "use_ema_warmup", "inv_gamma", "power")
+
+    @classmethod
+    def from_pretrained(cls, path: str, model_cls) -> "EMAModel":
+        """EMAModel.from_pretrained(dir, UNet2DConditionModel) as in the reference's load hook (train.py:530-539)."""
+        model = model_cls.from_pretrained(path)
+        ema = cls(model.parameters(), model_cls=model_cls, model_config=model.config)
+        ema.load_state_dict({k: model.config[k] for k in cls._STATE_KEYS if k in model.config})
+        return ema
 
 
 def clip_grad_norm_(parameters, max_norm: float) -> torch.Tensor:

@@ -441,5 +441,7 @@ class UNet2DConditionModel(nn.Module):
         cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
         cfg.update({k: v for k, v in kwargs.items() if k in ("max_batch",)})
         model = cls(init_seed=None, **cfg)
+        # keys the constructor does not know (e.g. the EMA state diffusers' EMAModel.save_pretrained adds) stay in .config
+        model.register_to_config(**{k: v for k, v in cfg.items() if k not in model.config and k != "max_batch"})
         model.load_state_dict(load_file(os.path.join(d, cls.weights_name)))
         return model

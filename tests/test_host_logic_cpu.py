@@ -173,3 +173,43 @@ def test_world_size_2_gloo_gradient_all_reduce_matches_single_process():
 def test_all_reduce_gradients_is_identity_without_a_process_group():
     g = torch.arange(5, dtype=torch.float32)
     assert ddist.all_reduce_gradients(g) is g and g.tolist() == [0, 1, 2, 3, 4]
+
+
+# ----------------------------------------------------------------------------- checkpoint directories (train.py:516-554)
+def test_checkpoint_directories_round_trip_like_the_reference_hooks(tmp_path):
+    """save hook: unet.save_pretrained / fashion_encoder.save_pretrained / ema.save_pretrained; load hook:
+    from_pretrained(dir, subfolder=...), register_to_config(**loaded.config), load_state_dict, EMAModel.from_pretrained."""
+    import difashion_amd as da
+    torch.manual_seed(0)
+    unet = da.UNet2DConditionModel(sample_size=16, in_channels=4, block_out_channels=(32, 64, 64, 64), cross_attention_dim=64,
+                                   attention_head_dim=(1, 2, 2, 2), init_seed=3)
+    unet.conv_in = torch.nn.Conv2d(8, 32, 3, 1, 1)           # widened like difashion.py:84-93
+    unet.register_to_config(in_channels=8)
+    enc = da.MutualEncoder(cate_num=11, cate_emb_size=8, latent_channels=4, latent_size=16, hid_dim=32)
+    ema = da.EMAModel(unet.parameters(), decay=0.99, model_cls=da.UNet2DConditionModel, model_config=unet.config)
+    ema.optimization_step = 17
+    with torch.no_grad():
+        ema.shadow_params[0].add_(1.0)
+    out = str(tmp_path)
+    unet.save_pretrained(os.path.join(out, "unet"))
+    enc.save_pretrained(os.path.join(out, "fashion_encoder"))
+    ema.save_pretrained(os.path.join(out, "unet_ema"))
+    for sub in ("unet", "fashion_encoder", "unet_ema"):
+        assert sorted(os.listdir(os.path.join(out, sub))) == ["config.json", "diffusion_pytorch_model.safetensors"]
+
+    u2 = da.UNet2DConditionModel.from_pretrained(out, subfolder="unet")
+    assert u2.config.in_channels == 8 and tuple(u2.conv_in.weight.shape) == (32, 8, 3, 3)
+    assert all(torch.equal(a, b) for a, b in zip(unet.state_dict().values(), u2.state_dict().values()))
+    fresh = da.UNet2DConditionModel(sample_size=16, in_channels=8, block_out_channels=(32, 64, 64, 64), cross_attention_dim=64,
+                                    attention_head_dim=(1, 2, 2, 2), init_seed=None)
+    fresh.register_to_config(**u2.config)
+    fresh.load_state_dict(u2.state_dict())
+
+    e2 = da.MutualEncoder.from_pretrained(out, subfolder="fashion_encoder")
+    assert dict(e2.config) == dict(enc.config) and e2.config.hid_dim == 32
+    assert all(torch.equal(a, b) for a, b in zip(enc.state_dict().values(), e2.state_dict().values()))
+
+    ema2 = da.EMAModel.from_pretrained(os.path.join(out, "unet_ema"), da.UNet2DConditionModel)
+    assert ema2.optimization_step == 17 and ema2.decay == 0.99
+    assert all(torch.equal(a, b) for a, b in zip(ema.shadow_params, ema2.shadow_params))
+    ema.load_state_dict(ema2.state_dict())                    # train.py:532

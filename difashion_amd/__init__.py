@@ -12,9 +12,10 @@ from .pipeline import OutfitSampler, guidance_plan, sample_outfits, sampling_tab
 from .schedulers import DDIMScheduler, PNDMScheduler
 from .training import EMAModel, FusedAdamW, clip_grad_norm_, train_step
 from .unet import UNet2DConditionModel, UNet2DConditionOutput
+from .vae import AutoencoderKL
 
 __all__ = [
     "DfhError", "UNet2DConditionModel", "UNet2DConditionOutput", "DDIMScheduler", "PNDMScheduler",
     "MutualEncoder", "OutfitSampler", "sample_outfits", "train_forward", "guidance_plan", "sampling_tables", "training_tables",
-    "FusedAdamW", "EMAModel", "clip_grad_norm_", "train_step",
+    "FusedAdamW", "EMAModel", "clip_grad_norm_", "train_step", "AutoencoderKL",
 ]

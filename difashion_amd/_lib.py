@@ -31,6 +31,11 @@ class UNetConfigC(C.Structure):
     ]
 
 
+class VAEConfigC(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("latent_channels", C.c_int), ("num_blocks", C.c_int),
+                ("block_out_channels", C.c_int * DFH_MAX_BLOCKS), ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("conv_src", C.c_void_p), ("conv_c", C.c_int), ("conv", C.c_int),
@@ -81,6 +86,19 @@ SIGNATURES = {
     "dfh_unet_pack": (_i, [_vp, C.POINTER(_vp), _i, _vp]),
     "dfh_unet_forward": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "dfh_unet_debug_tap": (_i, [_vp, C.c_char_p, _vp, _sz, _vp]),
+    "dfh_vae_create": (_i, [C.POINTER(VAEConfigC), C.POINTER(_vp)]),
+    "dfh_vae_destroy": (None, [_vp]),
+    "dfh_vae_num_params": (_i, [_vp]),
+    "dfh_vae_param_name": (C.c_char_p, [_vp, _i]),
+    "dfh_vae_param_ndim": (_i, [_vp, _i]),
+    "dfh_vae_param_dim": (_i, [_vp, _i, _i]),
+    "dfh_vae_arena16_bytes": (_sz, [_vp]),
+    "dfh_vae_arena32_bytes": (_sz, [_vp]),
+    "dfh_vae_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "dfh_vae_bind": (_i, [_vp, _vp, _vp, _vp, _sz]),
+    "dfh_vae_pack": (_i, [_vp, C.POINTER(_vp), _i, _vp]),
+    "dfh_vae_encode": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "dfh_vae_decode": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "dfh_unet_arena16t_bytes": (_sz, [_vp]),
     "dfh_unet_grad16_bytes": (_sz, [_vp]),
     "dfh_unet_grad32_bytes": (_sz, [_vp]),
@@ -134,7 +152,8 @@ SIGNATURES = {
     "dfh_noise_mix": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "dfh_mse_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
 }
-_NO_STATUS = {"dfh_abi_version", "dfh_unet_num_params", "dfh_unet_param_ndim", "dfh_unet_param_dim"}
+_NO_STATUS = {"dfh_abi_version", "dfh_unet_num_params", "dfh_unet_param_ndim", "dfh_unet_param_dim", "dfh_vae_num_params",
+              "dfh_vae_param_ndim", "dfh_vae_param_dim"}
 
 _lib = None
 

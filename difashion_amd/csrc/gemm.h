@@ -23,6 +23,7 @@ struct GemmArgs {
   // --- K segments
   const bf16_t* conv_src; int conv_c; int ntaps;
   int Hin, Win, Hout, Wout, stride, ups;
+  int pad0;        // 1: conv padding 0 with the input zero-extended on the right / bottom (VAE Downsample2D: F.pad(0,1,0,1) + stride 2)
   const bf16_t* p_src[2]; int p_c[2]; int nplain;
   const bf16_t* W; int ldw;
   const bf16_t* zero;  // >= 16 bytes of zeros in device memory

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
       if (a.ntaps) {
         const int b = m / HWo, rem = m - b * HWo;
         const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
-        a_y[i] = oy * a.stride - 1; a_x[i] = ox * a.stride - 1;
+        a_y[i] = oy * a.stride - (a.pad0 ? 0 : 1); a_x[i] = ox * a.stride - (a.pad0 ? 0 : 1);
         a_bbase[i] = b * a.Hin * a.Win;
       }
     }

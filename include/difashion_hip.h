@@ -130,6 +130,37 @@ int dfh_unet_backward(dfh_unet* u, const float* d_out, float* d_sample, float* c
  * parity tests).  Names: "conv_in", "down0".."down3", "mid", "up0".."up3". */
 int dfh_unet_debug_tap(dfh_unet* u, const char* name, float* dst, size_t dst_floats, void* stream);
 
+/* ------------------------------------------------------------------ AutoencoderKL
+ * Replaces diffusers' AutoencoderKL as the reference calls it: vae.encode(images).latent_dist (df.py:129,144,376,435-437)
+ * and vae.decode(latents / scaling_factor) (df.py:580).  Same ownership rules as dfh_unet: caller-owned, zero-filled
+ * arenas + workspace, fp32 master parameters in table order with diffusers state-dict names. */
+typedef struct dfh_vae_config {
+  int in_channels;                 /* 3 */
+  int out_channels;                /* 3 */
+  int latent_channels;             /* 4 */
+  int num_blocks;                  /* 4 */
+  int block_out_channels[DFH_MAX_BLOCKS];   /* 128, 256, 512, 512 */
+  int layers_per_block;            /* 2 */
+  int norm_num_groups;             /* 32 */
+} dfh_vae_config;
+typedef struct dfh_vae dfh_vae;
+int dfh_vae_create(const dfh_vae_config* cfg, dfh_vae** out);
+void dfh_vae_destroy(dfh_vae* u);
+int dfh_vae_num_params(const dfh_vae* u);
+const char* dfh_vae_param_name(const dfh_vae* u, int i);
+int dfh_vae_param_ndim(const dfh_vae* u, int i);
+int dfh_vae_param_dim(const dfh_vae* u, int i, int d);
+size_t dfh_vae_arena16_bytes(const dfh_vae* u);
+size_t dfh_vae_arena32_bytes(const dfh_vae* u);
+/* encode != 0: size = image side; else size = latent side */
+size_t dfh_vae_workspace_bytes(dfh_vae* u, int encode, int batch, int size);
+int dfh_vae_bind(dfh_vae* u, void* arena16, void* arena32, void* workspace, size_t workspace_bytes);
+int dfh_vae_pack(dfh_vae* u, const float* const* master_params, int count, void* stream);
+/* images [B][in_channels][S][S] fp32 -> moments [B][2*latent_channels][S/8][S/8] fp32 = [mean | logvar] */
+int dfh_vae_encode(dfh_vae* u, const float* images, float* moments, int batch, int image_size, void* stream);
+/* latents [B][latent_channels][s][s] fp32 -> images [B][4][8s][8s] fp32 (out_channels = 3 used, the 4th plane is padding) */
+int dfh_vae_decode(dfh_vae* u, const float* latents, float* images, int batch, int latent_size, void* stream);
+
 /* ------------------------------------------------------------------ op-level entry points (tests, profiling)
  * ResnetBlock2D conv3x3 / Downsample2D / Upsample2D / 1x1 conv / Linear, as one implicit GEMM:
  *   out[M][N] = act( conv3x3(x) (+ a0 . W[:, k0:] + a1 . W[:, k1:]) + bias + rowvec[b] ) + resid */

@@ -165,6 +165,94 @@ def run_train(args, da, _lib, ddist, rank, world, dev):
     print(json.dumps(out), flush=True)
 
 
+def vae_flops(boc=(128, 256, 512, 512), layers=2, latent=64):
+    """Algorithmic FLOPs of one SD-VAE decode / encode (2 x MACs of every conv / linear / attention product)."""
+    def conv(cin, cout, hw, k=9):
+        return 2.0 * k * cin * cout * hw
+    def resnet(cin, cout, hw):
+        return conv(cin, cout, hw) + conv(cout, cout, hw) + (conv(cin, cout, hw, 1) if cin != cout else 0.0)
+    def mid(c, hw):
+        return 2 * resnet(c, c, hw) + 4 * conv(c, c, hw, 1) + 2 * 2.0 * hw * hw * c
+    rev, hw = tuple(reversed(boc)), latent * latent
+    dec = conv(4, 4, hw, 1) + conv(4, rev[0], hw) + mid(rev[0], hw)
+    ch = rev[0]
+    for i, oc in enumerate(rev):
+        for j in range(layers + 1):
+            dec += resnet(ch if j == 0 else oc, oc, hw)
+        ch = oc
+        if i != len(rev) - 1:
+            hw *= 4
+            dec += conv(ch, ch, hw)
+    dec += conv(boc[0], 3, hw)
+    enc = conv(3, boc[0], hw)
+    ch = boc[0]
+    for i, oc in enumerate(boc):
+        for j in range(layers):
+            enc += resnet(ch if j == 0 else oc, oc, hw)
+        ch = oc
+        if i != len(boc) - 1:
+            hw //= 4
+            enc += conv(ch, ch, hw)
+    enc += mid(ch, hw) + conv(ch, 8, hw) + conv(8, 8, hw, 1)
+    return dec, enc
+
+
+def run_vae(args, da, _lib, ddist, rank, world, dev):
+    """the VAE on either side of the denoising path -- decode of one outfit's four 64x64x4 latents to
+    512x512 images (difashion.py:580) and encode of four 512x512 images (:144); random SD-VAE-shape weights."""
+    vae = da.AutoencoderKL(init_seed=None).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(0)
+    with torch.no_grad():
+        for n, p in vae.named_parameters():
+            if n.endswith(".weight") and "norm" not in n.split(".")[-2]:
+                p.normal_(0.0, 0.02, generator=g)
+    z = torch.randn(4, 4, 64, 64, device=dev)
+    x = torch.rand(4, 3, 512, 512, device=dev) * 2 - 1
+    K, W = args.steps, args.warmup
+    res = {}
+    dec_f, enc_f = vae_flops()
+    for name, fn, fl in (("decode", lambda: vae.decode(z), dec_f), ("encode", lambda: vae.encode(x), enc_f)):
+        for _ in range(W):
+            fn()
+        torch.cuda.synchronize(); ddist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            fn()
+        torch.cuda.synchronize(); ddist.barrier(); torch.cuda.synchronize()
+        el = ddist.max_over_ranks(time.perf_counter() - t0)
+        res[name] = dict(ms_per_outfit=round(el * 1e3 / K, 2), images_per_s=round(world * 4 * K / el, 1),
+                         algorithmic_tflop_per_image=round(fl / 1e12, 3), tflops=round(4 * fl * K / el / 1e12, 1))
+    classes = None
+    if not args.no_profile and rank == 0:
+        _lib.prof_begin()
+        for _ in range(K):
+            vae.decode(z)
+        classes = _lib.prof_end()
+    if rank != 0:
+        return
+    out = {"metric": "VAE decode images/sec, 4-item outfit @ 64x64x4 latent -> 512x512", "value": res["decode"]["images_per_s"], "unit": "images/s",
+           "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": res["decode"]["ms_per_outfit"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "SURVEY 8f-1: AutoencoderKL (SD VAE shape, 83.65 M parameters), one outfit = 4 images per step per GPU"},
+           "decode": res["decode"], "encode": res["encode"], "hbm_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
+    if classes is not None:
+        out["decode_kernel_classes"] = {c: dict(launches_per_step=v["launches"] // K, ms_per_step=round(v["ms"] / K, 3),
+                                                tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] > 0 else None)
+                                        for c, v in classes.items() if v["launches"]}
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import vae_ref
+        torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+        p = vae_ref.init_params(vae_ref.SD_VAE, seed=0)
+        zc = torch.randn(1, 4, 64, 64)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            vae_ref.decode(p, vae_ref.SD_VAE, zc)
+            t = time.perf_counter() - t0
+        out["cpu_baseline"] = dict(value=round(1.0 / t, 3), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                                   sample=f"oracle fp32 decode of one 64x64x4 latent = {t:.2f}s")
+    print(json.dumps(out), flush=True)
+
+
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/rNN/pmc_traffic.json,
     written by scripts/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command,
@@ -188,8 +276,8 @@ def main():
     ap.add_argument("--config", default="sd15", choices=["sd15", "sd2base"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--mode", default="sample", choices=["sample", "train"],
-                    help="sample: the headline metric (default); train: BASELINE configs[2]/[3] training step")
+    ap.add_argument("--mode", default="sample", choices=["sample", "train", "vae"],
+                    help="sample: the headline metric (default); train: BASELINE configs[2]/[3] training step; vae: SURVEY 8f-1")
     ap.add_argument("--outfits", type=int, default=8, help="--mode train: outfits per GPU per step")
     args = ap.parse_args()
 
@@ -206,6 +294,8 @@ def main():
 
     if args.mode == "train":
         return run_train(args, da, _lib, ddist, rank, world, dev)
+    if args.mode == "vae":
+        return run_vae(args, da, _lib, ddist, rank, world, dev)
     unet, enc = build_models(dev, args.config)
     cross = unet.config.cross_attention_dim
     K, W = args.steps, args.warmup

@@ -213,3 +213,53 @@ def test_checkpoint_directories_round_trip_like_the_reference_hooks(tmp_path):
     assert ema2.optimization_step == 17 and ema2.decay == 0.99
     assert all(torch.equal(a, b) for a, b in zip(ema.shadow_params, ema2.shadow_params))
     ema.load_state_dict(ema2.state_dict())                    # train.py:532
+
+
+# ----------------------------------------------------------------------------- batch builder
+def test_preprocess_dataset_matches_the_reference_function(tmp_path):
+    """difashion_amd.data.preprocess_dataset vs golden vectors captured from the REAL DiFashion/data_utils.py
+    (tests/golden/make_golden_data.py): prompts, token ids, history latents (bit-exact), FITB masking."""
+    import numpy as np
+    from difashion_amd import data as dd
+    from tests.helpers import GOLDEN
+    from tests.helpers_data import StubTokenizer, synthetic_dataset
+    rec = np.load(os.path.join(GOLDEN, "data_prep.npz"), allow_pickle=False)
+    data, id_cate, history, latents = synthetic_dataset()
+    np.save(os.path.join(str(tmp_path), "all_item_latents.npy"), latents.numpy())
+    tok = StubTokenizer()
+    out, hist = dd.preprocess_dataset(data, str(tmp_path), id_cate, history, None, tok, None, "cpu")
+    assert tok.seen == list(rec["prompts"])
+    assert "a pair of wide-leg pants" in tok.seen[5] and "A photo of a t-shirt," in tok.seen[0]
+    for i in range(int(rec["n_outfits"])):
+        assert np.array_equal(out["input_ids"][i].numpy(), rec[f"input_ids_{i}"])
+        assert np.array_equal(out["category"][i].numpy(), rec[f"category_{i}"])
+        assert out["outfits"][i].dtype == torch.int64 and np.array_equal(out["outfits"][i].numpy(), rec[f"outfits_{i}"])
+    assert np.array_equal(hist["null"].numpy(), rec["hist_null"])
+    for uid in history:
+        for cate in history[uid]:
+            assert np.array_equal(hist[uid][cate].numpy(), rec[f"hist_{uid}_{cate}"])       # bit-exact fp32 means
+    fitb = dd.FashionFITBData(out, {"outfits": [o.tolist() for o in out["outfits"]]}, fill_num=2)[1]
+    assert np.array_equal(fitb["outfits"].numpy(), rec["fitb_outfits_1"])
+    item = dd.FashionDiffusionData(out)[2]
+    assert set(item) == {"uids", "oids", "outfits", "input_ids", "category"} and item["oids"] == 102
+
+
+def test_encode_item_latents_batches_through_the_vae():
+    from difashion_amd import data as dd
+
+    class FakeVAE:                                   # the cache-miss branch: 64-image batches, mode() * scaling_factor
+        class config:
+            scaling_factor = 0.5
+        calls = []
+
+        def to(self, dev):
+            return self
+
+        def encode(self, x):
+            self.calls.append(x.shape[0])
+            return type("O", (), {"latent_dist": type("D", (), {"mode": staticmethod(lambda: x[:, :1] * 2)})})
+
+    imgs = [torch.full((3, 4, 4), float(i)) for i in range(130)]
+    vae = FakeVAE()
+    lat = dd.encode_item_latents(vae, imgs, "cpu")
+    assert vae.calls == [64, 64, 2] and lat.shape == (130, 1, 4, 4) and float(lat[7, 0, 0, 0]) == 7.0

@@ -185,8 +185,11 @@ def sample_outfits(unet, fashion_encoder: MutualEncoder, scheduler, *, olists: t
                    num_inference_steps: int = 50, cate_scale: float = 12.0, hist_scale: float = 4.0,
                    mutual_scale: float = 5.0, eta: float = 0.1, ddim_eta: float = 0.0,
                    use_history: bool = True, use_mutual_guidance: bool = True, generator=None,
-                   taps: Optional[dict] = None, callback: Optional[Callable] = None) -> torch.Tensor:
-    """CFG sampler for the F blank slots of ``olists`` (0 = generate).  Returns final latents (F,4,S,S).
+                   taps: Optional[dict] = None, callback: Optional[Callable] = None, vae=None,
+                   output_type: str = "latent") -> torch.Tensor:
+    """CFG sampler for the F blank slots of ``olists`` (0 = generate).  Returns final latents (F,4,S,S), or -- with
+    ``vae`` and ``output_type="image"`` -- the decoded images in [-1, 1] (F,3,8S,8S):
+    ``vae.decode(latents / vae.config.scaling_factor)[0]`` as at difashion.py:580.
 
     ``all_latents`` (bsz*olen,4,S,S): clean latents of every slot (blank slots unused);
     ``hist_latents`` (F,4,S,S): history rows selected for the blank slots; ``category_prompts``
@@ -206,7 +209,11 @@ def sample_outfits(unet, fashion_encoder: MutualEncoder, scheduler, *, olists: t
             taps[f"unet_out_{i}"] = s.eps_all.clone()
         if callback is not None:
             callback(i, t, s.latents)
-    return s.latents
+    if output_type == "latent":
+        return s.latents
+    if vae is None:
+        raise ValueError("output_type='image' needs the vae")
+    return vae.decode(s.latents / vae.config.scaling_factor, return_dict=False)[0]
 
 
 class _AssembleInput(torch.autograd.Function):

@@ -82,3 +82,26 @@ def test_vae_api_and_errors():
         m.encode(torch.rand(2, 3, 30, 30, device=DEV))
     with pytest.raises(da.DfhError, match="no CPU fallback"):
         da.AutoencoderKL(block_out_channels=cfg.block_out_channels, init_seed=None).decode(torch.zeros(1, 4, 4, 4))
+
+
+def test_sample_outfits_decodes_through_the_vae():
+    """difashion.py:456-580 end to end on the HIP path: guided sampling of a 4-item outfit, then vae.decode(latents / scale)."""
+    from oracle import unet_ref
+    from tests.test_gpu_unet import hip_unet
+    ucfg = unet_ref.UNetConfig(sample_size=8, block_out_channels=(64, 128, 256, 256), cross_attention_dim=64, num_heads=(2, 2, 2, 2))
+    unet = hip_unet(ucfg, unet_ref.init_params(ucfg, seed=1, w_std=0.05), max_batch=16)
+    vcfg = vae_ref.TINY_VAE
+    vp = vae_ref.init_params(vcfg, seed=6, w_std=0.05)
+    vae = hip_vae(vcfg, vp)
+    enc = da.MutualEncoder(cate_num=4, cate_emb_size=8, latent_channels=4, latent_size=8, hid_dim=32).to(DEV).eval()
+    g = torch.Generator().manual_seed(7)
+    rn = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    kw = dict(olists=torch.zeros(1, 4, dtype=torch.long), all_latents=rn(4, 4, 8, 8), init_latents=rn(4, 4, 8, 8),
+              hist_latents=rn(4, 4, 8, 8) * 0.2, null_latent=rn(4, 8, 8) * 0.2, category_prompts=rn(4, 77, 64),
+              null_prompt=rn(1, 77, 64), num_inference_steps=3)
+    lat = da.sample_outfits(unet, enc, da.DDIMScheduler(), **kw)
+    img = da.sample_outfits(unet, enc, da.DDIMScheduler(), vae=vae, output_type="image", **kw)
+    assert img.shape == (4, 3, 64, 64) and torch.isfinite(img).all()
+    with torch.no_grad():
+        ref = vae_ref.decode(vp, vcfg, lat.cpu() / vcfg.scaling_factor)
+    assert rel_err(img.cpu(), ref) <= TOL

@@ -193,6 +193,69 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 
 }  // namespace
 
+// ---- small tensors (16x16 / 8x8 levels, and 32x32 at 640 channels): ONE launch.  A block owns one (batch, group) slab of
+// HW x cpg <= 32768 elements, reads it once into registers (8-byte units = 4 channels of a pixel), reduces it in a fixed
+// order (two-pass variance from the registers), normalises and writes.  The two-kernel path above spends ~2 x 8 us of launch
+// and dependency latency on tensors that hold a few hundred KB.
+template <int UNITS>
+__global__ __launch_bounds__(256) void gn_small_kernel(const GnArgs a) {
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int cpg = a.C / a.G, upp = cpg >> 2, total = a.HW * upp;
+  const int cg = g * cpg;                                     // first channel of the group in the concatenated tensor
+  const bool first = cg < a.C0;
+  const bf16_t* src = first ? a.src0 + (long)b * a.HW * a.C0 + cg : a.src1 + (long)b * a.HW * a.C1 + (cg - a.C0);
+  const int ldc = first ? a.C0 : a.C1;
+  __shared__ float red[8];
+  float v[UNITS][4];
+  int pix[UNITS], ch[UNITS];
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < UNITS; ++u) {
+    const int idx = tid + u * 256;
+    pix[u] = -1; ch[u] = 0;
+    v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.f;
+    if (idx < total) {
+      const int p = idx / upp, j = idx - p * upp;
+      pix[u] = p; ch[u] = j * 4;
+      const uint2 r = *(const uint2*)(src + (long)p * ldc + j * 4);
+      v[u][0] = __uint_as_float(r.x << 16); v[u][1] = __uint_as_float(r.x & 0xffff0000u);
+      v[u][2] = __uint_as_float(r.y << 16); v[u][3] = __uint_as_float(r.y & 0xffff0000u);
+      s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+    }
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float n = (float)a.HW * (float)cpg;
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / n;
+  float q = 0.f;
+#pragma unroll
+  for (int u = 0; u < UNITS; ++u)
+    if (pix[u] >= 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float d = v[u][k] - mean; q += d * d; }
+    }
+  q = wave_sum(q);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
+  __syncthreads();
+  const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) / n + a.eps);
+  if (a.stats_out && tid == 0) { a.stats_out[((long)b * a.G + g) * 2] = mean; a.stats_out[((long)b * a.G + g) * 2 + 1] = rstd; }
+  bf16_t* dst = a.out + (long)b * a.HW * a.C + cg;
+#pragma unroll
+  for (int u = 0; u < UNITS; ++u)
+    if (pix[u] >= 0) {
+      const float4 gm = *(const float4*)(a.gamma + cg + ch[u]), bt = *(const float4*)(a.beta + cg + ch[u]);
+      float y[4] = {(v[u][0] - mean) * rstd * gm.x + bt.x, (v[u][1] - mean) * rstd * gm.y + bt.y,
+                    (v[u][2] - mean) * rstd * gm.z + bt.z, (v[u][3] - mean) * rstd * gm.w + bt.w};
+      if (a.silu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = silu_f(y[k]);
+      }
+      uint2 o; o.x = pack2bf(y[0], y[1]); o.y = pack2bf(y[2], y[3]);
+      *(uint2*)(dst + (long)pix[u] * a.C + ch[u]) = o;
+    }
+}
+
 namespace dfh {
 
 static void gn_geometry(GnArgs& a, int* block, int* achunks) {
@@ -221,6 +284,19 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
   DFH_REQUIRE(a.C / 8 <= 1024, "too many channels");
   DFH_REQUIRE(a.partial != nullptr && a.out != nullptr && a.src0 != nullptr, "null pointer");
   DFH_REQUIRE(a.C1 == 0 || a.src1 != nullptr, "second source missing");
+  {
+    const int cpg = a.C / a.G;
+    const long units = (long)a.HW * (cpg >> 2);
+    const bool one_source_per_group = a.C1 == 0 || a.C0 % cpg == 0;
+    if ((cpg & 3) == 0 && units <= 256 * 32 && one_source_per_group && (long)a.B * a.G >= 64) {
+      ProfScope ps(PC_GNORM, 0.0, 4.0 * a.B * (double)a.HW * a.C, stream);
+      const dim3 grid(a.G, a.B);
+      if (units <= 256 * 8) hipLaunchKernelGGL(gn_small_kernel<8>, grid, dim3(256), 0, stream, a);
+      else if (units <= 256 * 16) hipLaunchKernelGGL(gn_small_kernel<16>, grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL(gn_small_kernel<32>, grid, dim3(256), 0, stream, a);
+      return check_launch("gn_small_kernel");
+    }
+  }
   int block, achunks;
   gn_geometry(a, &block, &achunks);
   DFH_REQUIRE(block <= 1024, "block too large");

@@ -30,6 +30,10 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 MFMA_BF16_PEAK = 2500.0   # TFLOP/s dense, MI355X_MICROARCH.md
+# What a register-resident loop of nothing but v_mfma_f32_16x16x32_bf16 sustains on this pool's boxes with random operands
+# (scripts/probes/mfma_rate.hip -> profiles/r01/mfma_rate.txt: 1157-1175 TFLOP/s at 2-4 waves per SIMD, 1300 zero-filled): the
+# part is power / clock limited under dense MFMA load.  Reported next to the nominal peak; roofline.frac stays against 2500.
+MFMA_BF16_SUSTAINED = 1170.0
 HBM_PEAK = 8000.0         # GB/s
 
 
@@ -334,6 +338,7 @@ def main():
                         achieved=round(achieved, 1), peak=MFMA_BF16_PEAK, unit="TFLOP/s", frac=round(achieved / MFMA_BF16_PEAK, 4),
                         traffic=traffic, traffic_unit="HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", traffic_source=traffic_src,
                         algorithmic_bytes_per_launch=round(gemm["bytes"] / max(1, gemm["launches"])),
+                        sustained_mfma_only_peak=MFMA_BF16_SUSTAINED, frac_of_sustained=round(achieved / MFMA_BF16_SUSTAINED, 4),
                         launches_per_step=gemm["launches"] // K,
                         avg_launch_us=round(gemm["ms"] * 1e3 / max(1, gemm["launches"]), 2),
                         algorithmic_tflop_per_step=round(gemm["flops"] / K / 1e12, 3))

@@ -263,3 +263,24 @@ def test_encode_item_latents_batches_through_the_vae():
     vae = FakeVAE()
     lat = dd.encode_item_latents(vae, imgs, "cpu")
     assert vae.calls == [64, 64, 2] and lat.shape == (130, 1, 4, 4) and float(lat[7, 0, 0, 0]) == 7.0
+
+
+def test_prompt_table_equals_per_batch_encoding():
+    """encoding the closed prompt set once + a gather == the reference's per-batch text_encoder calls
+    (difashion.py:218-224, :340-353) for any deterministic encoder."""
+    from difashion_amd.data import category_prompt
+    from difashion_amd.prompts import PromptTable
+    from tests.helpers_data import StubTokenizer, synthetic_dataset
+    _, id_cate, _, _ = synthetic_dataset()
+    emb = torch.nn.Embedding(1001, 6)
+    encoder = lambda ids: (emb(ids),)                               # stand-in for CLIPTextModel: (last_hidden_state,)
+    tok = StubTokenizer()
+    table = PromptTable.build(encoder, tok, id_cate, "cpu", batch_size=3)
+    assert table.table.shape == (len(id_cate) + 1, tok.model_max_length, 6)
+    cats = torch.tensor([[1, 2, 3, 5], [4, 6, 1, 3]])
+    got = table.lookup(cats)
+    ids = StubTokenizer()([category_prompt(id_cate[int(c)]) for c in cats.reshape(-1)], max_length=16, padding="max_length",
+                          truncation=True, return_tensors="pt").input_ids
+    assert torch.equal(got, encoder(ids)[0])
+    null_ids = StubTokenizer()([""], max_length=16, padding="max_length", truncation=True, return_tensors="pt").input_ids
+    assert torch.equal(table.null_prompt, encoder(null_ids)[0])

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
   const unsigned a_off = (wm * TM + fr) * 64 + fslot;
   const unsigned b_off = A_BYTES + (wn * TN + fr) * 64 + fslot;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  static_assert((FM == 8 || FM == 4) && FN == 5, "the hand-scheduled k-step is written for {8,4} x 5 fragments");
+  static_assert((FM == 8 || FM == 4) && (FN == 5 || FN == 4), "the hand-scheduled k-step is written for {8,4} x {5,4} fragments");
 
   if (nk > 0) {
     KIterW it = kiterw_at(a, 0);
@@ -210,9 +210,11 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
       const unsigned sa = lds0 + buf * STAGE + a_off, sb = lds0 + buf * STAGE + b_off;
       u32x4_t b[FN], a0, a1, a2;
       __builtin_amdgcn_sched_barrier(0);
-      WRD(b[0], sb, 0); WRD(b[1], sb, 1024); WRD(b[2], sb, 2048); WRD(b[3], sb, 3072); WRD(b[4], sb, 4096);
+      WRD(b[0], sb, 0); WRD(b[1], sb, 1024); WRD(b[2], sb, 2048); WRD(b[3], sb, 3072);
+      if constexpr (FN == 5) WRD(b[4], sb, 4096);
       WRD(a0, sa, 0); WRD(a1, sa, 1024);
-      asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(a0));
+      if constexpr (FN == 5) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(a0));
+      else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(a0));
 #define WROW(i, ar)                                                                                                    \
       _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                                   \
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b[j]), __builtin_bit_cast(bf16x8_t, ar), \
@@ -338,11 +340,15 @@ int gemm_wide_ksteps(const GemmArgs& a) {
 }
 
 // bf16 row-major output, no GEGLU / split-K, 16-byte aligned rows, and enough tiles to give every CU its two workgroups
-// 1 = 256 x 160, 2 = 128 x 160 (same pipeline, for grids the 256-row tile cannot fill), 0 = not eligible
+// 1 = 256 x 160, 4 = 256 x 128 (N a multiple of 128 but not of 160), 0 = not eligible; 2 / 3 are experiment variants
 int gemm_wide_pick(const GemmArgs& a) {
   if (a.out_mode != OUT_BF16) return 0;
   if (a.act == ACT_GEGLU && (a.N % 160 != 0 || a.resid || a.rowvec)) return 0;
   if ((a.N & 7) || (a.ld_out & 7) || (a.resid && (a.ld_res & 7))) return 0;
+  if (a.N % 160 != 0 && a.N % 128 == 0) {       // 128 / 256 / 512 / 1024 output channels (the VAE): the 256 x 128 sibling
+    if (a.act == ACT_GEGLU) return 0;
+    return (long)((a.M + 255) / 256) * (a.N / 128) >= 448 ? 4 : 0;
+  }
   if (a.N % 160 != 0 && a.N < 640) return 0;
   const long nt = (a.N + 159) / 160;
   // the 128-row sibling (variant 2) is kept for experiments only: at equal tile size the 64-deep two-stage kernel of
@@ -376,6 +382,7 @@ static int wide_launch_t(GemmArgs a, hipStream_t s) {
 
 int gemm_wide_launch(GemmArgs a, hipStream_t s, int variant) {
   if (variant == 3) return wide_launch_t<256, 320, 4, 4>(a, s);
+  if (variant == 4) return wide_launch_t<256, 128, 2, 3>(a, s);
   return variant == 2 ? wide_launch_t<128, 160, 2, 3>(a, s) : wide_launch_t<256, 160, 2, 3>(a, s);
 }
 

@@ -125,7 +125,8 @@ def sample_inputs(bsz, olists, seed):
 
 @pytest.mark.parametrize("name,bsz,ol,scales,steps", [("fitb_full_ddim10", 2, [[3, 0, 5, 6], [7, 8, 9, 0]], (12.0, 4.0, 5.0), 10),
                                                       ("gor_full_ddim10", 1, [[0, 0, 0, 0]], (12.0, 4.0, 5.0), 10),
-                                                      ("fitb_cate_hist", 2, [[3, 0, 5, 6], [0, 8, 9, 2]], (7.5, 3.0, 1.0), 6)])
+                                                      ("fitb_cate_hist", 2, [[3, 0, 5, 6], [0, 8, 9, 2]], (7.5, 3.0, 1.0), 6),
+                                                      ("mix_full_pndm10", 2, [[0, 0, 5, 6], [7, 0, 0, 0]], (12.0, 4.0, 5.0), 10)])
 def test_difashion_fashion_generation_from_raw_inputs(name, bsz, ol, scales, steps, unet):
     rec = load(f"sample_{name}.npz")
     olists = torch.tensor(ol)
@@ -133,7 +134,8 @@ def test_difashion_fashion_generation_from_raw_inputs(name, bsz, ol, scales, ste
     if not torch.equal(init, rec["init_latents"]):
         pytest.skip("torch CPU RNG stream differs from the capture container")
     args = types.SimpleNamespace(use_history=True, use_mutual_guidance=True, eta=0.1)
-    m = DiFashion(args, vae=IdentityVAE(), unet=unet, fashion_encoder=encoder(rec), noise_scheduler=da.DDIMScheduler(),
+    sched = da.PNDMScheduler() if str(rec["sched"]) == "pndm" else da.DDIMScheduler()       # the reference default is PNDM (difashion.py:64)
+    m = DiFashion(args, vae=IdentityVAE(), unet=unet, fashion_encoder=encoder(rec), noise_scheduler=sched,
                   text_encoder=TableText(), tokenizer=ZeroTok())
     d = lambda t: t.to(DEV)
     hist_dev = {u: TensorKeyDict({c: d(v) for c, v in h.items()}) for u, h in hist.items()}

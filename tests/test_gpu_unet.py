@@ -150,3 +150,22 @@ def test_unet_sd15_full_size_matches_oracle():
     report["out"] = rel_err(out.cpu(), ref)
     print("sd15", {k: f"{v:.2e}" for k, v in report.items()})
     assert all(v <= TOL for v in report.values()), report
+
+
+@pytest.mark.timeout(900)
+def test_unet_sd2base_full_size_matches_oracle():
+    """SD-2-base shape (865.9 M parameters: linear projections, 1024-wide text states, head dim 64 at every level), B=1."""
+    cfg = unet_ref.SD2BASE
+    params = unet_ref.init_params(cfg, seed=0)
+    x, _ = inputs(cfg, 1, 321)
+    e = torch.randn(1, 77, cfg.cross_attention_dim, generator=torch.Generator().manual_seed(322))
+    t = torch.tensor([731])
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(params, cfg, x, t, e)
+    m = hip_unet(cfg, params, max_batch=1)
+    del params
+    with torch.no_grad():
+        out = m(x.to(DEV), t.to(DEV), e.to(DEV)).sample
+    err = rel_err(out.cpu(), ref)
+    print("sd2base", f"{err:.2e}")
+    assert err <= TOL

@@ -368,6 +368,7 @@ def main():
         attn = classes["attention"]
         if attn["ms"] > 0:
             out["attention_mfma_frac"] = round(attn["flops"] / (attn["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK, 4)
+            out["attention_frac_of_sustained"] = round(attn["flops"] / (attn["ms"] * 1e-3) / 1e12 / MFMA_BF16_SUSTAINED, 4)
         gn = classes["groupnorm"]
         if gn["ms"] > 0:
             out["groupnorm_hbm_frac"] = round(gn["bytes"] / (gn["ms"] * 1e-3) / 1e9 / HBM_PEAK, 4)

@@ -5,7 +5,7 @@ Compute lives in ``csrc/libdifashion_hip.so`` (C ABI: ``include/difashion_hip.h`
 the Python host side mirroring the reference interface.  Importing the package does not need a GPU;
 running any op does, and fails loudly if the library was not built (no CPU fallback).
 """
-from . import _lib, data, prompts
+from . import _lib, data, evalio, prompts
 from ._lib import DfhError
 from .mutual import MutualEncoder
 from .pipeline import OutfitSampler, guidance_plan, sample_outfits, sampling_tables, train_forward, training_tables

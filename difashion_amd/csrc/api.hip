@@ -1,5 +1,7 @@
 // extern "C" surface of libdifashion_hip.so (declared in include/difashion_hip.h): error plumbing and
 // the op-level entry points.  The U-Net context entry points live in unet.hip.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -86,11 +88,16 @@ int dfh_prof_end(dfh_prof_class* out, int max_classes) {
     std::strncpy(out[i].name, names[i], sizeof(out[i].name) - 1);
   }
   if (hipDeviceSynchronize() != hipSuccess) { dfh::set_error("hipDeviceSynchronize failed in dfh_prof_end"); return -2; }
+  // DFH_PROF_DUMP=<file>: one line per launch (class, algorithmic flops, algorithmic bytes, ms) for per-shape tables
+  const char* dump_path = std::getenv("DFH_PROF_DUMP");
+  FILE* dump = dump_path ? std::fopen(dump_path, "w") : nullptr;
   for (const auto& r : dfh::g_recs) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
     out[r.cls].launches += 1; out[r.cls].ms += ms; out[r.cls].flops += r.flops; out[r.cls].bytes += r.bytes;
+    if (dump) std::fprintf(dump, "%s %.0f %.0f %.6f\n", names[r.cls], r.flops, r.bytes, ms);
   }
+  if (dump) std::fclose(dump);
   dfh::g_recs.clear();
   return dfh::PC_COUNT;
 }

@@ -508,8 +508,15 @@ struct TileInfo { int bm, bn; };
 // variant ids (force_tile - 1):
 //   0: 256x160 8 waves 3 stages   1: 256x128 8 waves 3 stages   2: 128x64 4 waves 3 stages
 //   3: 128x160 4 waves 2 stages   4: 128x128 4 waves 2 stages
-constexpr TileInfo kTiles[5] = {{256, 160}, {256, 128}, {128, 64}, {128, 160}, {128, 128}};
-constexpr int kNumTiles = 5;
+//   5: 128x160 EIGHT waves (4 x 2, 32 x 80 each) 2 stages, external id 10 (ids 6-9 are the wide kernel) -- the default
+//      128 x 160 kernel: issuing a k-step's 36 LDS-DMA pieces costs a wave ~100 cycles apiece during which it issues no
+//      MFMA, so with one wave per SIMD (a 4-wave workgroup alone on its CU: the 256-tile launches of the 16x16 level) a
+//      k-step takes 0.93 us against 0.29 us of MFMA work; two waves per SIMD overlap the two (0.75 us; 12.6 / 25.0 / 69.2
+//      vs 15.0 / 28.3 / 78.5 us on 4096 x 1280 x {320, 1280, 5120}), and at two workgroups per CU (122 VGPRs: 16 waves
+//      fit) it still wins 4-5 % (scripts/gemm_deepring_probe.py).  A 4-stage ring on the 4-wave tile gained nothing.
+constexpr TileInfo kTiles[6] = {{256, 160}, {256, 128}, {128, 64}, {128, 160}, {128, 128}, {128, 160}};
+constexpr int kNumTiles = 5;                      // ids 1..5 of force_tile; the eight-wave 128 x 160 variant is id 10
+constexpr int kEightWave = 5;
 
 int launch_variant(int tile, const GemmArgs& a, hipStream_t s) {
   switch (tile) {
@@ -517,6 +524,7 @@ int launch_variant(int tile, const GemmArgs& a, hipStream_t s) {
     case 1: return launch_tile<256, 128, 4, 2, 3>(a, s);
     case 2: return launch_tile<128, 64, 2, 2, 3>(a, s);
     case 3: return launch_tile<128, 160, 2, 2, 2>(a, s);
+    case 5: return launch_tile<128, 160, 4, 2, 2>(a, s);
     default: return launch_tile<128, 128, 2, 2, 2>(a, s);
   }
 }
@@ -540,7 +548,7 @@ int gemm_pick_split(const GemmArgs& a, int* tile_out) {
   int tile;
   if (a.N <= 64 && !geglu) tile = 2;
   else if (a.M > 128 && a.M <= 1024 && gemm_count_ksteps(a) >= 64) tile = n160 ? 0 : 1;
-  else tile = n160 ? 3 : 4;
+  else tile = n160 ? kEightWave : 4;   // same-box A/B over the whole step: linear class 7.65 -> 7.33 ms, conv3x3 6.92 -> 6.87 ms
   const TileInfo ti = kTiles[tile];
   const int blocks = ((a.M + ti.bm - 1) / ti.bm) * ((a.N + ti.bn - 1) / ti.bn);
   const int ksteps = gemm_count_ksteps(a);
@@ -580,6 +588,8 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
   int tile;
   int split = gemm_pick_split(a, &tile);
   // microbench / tests: tile id 6 = the 256 x 160 wide kernel, 7 = its 128 x 160 sibling
+  const bool force_deep = force_tile == 10;
+  if (force_deep) { tile = kEightWave; force_tile = 0; }
   const int force_wide = force_tile > kNumTiles ? force_tile - kNumTiles : 0;
   if (force_wide) force_tile = 0;
   if (force_tile > 0) { DFH_REQUIRE(force_tile <= kNumTiles, "unknown tile variant"); tile = force_tile - 1; }
@@ -610,7 +620,7 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     ProfScope ps(a.ntaps ? PC_CONV3 : PC_LINEAR, 2.0 * a.M * a.N * kreal, abytes + (double)a.N * kreal * 2.0 + obytes, stream);
     const bool wide_ok = split == 1 && a.out_mode == OUT_BF16 && (a.act != ACT_GEGLU || a.N % 160 == 0) && (a.N & 7) == 0 &&
                          (a.ld_out & 7) == 0 && (!a.resid || (a.ld_res & 7) == 0);
-    const int wide = !wide_ok ? 0 : (force_wide ? force_wide : ((force_tile == 0 && force_split == 0) ? gemm_wide_pick(a) : 0));
+    const int wide = (!wide_ok || force_deep) ? 0 : (force_wide ? force_wide : ((force_tile == 0 && force_split == 0) ? gemm_wide_pick(a) : 0));
     if (wide) rc = gemm_wide_launch(a, stream, wide);
     else rc = launch_variant(tile, a, stream);
   }

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 # ----------------------------------------------------------------------------- GEMM (linear / 1x1 conv)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])  # every tile / pipeline-depth variant of gemm.hip; 6-9 = gemm_wide.hip
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])  # every tile / pipeline-depth variant of gemm.hip; 6-9 = gemm_wide.hip; 10 = eight-wave 128x160
 @pytest.mark.parametrize("glds", [1])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (128, 160, 64), (77 * 3, 64, 768), (16, 1280, 200), (4, 256, 2048)])
 def test_gemm_plain(tile, glds, M, N, K):
@@ -100,7 +100,7 @@ def test_gemm_transposed_outputs():
     (64, 4, 16, 1, 0),      # conv_out shape class
     (128, 128, 2, 1, 0),    # 2x2 level of the tiny configs: every tap hits padding somewhere
 ])
-@pytest.mark.parametrize("glds", [0, 1, 4, 6, 7, 8, 9])   # here: forced tile variant (0 = heuristic, 1 = 256x160 ring, 4 = 128x160 2-stage, 6 = wide)
+@pytest.mark.parametrize("glds", [0, 1, 4, 6, 7, 8, 9, 10])   # here: forced tile variant (0 = heuristic, 1 = 256x160 ring, 4 = 128x160 2-stage, 6 = wide)
 def test_conv3x3(cin, cout, H, stride, ups, glds):
     B = 2
     x = bf(rnd(B, cin, H, H, seed=20))

@@ -126,6 +126,7 @@ def run_train(args, da, _lib, ddist, rank, world, dev):
     unet, enc = build_models(dev, args.config)
     unet.train(); enc.train()
     opt = da.FusedAdamW(list(unet.parameters()) + list(enc.parameters()), lr=1e-5, weight_decay=1e-2, max_grad_norm=1.0)
+    ddist.broadcast_parameters(opt.flat_param)          # replicas start identical (DDP's construction-time broadcast)
     ema = da.EMAModel(unet.parameters())
     sched = da.DDIMScheduler()
     kw = train_inputs(dev, unet.config.cross_attention_dim, rank, args.outfits)

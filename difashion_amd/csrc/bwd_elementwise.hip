@@ -1,6 +1,8 @@
 // Elementwise / layout kernels of the training step (reference: DiFashion/train.py:691-716 --
 // accelerator.backward, clip_grad_norm_, AdamW, EMA -- and the autograd of the glue in
 // DiFashion/models/difashion.py:160-267).  HBM-bound; bf16 data as 16-byte vectors, fp32 state as float4.
+#include <mutex>
+#include <unordered_map>
 #include "dfh_common.h"
 #include "bwd_elementwise.h"
 
@@ -219,14 +221,35 @@ __global__ void assemble_bwd_kernel(const float* __restrict__ dx, const unsigned
 }
 
 // ---- optimizer (train.py:586-593,700-711) ---------------------------------------------------------------------
-__global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+// *out += sum(g^2), bit-reproducible: per-block partials in a fixed order, summed in index order by whichever block arrives
+// last (ticket counter) -- no float atomics.  Data-parallel replicas derive their clip coefficient from this number: with an
+// atomic accumulation they drift apart in the last bits after every step (tests/test_gpu_ddp.py).
+__global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out, float* __restrict__ partials,
+                             unsigned* __restrict__ counter) {
   __shared__ float red[4];
+  __shared__ bool last;
   float s = 0.f;
   for (long i = gtid(); i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    __threadfence();                                             // release: the partial is visible before the ticket
+    last = atomicAdd(counter, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();                                               // acquire: every other block's partial
+  float t = 0.f;
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) t += ((const volatile float*)partials)[i];
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *out += (red[0] + red[1]) + (red[2] + red[3]);
+    *counter = 0u;                                               // ready for the next launch on this stream
+  }
 }
 // torch.optim.AdamW step (decoupled weight decay), gradient pre-scaled by clip_coef = min(1, max_norm / (norm + 1e-6))
 // read from device memory so the clip needs no host synchronisation
@@ -322,10 +345,26 @@ int mse_bwd_launch(const float* pred, const float* target, const float* w, float
 int assemble_bwd_launch(const float* dx, const unsigned char* mutual_real, float* dmutual, int rows, int CL, float eta, hipStream_t s) {
   EW_LAUNCH(assemble_bwd_kernel, (long)rows * CL, dx, mutual_real, dmutual, rows, CL, eta);
 }
+constexpr unsigned SUMSQ_MAX_BLOCKS = 2048;
+// per-stream scratch of sumsq_kernel: SUMSQ_MAX_BLOCKS partials + the ticket counter (zeroed once; the kernel resets it)
+static float* sumsq_scratch_for(hipStream_t stream) {
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, float*> table;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = table.find(stream);
+  if (it != table.end()) return it->second;
+  float* p = nullptr;
+  if (hipMalloc((void**)&p, (SUMSQ_MAX_BLOCKS + 1) * sizeof(float)) != hipSuccess) return nullptr;
+  if (hipMemset(p, 0, (SUMSQ_MAX_BLOCKS + 1) * sizeof(float)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+  table[stream] = p;
+  return p;
+}
 int sumsq_launch(const float* g, long n, float* out, hipStream_t s) {
+  float* scratch = sumsq_scratch_for(s);
+  DFH_REQUIRE(scratch != nullptr, "sumsq scratch allocation failed");
   ProfScope ps(PC_OPTIM, 0.0, 4.0 * n, s);
-  const unsigned blocks = (unsigned)std::min<long>((n + EW_BLOCK - 1) / EW_BLOCK, 2048);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(EW_BLOCK), 0, s, g, n, out);
+  const unsigned blocks = (unsigned)std::max<long>(1, std::min<long>((n + EW_BLOCK - 1) / EW_BLOCK, SUMSQ_MAX_BLOCKS));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(EW_BLOCK), 0, s, g, n, out, scratch, (unsigned*)(scratch + SUMSQ_MAX_BLOCKS));
   return check_launch("sumsq_kernel");
 }
 int adamw_launch(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,

@@ -85,6 +85,14 @@ def all_reduce_gradients(flat_grad: torch.Tensor, average: bool = True) -> torch
     return flat_grad
 
 
+def broadcast_parameters(flat_param: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """Make every replica start from rank ``src``'s weights (what DDP does when it wraps a module, train.py:611): ONE
+    broadcast of the flat fp32 parameter buffer (training.FusedAdamW.flat_param -- the parameters are views of it)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(flat_param, src=src)
+    return flat_param
+
+
 def gather_outfit_latents(local: torch.Tensor, counts: Sequence[int]) -> torch.Tensor:
     """Concatenate every rank's finished latents in rank order (not on the timed path).
     ``counts[r]`` = number of latent rows rank r holds."""

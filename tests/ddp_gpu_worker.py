@@ -1,0 +1,94 @@
+"""Worker of tests/test_gpu_ddp.py: launched as 2 ranks by torch.distributed.run, BOTH on cuda:0 (the GPU box has one device),
+process group on gloo (which all-reduces CUDA tensors through the host; RCCL refuses two ranks on one device).  Everything
+above the collective is the product's data-parallel training step as it runs under RCCL: native backward into the flat
+gradient buffer, ONE all-reduce of that buffer, the fused clip + AdamW + EMA on every rank.
+
+Checks: (1) the averaged gradient of two half-batches equals the gradient of the whole batch computed
+by one process (same kernels, other summation order: RTOL), (2) the loss of the whole batch is the mean of the shard losses,
+(3) after the optimizer step the replicas hold bit-identical parameters and EMA shadows.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as tdist
+
+import difashion_amd as da
+from difashion_amd import dist as ddist
+from difashion_amd.pipeline import train_forward
+from tests.helpers import GLUE_CFG, glue_unet_params, load
+from tests.test_gpu_train import batch_kwargs, make_encoder
+from tests.test_gpu_unet import hip_unet
+
+RTOL = 2e-2
+DEV = "cuda:0"
+
+
+def shard(kw, rank, world, olen=4):
+    """Outfits [rank * b/world, (rank+1) * b/world) of the batch: per-outfit tensors by outfit, per-item tensors by 4 items."""
+    b = kw["timesteps_outfit"].shape[0]
+    lo, hi = rank * b // world, (rank + 1) * b // world
+    out = dict(kw)
+    out["timesteps_outfit"] = kw["timesteps_outfit"][lo:hi]
+    for k in ("latents", "noise", "hist_latents", "ehs", "random_p", "random_p_cate", "dropout_mask"):
+        if kw.get(k) is not None:
+            out[k] = kw[k][lo * olen:hi * olen]
+    return out
+
+
+def build(rec):
+    unet = hip_unet(GLUE_CFG, glue_unet_params(), max_batch=32).train()
+    enc = make_encoder(rec)
+    opt = da.FusedAdamW(list(unet.parameters()) + list(enc.parameters()), lr=2e-4, weight_decay=1e-2, max_grad_norm=1.0)
+    ddist.broadcast_parameters(opt.flat_param)        # the unused category embedding is initialised from each process's RNG
+    ema = da.EMAModel(unet.parameters(), decay=0.9999)
+    return unet, enc, opt, ema
+
+
+def main():
+    rank, world, _ = ddist.init("gloo")
+    assert world == 2 and tdist.get_backend() == "gloo"
+    torch.cuda.set_device(0)
+    rec = load("train_b8_snr5.npz")
+    sched = da.DDIMScheduler(prediction_type=str(rec["pred_type"]))
+    kw = batch_kwargs(rec, DEV)
+
+    # whole batch, one process, no collective: the reference gradient
+    unet, enc, opt, _ = build(rec)
+    loss_full = train_forward(unet, enc, sched, **kw)
+    loss_full.backward()
+    g_full = opt.flat_grad.clone()
+    del unet, enc, opt
+
+    # the product's data-parallel step on this rank's half of the outfits
+    unet, enc, opt, ema = build(rec)
+    mine = shard(kw, rank, world)
+    loss = da.train_step(unet, enc, sched, opt, ema_unet=ema, **mine)
+    g_dp = opt.flat_grad                       # all-reduced (averaged) gradient; the lazy zero_grad keeps the buffer
+    err = float((g_dp - g_full).norm() / g_full.norm())
+    mean_loss = ddist.sum_over_ranks(float(loss)) / world
+    print(f"[rank {rank}] shard loss {float(loss):.5f} mean {mean_loss:.5f} full {float(loss_full):.5f}  grad rel err {err:.3e}", flush=True)
+    assert err < RTOL, err
+    assert abs(mean_loss - float(loss_full)) < 2e-3 * abs(float(loss_full)) + 1e-5
+
+    # replicas stay bit-identical: compare a 64-bit digest of parameters and EMA shadows across the ranks
+    def digest(t):
+        return t.view(torch.int32).to(torch.int64).sum().item() if t.dtype == torch.float32 else 0
+    mine_d = torch.tensor([digest(opt.flat_param), digest(ema.flat)], dtype=torch.int64)
+    both = [torch.zeros_like(mine_d) for _ in range(world)]
+    tdist.all_gather(both, mine_d)
+    assert torch.equal(both[0], both[1]), both
+    # a second step keeps them identical and still reduces ONE flat buffer
+    da.train_step(unet, enc, sched, opt, ema_unet=ema, **mine)
+    mine_d = torch.tensor([digest(opt.flat_param), digest(ema.flat)], dtype=torch.int64)
+    tdist.all_gather(both, mine_d)
+    assert torch.equal(both[0], both[1]), both
+    torch.cuda.synchronize()
+    tdist.barrier()
+    if rank == 0:
+        print("DDP_GPU_OK", flush=True)
+
+
+if __name__ == "__main__":
+    main()

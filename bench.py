@@ -157,7 +157,7 @@ def run_train(args, da, _lib, ddist, rank, world, dev):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": f"BASELINE configs[2]: training step, {args.outfits} outfits x 4 items per GPU, {args.config} shape in_channels=8, "
                                   "min-SNR MSE loss, mutual + history conditioning, clip 1.0 + AdamW + EMA",
-                      "unet_batch": items, "parallelism": f"data-parallel x{world}, one flat-buffer RCCL all-reduce per step"},
+                      "unet_batch": items, "parallelism": f"data-parallel x{world}, gradients all-reduced over RCCL in 256 MB ranges of the packed arena, overlapped with the backward walk"},
            "loss": round(float(loss), 5), "hbm_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
     if classes is not None:
         tot_f = sum(v["flops"] for v in classes.values())

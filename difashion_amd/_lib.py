@@ -107,6 +107,9 @@ SIGNATURES = {
     "dfh_unet_pack_train": (_i, [_vp, C.POINTER(_vp), _i, _vp]),
     "dfh_unet_forward_train": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "dfh_unet_backward": (_i, [_vp, _vp, _vp, C.POINTER(_vp), _i, _i, _vp]),
+    "dfh_unet_backward_begin": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "dfh_unet_backward_next": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz), _vp]),
+    "dfh_unet_backward_finish": (_i, [_vp, C.POINTER(_vp), _i, _i, _vp]),
     "dfh_gemm_partial_floats": (_sz, [C.POINTER(GemmDesc)]),
     "dfh_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "dfh_gemm_wgrad": (_i, [C.POINTER(GemmDesc), _vp, _i, _vp, _i, _i, _vp]),
@@ -193,6 +196,14 @@ def call(name: str, *args):
     """Call a status-returning entry point; raise DfhError with the library's message on failure."""
     rc = getattr(raw(), name)(*args)
     if name not in _NO_STATUS and SIGNATURES[name][0] is _i and rc != 0:
+        raise DfhError(f"{name} failed ({rc}): {last_error()}")
+    return rc
+
+
+def call_count(name: str, *args):
+    """Call an entry point that returns a count (>= 0) or a negative status."""
+    rc = getattr(raw(), name)(*args)
+    if rc < 0:
         raise DfhError(f"{name} failed ({rc}): {last_error()}")
     return rc
 

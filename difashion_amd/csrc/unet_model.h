@@ -126,6 +126,10 @@ struct dfh_unet {
   int forward_train(const void* sample, int sample_bf16, const float* timestep, const void* ehs, int ehs_bf16, float* out, int B,
                     hipStream_t s);
   int backward(const float* d_out, float* d_sample, float* const* master_grads, int count, hipStream_t s, int overwrite);
+  // the same backward in pieces, for a data-parallel caller that all-reduces finished ranges of grad16 while the walk goes on
+  int backward_begin(const float* d_out, float* d_sample, size_t bucket_floats, hipStream_t s);
+  int backward_next(size_t* lo, size_t* hi, hipStream_t s);             // 1: grad16[lo, hi) is final; 0: tape done; < 0: error
+  int backward_finish(float* const* master_grads, int count, hipStream_t s, int overwrite);
   int pack_train(const float* const* master, int count, hipStream_t s);
   ~dfh_unet();
 

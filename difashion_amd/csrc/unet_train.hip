@@ -16,6 +16,7 @@
 //   * 288 GB HBM: every activation of the step is kept (no recomputation / gradient checkpointing); layer-internal
 //     gradient buffers come from a stack allocator and overlap across layers.
 //   * nothing is allocated per step: a dry run of the same forward + tape sizes the workspace.
+#include <array>
 #include <functional>
 #include <memory>
 
@@ -37,6 +38,14 @@ struct dfh_unet::TrainRun {
   std::vector<char> gstate;
   const float* d_out = nullptr; float* d_sample = nullptr;   // set by backward()
   float* dtemb_all = nullptr; size_t dtemb_bytes = 0;
+  // weight-gradient write ranges per tape entry (recorded by the dry run of the tape): a bucket of grad16 is final once the
+  // LOWEST tape index that writes into it has run (the tape runs from the back)
+  int cur_entry = -1;
+  std::vector<std::array<size_t, 3>> writes;                  // {tape index, first float, end float}
+  // segmented backward
+  size_t bucket = 0; int next_entry = -1;
+  std::vector<int> bucket_last;                                // per bucket: lowest tape index writing into it (-1: never written)
+  std::vector<std::pair<size_t, size_t>> ready;                // finished ranges not handed out yet
 
   bf16_t* w16(const Mat& m) const { return u->arena16 + m.off; }
   bf16_t* w16t(const Mat& m) const { return u->arena16t + m.off; }
@@ -102,7 +111,11 @@ struct dfh_unet::TrainRun {
     w.dbias = bias ? g32(*bias) : nullptr;
     w.overwrite = 1;          // every packed matrix has exactly one weight-gradient launch per backward: no memset, no RMW
     w.partial = partial; w.partial_cap = partial_cap / sizeof(float);     // shares the split-K slab region of the GEMMs
-    if (dry) { partial_need = std::max(partial_need, dfh::wgrad_partial_floats(w) * sizeof(float)); return; }
+    if (dry) {
+      partial_need = std::max(partial_need, dfh::wgrad_partial_floats(w) * sizeof(float));
+      if (cur_entry >= 0) writes.push_back({(size_t)cur_entry, w_off, w_off + (size_t)f.N * f.ldw});
+      return;
+    }
     rc = dfh::wgrad_launch(w, s);
   }
   void colsum(const bf16_t* Y, int ldy, int N, int groups, int rows_per_group, float* out, int ld_out) {
@@ -548,7 +561,7 @@ int dfh_unet::forward_train(const void* sample, int sample_bf16, const float* ti
   // size the regions for this batch with a dry walk, then lay them out in the bound workspace
   TrainRun plan; plan.u = this; plan.B = B; plan.dry = true;
   plan.walk(nullptr, 0, nullptr, nullptr, 0, nullptr);
-  for (auto it = plan.tape.rbegin(); it != plan.tape.rend(); ++it) (*it)();
+  for (int i = (int)plan.tape.size() - 1; i >= 0; --i) { plan.cur_entry = i; plan.tape[i](); }
   const size_t partial = (plan.partial_need + 255) & ~(size_t)255;
   const size_t persist_bytes = (plan.persist.peak + 255) & ~(size_t)255, gtemp_bytes = (plan.gtemp.peak + 255) & ~(size_t)255;
   const size_t head = head_bytes_for(B, partial);
@@ -565,26 +578,75 @@ int dfh_unet::forward_train(const void* sample, int sample_bf16, const float* ti
   r.gtemp.base = tws + head + persist_bytes;
   (void)hipMemsetAsync(r.zero, 0, 256, s);
   r.walk(sample, sample_bf16, timestep, ehs, ehs_bf16, out);
+  r.writes = std::move(plan.writes);          // same walk, same tape: entry i of the dry tape is entry i of this one
+  DFH_REQUIRE(r.rc || r.tape.size() == plan.tape.size(), "dry and real tape differ");
   return r.rc;
 }
 
 int dfh_unet::backward(const float* d_out, float* d_sample, float* const* master_grads, int count, hipStream_t s, int overwrite) {
-  DFH_REQUIRE(tr != nullptr && !tr->tape.empty(), "dfh_unet_backward needs a preceding dfh_unet_forward_train");
   DFH_REQUIRE(count == (int)params.size(), "parameter count mismatch");
+  if (int rc = backward_begin(d_out, d_sample, a16 ? a16 : 1, s); rc < 0) return rc;
+  size_t lo, hi;
+  for (;;) {
+    const int rc = backward_next(&lo, &hi, s);
+    if (rc < 0) { tr->tape.clear(); tr->bucket = 0; return rc; }      // one backward per forward, also after an error
+    if (rc == 0) break;
+  }
+  return backward_finish(master_grads, count, s, overwrite);
+}
+
+int dfh_unet::backward_begin(const float* d_out, float* d_sample, size_t bucket_floats, hipStream_t s) {
+  DFH_REQUIRE(tr != nullptr && !tr->tape.empty(), "dfh_unet_backward needs a preceding dfh_unet_forward_train");
+  DFH_REQUIRE(bucket_floats > 0, "bucket size must be positive");
   TrainRun& r = *tr;
   r.s = s; r.d_out = d_out; r.d_sample = d_sample;
   std::fill(r.gstate.begin(), r.gstate.end(), 0);
-  (void)hipMemsetAsync(grad32, 0, a32 * sizeof(float), s);     // bias / affine gradients accumulate with atomics
+  (void)hipMemsetAsync(grad32, 0, a32 * sizeof(float), s);
   (void)hipMemsetAsync(r.dtemb_all, 0, r.dtemb_bytes, s);
-  for (auto it = r.tape.rbegin(); it != r.tape.rend() && !r.rc; ++it) (*it)();
-  r.tape.clear();           // one backward per forward
+  r.bucket = bucket_floats;
+  const size_t nb = (a16 + bucket_floats - 1) / bucket_floats;
+  r.bucket_last.assign(nb, -1);
+  for (const auto& w : r.writes)
+    for (size_t b = w[1] / bucket_floats; b <= (w[2] - 1) / bucket_floats && b < nb; ++b)
+      if (r.bucket_last[b] < 0 || (int)w[0] < r.bucket_last[b]) r.bucket_last[b] = (int)w[0];
+  r.ready.clear();
+  r.next_entry = (int)r.tape.size() - 1;
+  return (int)r.tape.size();
+}
+
+int dfh_unet::backward_next(size_t* lo, size_t* hi, hipStream_t s) {
+  DFH_REQUIRE(tr != nullptr && tr->bucket > 0 && lo && hi, "dfh_unet_backward_begin must come first");
+  TrainRun& r = *tr;
+  r.s = s;
+  while (r.ready.empty() && r.next_entry >= 0 && !r.rc) {
+    const int i = r.next_entry--;
+    r.tape[i]();
+    // buckets whose last writer just ran; neighbours that finish together are handed out as one range
+    for (size_t b = 0; b < r.bucket_last.size(); ++b) {
+      if (r.bucket_last[b] != i) continue;
+      const size_t first = b * r.bucket, end = std::min(a16, (b + 1) * r.bucket);
+      if (!r.ready.empty() && r.ready.back().second == first) r.ready.back().second = end;
+      else r.ready.push_back({first, end});
+    }
+  }
   if (r.rc) return r.rc;
-  // packed fp32 gradients -> master-layout .grad (+=), one launch over the op table
+  if (r.ready.empty()) return 0;
+  *lo = r.ready.back().first; *hi = r.ready.back().second;
+  r.ready.pop_back();
+  return 1;
+}
+
+int dfh_unet::backward_finish(float* const* master_grads, int count, hipStream_t s, int overwrite) {
+  DFH_REQUIRE(tr != nullptr && tr->bucket > 0, "dfh_unet_backward_begin must come first");
+  DFH_REQUIRE(tr->next_entry < 0 && tr->ready.empty(), "dfh_unet_backward_next has not reached the end of the tape");
+  DFH_REQUIRE(count == (int)params.size(), "parameter count mismatch");
+  TrainRun& r = *tr;
+  r.tape.clear(); r.bucket = 0;
+  if (r.rc) return r.rc;
   tab_unpack.clear();
   for (const PackOp& op : packs) {
     float* g = master_grads ? master_grads[op.param] : nullptr;
     if (!g) continue;
-    // overwrite: the caller states that the gradients hold nothing yet (first micro-batch after zero_grad): plain stores
     if (op.kind == PK_VEC) tab_unpack.add(g, TAB_UNPACK_VEC, (long)op.dst, op.N, 0, 0, op.geglu, overwrite, 0, 0, op.N);
     else if (op.kind == PK_MAT) tab_unpack.add(g, TAB_UNPACK_MAT, (long)op.dst, op.N, op.K, op.ldw, op.row_off, op.col_off, op.geglu, overwrite, (long)op.N * op.K);
     else tab_unpack.add(g, TAB_UNPACK_CONV, (long)op.dst, op.N, op.K, op.ldw, overwrite, op.col_off, 0, op.cin_pad, (long)op.N * op.K * 9);
@@ -646,6 +708,19 @@ int dfh_unet_backward(dfh_unet* u, const float* d_out, float* d_sample, float* c
                       void* stream) {
   DFH_REQUIRE(u && d_out, "null argument");
   return u->backward(d_out, d_sample, master_grads, count, (hipStream_t)stream, overwrite ? 1 : 0);
+}
+
+int dfh_unet_backward_begin(dfh_unet* u, const float* d_out, float* d_sample, size_t bucket_floats, void* stream) {
+  DFH_REQUIRE(u && d_out, "null argument");
+  return u->backward_begin(d_out, d_sample, bucket_floats, (hipStream_t)stream);
+}
+int dfh_unet_backward_next(dfh_unet* u, size_t* lo, size_t* hi, void* stream) {
+  DFH_REQUIRE(u, "null argument");
+  return u->backward_next(lo, hi, (hipStream_t)stream);
+}
+int dfh_unet_backward_finish(dfh_unet* u, float* const* master_grads, int count, int overwrite, void* stream) {
+  DFH_REQUIRE(u, "null argument");
+  return u->backward_finish(master_grads, count, (hipStream_t)stream, overwrite ? 1 : 0);
 }
 
 }  // extern "C"

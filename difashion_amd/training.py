@@ -98,6 +98,17 @@ class FusedAdamW(torch.optim.Optimizer):
                     off, n = self._slices[id(p)]
                     p.grad = self.flat_grad[off:off + n].view(p.shape)
 
+    def ranges_excluding(self, module) -> List[tuple]:
+        """Merged [start, end) element ranges of the flat buffers that hold parameters NOT owned by ``module``."""
+        own = {id(p) for p in module.parameters()}
+        runs = []
+        for off, n in sorted(v for k, v in self._slices.items() if k not in own):
+            if runs and runs[-1][1] == off:
+                runs[-1][1] = off + n
+            else:
+                runs.append([off, off + n])
+        return [tuple(r) for r in runs]
+
     def grad_norm(self) -> torch.Tensor:
         """Global L2 norm of the gradients at the last step() (device scalar; no host sync)."""
         return self._sumsq.sqrt()[0]
@@ -316,7 +327,12 @@ def train_step(unet, fashion_encoder, scheduler, optimizer: FusedAdamW, *, lr_sc
     from .pipeline import train_forward
     loss = train_forward(unet, fashion_encoder, scheduler, **batch)
     loss.backward()
-    _dist.all_reduce_gradients(optimizer.flat_grad)
+    if getattr(unet, "grads_synced", False):
+        # the U-Net averaged its gradients inside backward (overlapped with the walk): reduce what lies outside it
+        for lo, hi in optimizer.ranges_excluding(unet):
+            _dist.all_reduce_gradients(optimizer.flat_grad[lo:hi])
+    else:
+        _dist.all_reduce_gradients(optimizer.flat_grad)
     # EMA of the U-Net folded into the AdamW launch when it covers the head of the flat parameter buffer
     first = next(iter(unet.parameters()))
     fuse_ema = (ema_unet is not None and ema_unet.flat.device.type == "cuda"

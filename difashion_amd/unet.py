@@ -259,8 +259,8 @@ class UNet2DConditionModel(nn.Module):
         dev = self.device
         ctx = self._ctx
         a16t = torch.zeros(lib.dfh_unet_arena16t_bytes(ctx), dtype=torch.uint8, device=dev)
-        g16 = torch.empty(lib.dfh_unet_grad16_bytes(ctx), dtype=torch.uint8, device=dev)
-        g32 = torch.empty(lib.dfh_unet_grad32_bytes(ctx), dtype=torch.uint8, device=dev)
+        g16 = torch.zeros(lib.dfh_unet_grad16_bytes(ctx), dtype=torch.uint8, device=dev)     # padding between the packed
+        g32 = torch.zeros(lib.dfh_unet_grad32_bytes(ctx), dtype=torch.uint8, device=dev)     # matrices travels through the all-reduce
         wsb = lib.dfh_unet_train_workspace_bytes(ctx, batch)
         self._train_buffers = None          # release the previous workspace before allocating the next
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
@@ -353,9 +353,60 @@ class UNet2DConditionModel(nn.Module):
         # backward may overwrite instead of accumulate into (no 3.4 GB memset, no read-modify-write)
         overwrite = 1 if getattr(self, "grads_cleared", False) else 0
         self.grads_cleared = False
-        _lib.call("dfh_unet_backward", self._ctx, _lib.ptr(d_out), _lib.ptr(d_sample) if need_dsample else None, arr,
-                  len(plist), overwrite, _lib.stream_ptr())
+        self.grads_synced = False
+        import torch.distributed as tdist
+        if self.sync_grads_in_backward and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+            self._backward_overlapped(d_out, d_sample, arr, len(plist), overwrite, tdist)
+            self.grads_synced = True      # training.train_step then all-reduces only what lies outside this module
+        else:
+            _lib.call("dfh_unet_backward", self._ctx, _lib.ptr(d_out), _lib.ptr(d_sample) if need_dsample else None, arr,
+                      len(plist), overwrite, _lib.stream_ptr())
         return d_sample
+
+    # data-parallel: gradients averaged over the ranks INSIDE backward (DDP semantics; set False around the non-final
+    # micro-batches of a gradient-accumulation step, like DDP.no_sync(), and reduce once with dist.all_reduce_gradients)
+    sync_grads_in_backward = True
+    grads_synced = False
+    grad_bucket_bytes = 256 << 20         # few, large buckets: xGMI rings are per-link bound, not latency bound
+
+    def _backward_overlapped(self, d_out, d_sample, grad_ptrs, count, overwrite, tdist):
+        """The backward walk in pieces (dfh_unet_backward_begin / _next / _finish): whenever a range of the packed fp32
+        gradient arena is final -- no layer still to run writes into it -- it is all-reduced on a side stream while the
+        walk continues on the compute stream; the un-pack into the master ``.grad`` tensors then reads the averages.
+        Replaces DDP's per-parameter autograd hooks + 25 MB buckets (train.py:611,699) with ~14 ranges of 256 MB."""
+        lib, dev = _lib.raw(), d_out.device
+        g16 = self._train_buffers[1].view(torch.float32)
+        g32 = self._train_buffers[2].view(torch.float32)
+        world = tdist.get_world_size()
+        compute = torch.cuda.current_stream(dev)
+        if getattr(self, "_comm_stream", None) is None:
+            self._comm_stream = torch.cuda.Stream(device=dev)
+        comm = self._comm_stream
+        sp = _lib.stream_ptr()
+        _lib.call_count("dfh_unet_backward_begin", self._ctx, _lib.ptr(d_out), _lib.ptr(d_sample) if d_sample is not None else None,
+                        max(1, self.grad_bucket_bytes // 4), sp)
+        lo, hi = C.c_size_t(0), C.c_size_t(0)
+
+        def reduce_range(t):
+            ev = torch.cuda.Event()
+            ev.record(compute)                    # everything the walk has enqueued so far, i.e. the writers of this range
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev)
+                # RCCL: enqueued behind ``comm``, which then waits for the collective -- the host returns at once and goes
+                # on enqueuing the next layers on the compute stream.  (gloo, CPU-staged, blocks the host instead.)
+                tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
+                t.div_(world)
+
+        while True:
+            rc = lib.dfh_unet_backward_next(self._ctx, C.byref(lo), C.byref(hi), sp)
+            if rc < 0:
+                raise _lib.DfhError(f"dfh_unet_backward_next failed ({rc}): {_lib.last_error()}")
+            if rc == 0:
+                break
+            reduce_range(g16[lo.value:hi.value])
+        reduce_range(g32[: g32.numel()])          # bias / affine gradients: complete only now, a few MB
+        compute.wait_stream(comm)
+        _lib.call("dfh_unet_backward_finish", self._ctx, grad_ptrs, count, overwrite, sp)
 
     # ------------------------------------------------------------------ forward
     def forward(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor,

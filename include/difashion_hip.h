@@ -126,6 +126,18 @@ int dfh_unet_forward_train(dfh_unet* u, const void* sample, int sample_bf16, con
 int dfh_unet_backward(dfh_unet* u, const float* d_out, float* d_sample, float* const* master_grads, int count, int overwrite,
                       void* stream);
 
+/* The same backward in pieces, for data-parallel training: the caller all-reduces finished ranges of the packed fp32
+ * gradient arena (the ``grad16`` buffer of dfh_unet_bind_train) on a second stream while the walk continues -- the
+ * reference's DDP buckets (accelerate / torch DDP around train.py:611,699) without an autograd hook per parameter.
+ *   begin  : arms the walk; ``bucket_floats`` = granularity of the ranges (floats of grad16).  Returns the tape length.
+ *   next   : runs layers from the back of the tape until some range of grad16 is FINAL (no later layer writes into it),
+ *            returns 1 with [*lo, *hi) in floats, 0 when the tape is exhausted (every range has been handed out), < 0 on error.
+ *   finish : un-packs grad16 / grad32 (whatever they hold by then, e.g. the all-reduced average) into the master
+ *            gradients exactly as dfh_unet_backward does.  dfh_unet_backward == begin + next until 0 + finish. */
+int dfh_unet_backward_begin(dfh_unet* u, const float* d_out, float* d_sample, size_t bucket_floats, void* stream);
+int dfh_unet_backward_next(dfh_unet* u, size_t* lo, size_t* hi, void* stream);
+int dfh_unet_backward_finish(dfh_unet* u, float* const* master_grads, int count, int overwrite, void* stream);
+
 /* Copies a named NHWC bf16 intermediate of the LAST forward into ``dst`` as fp32 NCHW (layer-level
  * parity tests).  Names: "conv_in", "down0".."down3", "mid", "up0".."up3". */
 int dfh_unet_debug_tap(dfh_unet* u, const char* name, float* dst, size_t dst_floats, void* stream);

@@ -61,16 +61,29 @@ def main():
     g_full = opt.flat_grad.clone()
     del unet, enc, opt
 
-    # the product's data-parallel step on this rank's half of the outfits
-    unet, enc, opt, ema = build(rec)
+    # the product's data-parallel step on this rank's half of the outfits: (a) gradients averaged INSIDE backward, range by
+    # range on a side stream while the walk continues (the default; small ranges here so the tiny U-Net has many), (b) one
+    # all-reduce of the flat buffer after backward
     mine = shard(kw, rank, world)
-    loss = da.train_step(unet, enc, sched, opt, ema_unet=ema, **mine)
-    g_dp = opt.flat_grad                       # all-reduced (averaged) gradient; the lazy zero_grad keeps the buffer
-    err = float((g_dp - g_full).norm() / g_full.norm())
-    mean_loss = ddist.sum_over_ranks(float(loss)) / world
-    print(f"[rank {rank}] shard loss {float(loss):.5f} mean {mean_loss:.5f} full {float(loss_full):.5f}  grad rel err {err:.3e}", flush=True)
-    assert err < RTOL, err
-    assert abs(mean_loss - float(loss_full)) < 2e-3 * abs(float(loss_full)) + 1e-5
+    for overlapped in (False, True):
+        unet, enc, opt, ema = build(rec)
+        unet.sync_grads_in_backward = overlapped
+        unet.grad_bucket_bytes = 64 << 10
+        loss = da.train_step(unet, enc, sched, opt, ema_unet=ema, **mine)
+        assert unet.grads_synced == overlapped
+        g_dp = opt.flat_grad                   # averaged gradient; the lazy zero_grad keeps the buffer
+        err = float((g_dp - g_full).norm() / g_full.norm())
+        mean_loss = ddist.sum_over_ranks(float(loss)) / world
+        print(f"[rank {rank}] overlapped={overlapped} shard loss {float(loss):.5f} mean {mean_loss:.5f} full {float(loss_full):.5f}  "
+              f"grad rel err {err:.3e}", flush=True)
+        assert err < RTOL, err
+        assert abs(mean_loss - float(loss_full)) < 2e-3 * abs(float(loss_full)) + 1e-5
+        if not overlapped:
+            g_flat = g_dp.clone()
+            del unet, enc, opt, ema
+    err2 = float((g_dp - g_flat).norm() / g_flat.norm())      # the two exchange schemes against each other
+    print(f"[rank {rank}] overlapped vs flat all-reduce: {err2:.3e}", flush=True)
+    assert err2 < 1e-5, err2
 
     # replicas stay bit-identical: compare a 64-bit digest of parameters and EMA shadows across the ranks
     def digest(t):

@@ -192,8 +192,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[tt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = rows_max(mx);          // over the lane's four key groups (lanes l, l^16, l^32, l^48): two VALU row swaps
       mx *= c;             // c > 0: max commutes with the scale
       // deferred max (wave-uniform): rescale only if some query's max grew by more than the threshold
       if (__any(!(mx - m_run[qt] <= RESCALE_THR))) {
@@ -249,8 +248,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
       l = __shfl(oacc[qt][D / 16][(D % 16) % 4], ((D % 16) / 4) * 16 + fr, 64);
     } else {
       l = l_run[qt];
-      l += __shfl_xor(l, 16, 64);
-      l += __shfl_xor(l, 32, 64);
+      l = rows_sum(l);
     }
     const float inv = 1.0f / l;
     const int q = q0 + qt * 16 + fr;

@@ -58,10 +58,40 @@ DFH_DEVICE float erf_as_f(float x) {
 }
 DFH_DEVICE float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f)); }
 
+// Value of lane (l ^ 16) / (l ^ 32): gfx950's v_permlane{16,32}_swap exchange 16- / 32-lane rows between two registers in
+// the VALU (a few cycles); __shfl_xor goes through ds_bpermute_b32, an LDS round trip of ~100+ cycles on the critical path
+// of every softmax tile.  swap(x, x) leaves {x of the even row, x of the odd row} of each row pair in both rows.
+DFH_DEVICE float lane_xor16(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const bool odd_row = (__lane_id() & 16) != 0;
+  return __uint_as_float(odd_row ? r[0] : r[1]);
+}
+DFH_DEVICE float lane_xor32(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const bool upper = (__lane_id() & 32) != 0;
+  return __uint_as_float(upper ? r[0] : r[1]);
+}
+// max / sum over the four 16-lane rows (lanes l, l^16, l^32, l^48): no select needed, both halves of a swap are combined
+DFH_DEVICE float rows_max(float x) {
+  unsigned u = __float_as_uint(x);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = __float_as_uint(fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])));
+  r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+DFH_DEVICE float rows_sum(float x) {
+  unsigned u = __float_as_uint(x);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = __float_as_uint(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 DFH_DEVICE float wave_sum(float v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return rows_sum(v);
 }
 
 // ---- host side ------------------------------------------------------------------------------

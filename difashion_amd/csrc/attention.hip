@@ -27,6 +27,8 @@
 #include "dfh_common.h"
 #include "attention.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int KV_TILE = 64;
@@ -90,11 +92,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   // When D is not a multiple of 16 the V^T tile has spare rows: row D holds ONES, so the P.V MFMA
   // also accumulates the softmax denominator l = sum_k p (in O^T row D) -- no per-score VALU add.
   constexpr bool ONES_ROW = (D % 16) != 0;
-  auto load_tile = [&](int kv0) {   // global -> registers (zero beyond D / beyond Nk)
+  // full_c = std::true_type: the tile lies entirely inside Nk -- no per-key bounds predicates, no ragged-tail masking
+  auto load_tile = [&](int kv0, auto full_c) {   // global -> registers (zero beyond D / beyond Nk)
+    constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
       kreg[i] = uint4{0, 0, 0, 0};
-      if (kv0 + k_key[i] < a.Nk && k_slot[i] * 8 < D)
+      if ((FULL || kv0 + k_key[i] < a.Nk) && k_slot[i] * 8 < D)
         kreg[i] = *(const uint4*)(Kb + (long)(kv0 + k_key[i]) * a.ldk + k_slot[i] * 8);
     }
 #pragma unroll
@@ -104,9 +108,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
       const int k0 = kv0 + slot * 8;
       uint4 v = uint4{0, 0, 0, 0};
       if (ONES_ROW && row == D) v = uint4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};   // bf16 1.0 x8
-      if (idx < DF * 128 && row < D && k0 < a.Nk) {
+      if (idx < DF * 128 && row < D && (FULL || k0 < a.Nk)) {
         v = *(const uint4*)(Vb + (long)row * a.ldvt + k0);
-        if (k0 + 8 > a.Nk) {   // ragged tail (cross-attention, Nk = 77): zero the padding keys
+        if (!FULL && k0 + 8 > a.Nk) {   // ragged tail (cross-attention, Nk = 77): zero the padding keys
           const int valid = a.Nk - k0;
           uint32_t* w = (uint32_t*)&v;
 #pragma unroll
@@ -142,14 +146,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
   const float c = a.scale * 1.44269504088896340736f;   // fold log2(e): p = 2^(s*c - m)
 
   const int ntiles = (a.Nk + KV_TILE - 1) / KV_TILE;
-  load_tile(0);
+  load_tile(0, std::false_type{});
   store_tile(0);
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
+  // One key tile.  fast_c = std::true_type: this tile AND the next are entirely inside Nk -- the instantiation carries no
+  // ragged-tail code at all (left in one body, hipcc hoists the 40 key-index adds of the masking branch into every
+  // iteration: a quarter of the loop's VALU instructions at d = 40, where the loop is VALU-bound).
+  auto tile = [&](int t, auto fast_c) {
+    constexpr bool FAST = decltype(fast_c)::value;
     const int kv0 = t * KV_TILE;
-    const bool more = t + 1 < ntiles;
-    if (more) load_tile(kv0 + KV_TILE);       // in flight while this tile computes
+    const bool more = FAST || t + 1 < ntiles;
+    if (FAST) load_tile(kv0 + KV_TILE, std::true_type{});      // in flight while this tile computes
+    else if (more) load_tile(kv0 + KV_TILE, std::false_type{});
     const unsigned char* Ks = smem + (t & 1) * G::BUF;
     const unsigned char* Vs = Ks + G::K_BYTES;
 
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
       }
     }
     // lane (fr = query, fg) holds for tile tt, reg r: key kv0 + (tt>>1)*32 + fg*8 + (tt&1)*4 + r
-    const bool ragged = kv0 + KV_TILE > a.Nk;
+    const bool ragged = !FAST && kv0 + KV_TILE > a.Nk;
     bf16x8_t pf[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -238,7 +247,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
     }
     if (more) store_tile((t + 1) & 1);   // the other buffer: last read one barrier ago
     __syncthreads();
-  }
+  };
+  const int nfast = a.Nk / KV_TILE - 1;      // tiles whose successor is a full tile too
+  int t = 0;
+  for (; t < nfast; ++t) tile(t, std::true_type{});
+  for (; t < ntiles; ++t) tile(t, std::false_type{});
 
   // ---- normalise and store: lane holds O[q = fr][d = f*16 + fg*4 + r]
 #pragma unroll

@@ -15,6 +15,7 @@
 // (X^T fragments: head-dim rows, tile rows as contraction) are read transposed from the same row-major
 // LDS tiles with ds_read_b64_tr_b16.  Accumulators are transposed (out^T[d][col]) so a lane finishes with
 // 4 consecutive head-dim values of its own query / key: 8-byte stores, no cross-lane traffic.
+#include <type_traits>
 #include "dfh_common.h"
 #include "attention.h"
 
@@ -55,7 +56,7 @@ DFH_DEVICE bf16x8_t tr_frag(const unsigned char* tile, int m0, int d0, int L) {
 
 // KV_SIDE = false: columns are queries (dQ pass); true: columns are keys (dK / dV pass)
 template <int D, bool KV_SIDE, int NT>
-__global__ __launch_bounds__(256) void attention_bwd_kernel(const AttnBwdArgs a) {
+__global__ __launch_bounds__(256, ((D <= 40 && !KV_SIDE) ? 3 : 1)) void attention_bwd_kernel(const AttnBwdArgs a) {
   using G = BwdGeom<D>;
   constexpr int KS = G::KS, DF = G::DF, STR = G::STR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -113,20 +114,22 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const AttnBwdArgs a)
   }
   uint4 r1[KS], r2[KS];
   float rl = 0.f, rd = 0.f;
-  auto load_tile = [&](int row0) {
+  // full_c = std::true_type: the tile lies entirely inside nrows (no bounds predicates)
+  auto load_tile = [&](int row0, auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
       r1[i] = uint4{0, 0, 0, 0}; r2[i] = uint4{0, 0, 0, 0};
       const int r = row0 + s_row[i];
-      if (r < nrows && s_slot[i] * 8 < D) {
+      if ((FULL || r < nrows) && s_slot[i] * 8 < D) {
         r1[i] = *(const uint4*)(X1 + (long)r * ldx1 + s_slot[i] * 8);
         r2[i] = *(const uint4*)(X2 + (long)r * ldx2 + s_slot[i] * 8);
       }
     }
     if (KV_SIDE && tid < XT) {     // row statistics: +inf lse for rows beyond Nq makes their P exactly 0
       const int r = row0 + tid;
-      rl = r < nrows ? lse[r] : INFINITY;
-      rd = r < nrows ? dlt[r] : 0.f;
+      rl = (FULL || r < nrows) ? lse[r] : INFINITY;
+      rd = (FULL || r < nrows) ? dlt[r] : 0.f;
     }
   };
   auto store_tile = [&](int buf) {
@@ -151,13 +154,17 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const AttnBwdArgs a)
   const float c = a.scale * 1.44269504088896340736f;
 
   const int ntiles = (nrows + XT - 1) / XT;
-  load_tile(0);
+  load_tile(0, std::false_type{});
   store_tile(0);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
+  // fast_c = std::true_type: this row tile and the next lie entirely inside nrows -- an instantiation without bounds
+  // predicates or tail masking (see attention.hip: left in one body they are hoisted into every iteration)
+  auto tile = [&](int t, auto fast_c) {
+    constexpr bool FAST = decltype(fast_c)::value;
     const int row0 = t * XT;
-    const bool more = t + 1 < ntiles;
-    if (more) load_tile(row0 + XT);
+    const bool more = FAST || t + 1 < ntiles;
+    if (FAST) load_tile(row0 + XT, std::true_type{});
+    else if (more) load_tile(row0 + XT, std::false_type{});
     const unsigned char* T1 = smem + (t & 1) * G::BUF;
     const unsigned char* T2 = T1 + G::TILE;
     const float* st = (const float*)(T2 + G::TILE);
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const AttnBwdArgs a)
             const int lr = ch * 32 + fg * 8 + u * 4 + r;      // row inside the tile
             float L, Dl;
             if (KV_SIDE) { L = st[lr]; Dl = st[XT + lr]; }
-            else { L = (row0 + lr < nrows) ? col_l[nt] : INFINITY; Dl = col_d[nt]; }
+            else { L = (FAST || row0 + lr < nrows) ? col_l[nt] : INFINITY; Dl = col_d[nt]; }
             const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(tS[nt][u][r], c, -L));
             p[u * 4 + r] = pv;
             ds[u * 4 + r] = pv * (tU[nt][u][r] - Dl);
@@ -223,7 +230,11 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const AttnBwdArgs a)
       }
     if (more) store_tile((t + 1) & 1);
     __syncthreads();
-  }
+  };
+  const int nfast = nrows / XT - 1;
+  int t = 0;
+  for (; t < nfast; ++t) tile(t, std::true_type{});
+  for (; t < ntiles; ++t) tile(t, std::false_type{});
 
   // ---- store: lane holds out[col = fr][d = f*16 + fg*4 + r]
 #pragma unroll

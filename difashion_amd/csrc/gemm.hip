@@ -90,7 +90,11 @@ DFH_DEVICE void kiter_next(const GemmArgs& a, KIter& it) {
 template <int N> DFH_DEVICE void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NSTAGE>
+// LEAN: the launch has ONE plain K segment whose length is a multiple of 64 (every linear / 1x1 of the U-Net): a k-step's
+// sources are the previous k-step's plus 128 bytes, so the k-loop keeps one 64-bit pointer per staging piece and adds a
+// constant -- no segment iterator, no per-piece predicates / selects / multiplies (the generic loop spends ~190 SALU and
+// ~125 VALU instructions per k-step beside 20 MFMAs; with 2 waves per SIMD that, not the MFMA pipe, paces the loop).
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool LEAN = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
   constexpr int NWV = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;       // per-wave output tile
@@ -207,6 +211,36 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a
     }
   };
 
+  // LEAN staging: per-piece source pointers (the zero page with a zero stride for rows beyond M / N)
+  const bf16_t* lp_a[IA]; const bf16_t* lp_w[IB];
+  unsigned ls_a[IA], ls_w[IB];
+  if (LEAN) {
+    const unsigned k0 = (unsigned)ks_begin * BK + (unsigned)sslot * 8;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      const bool ok = a_pix[i] >= 0;
+      lp_a[i] = ok ? psrc0 + ((size_t)(unsigned)a_pix[i] * (unsigned)a.p_c[0] + k0) : a.zero;
+      ls_a[i] = ok ? BK : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const bool ok = w_row[i] >= 0;
+      lp_w[i] = ok ? a.W + ((size_t)(unsigned)w_row[i] + k0) : a.zero;
+      ls_w[i] = ok ? BK : 0;
+    }
+  }
+  auto issue_lean = [&](int buf) {
+    unsigned char* As = smem + buf * STAGE + wave * 1024;
+    unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) { glds(lp_a[i], As + i * NWV * 1024); lp_a[i] += ls_a[i]; }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      if (i * NWV + wave >= PB) continue;             // wave-uniform
+      glds(lp_w[i], Bs + i * NWV * 1024); lp_w[i] += ls_w[i];
+    }
+  };
+
   f32x4_t acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -235,13 +269,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a
   }
 
   if (nk > 0) {
-    KIter it = kiter_at(a, ks_begin);
+    KIter it;
+    if (!LEAN) it = kiter_at(a, ks_begin);
     int issued = 0;
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s) {
       if (s < nk) {
-        if (s) kiter_next(a, it);
-        issue_stage(it, s);
+        if (LEAN) issue_lean(s);
+        else {
+          if (s) kiter_next(a, it);
+          issue_stage(it, s);
+        }
         ++issued;
       }
     }
@@ -256,9 +294,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a
       __builtin_amdgcn_s_barrier();          // stage t visible to all waves; all waves done with k-step t-1
       asm volatile("" ::: "memory");
       if (issued < nk) {                      // refill the buffer k-step t-1 just released
-        kiter_next(a, it);
         int nb = buf - 1; if (nb < 0) nb += NSTAGE;
-        issue_stage(it, nb);
+        if (LEAN) issue_lean(nb);
+        else { kiter_next(a, it); issue_stage(it, nb); }
         ++issued;
       }
       const unsigned char* As = smem + buf * STAGE;
@@ -488,19 +526,19 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(const GemmArgs a) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool LEAN = false>
 int launch_tile(const GemmArgs& a, hipStream_t stream) {
   constexpr int lds = NSTAGE * (BM + BN) * BK * 2;
   static_assert(lds <= 160 * 1024, "LDS ring exceeds the CU's 160 KiB");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE>,
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, LEAN>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   dim3 grid(ntm * ntn, 1, a.ksplit);
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE>), grid, dim3(WM * WN * 64), lds, stream, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, LEAN>), grid, dim3(WM * WN * 64), lds, stream, a);
   return dfh::check_launch("gemm_bf16_kernel");
 }
 
@@ -518,13 +556,21 @@ constexpr TileInfo kTiles[6] = {{256, 160}, {256, 128}, {128, 64}, {128, 160}, {
 constexpr int kNumTiles = 5;                      // ids 1..5 of force_tile; the eight-wave 128 x 160 variant is id 10
 constexpr int kEightWave = 5;
 
+// one plain K segment of a multiple of 64 channels, W rows long enough: the LEAN k-loop applies
+bool lean_plain(const GemmArgs& a) {
+  // same-box A/B (scripts/gemm_lean_probe.py): 4096 x 1280 x {1280, 5120} 26.8 -> 25.7 / 77 -> 71 us (one workgroup per CU),
+  // 0-3 % at two workgroups per CU -- the LDS-DMA issue itself (~100 cycles per 1-KB piece), not its address arithmetic,
+  // is what paces the loop
+  return a.ntaps == 0 && a.nplain == 1 && a.p_c[0] % BK == 0 && a.p_c[0] > 0;
+}
+
 int launch_variant(int tile, const GemmArgs& a, hipStream_t s) {
   switch (tile) {
     case 0: return launch_tile<256, 160, 4, 2, 3>(a, s);
     case 1: return launch_tile<256, 128, 4, 2, 3>(a, s);
     case 2: return launch_tile<128, 64, 2, 2, 3>(a, s);
     case 3: return launch_tile<128, 160, 2, 2, 2>(a, s);
-    case 5: return launch_tile<128, 160, 4, 2, 2>(a, s);
+    case 5: return lean_plain(a) ? launch_tile<128, 160, 4, 2, 2, true>(a, s) : launch_tile<128, 160, 4, 2, 2>(a, s);
     default: return launch_tile<128, 128, 2, 2, 2>(a, s);
   }
 }

@@ -71,6 +71,18 @@ def sum_over_ranks(value: float) -> float:
     return float(t.item())
 
 
+def gather_mean(value: torch.Tensor) -> torch.Tensor:
+    """Mean over the ranks of a per-rank tensor (the logged loss: ``accelerator.gather(loss.repeat(b)).mean()``,
+    train.py:695, with equal per-rank batches).  Returns a new tensor; nothing on the optimisation path depends on it."""
+    out = value.detach().clone().float()
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() != "nccl":
+            out = out.cpu()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        out = out / dist.get_world_size()
+    return out
+
+
 def all_reduce_gradients(flat_grad: torch.Tensor, average: bool = True) -> torch.Tensor:
     """Data-parallel gradient exchange of the training step (the reference: accelerate's DDP wrapper around
     accelerator.backward, train.py:611/:699).  Every rank holds a full replica and a different slice of the global

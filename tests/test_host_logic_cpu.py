@@ -145,6 +145,9 @@ def _grad_worker(rank, world, port, q):
     flat_grad = flat_grad.reshape(-1).contiguous()
     ddist.all_reduce_gradients(flat_grad)
     weight = weight - 0.1 * flat_grad.view(6, 3)
+    logged = ddist.gather_mean(torch.tensor(float(r + 1)))       # the logged loss: mean over the ranks (train.py:695)
+    assert float(logged) == 1.5
+    ddist.broadcast_parameters(weight)                           # no-op on identical replicas, exercises the collective
     q.put((r, flat_grad.tolist(), weight.reshape(-1).tolist()))
     dist.destroy_process_group()
 

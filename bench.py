@@ -289,11 +289,17 @@ def main():
     import difashion_amd as da
     from difashion_amd import _lib, dist as ddist
 
-    rank, world, local = ddist.init("nccl" if args.gpus > 1 else None)
-    if world != args.gpus:
-        log(f"[bench] WARNING: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    # RCCL ("nccl") under the launcher; DFH_DIST_BACKEND=gloo lets the multi-rank flow be exercised on a box with fewer GPUs
+    # than ranks (tests/test_gpu_ddp.py: two ranks sharing the one device) -- never the measured configuration
+    backend = os.environ.get("DFH_DIST_BACKEND", "nccl")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    local_dev = int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count()) if backend != "nccl" else None
+    rank, world, local = ddist.init(backend if args.gpus > 1 else None)
+    if world != args.gpus:
+        log(f"[bench] WARNING: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if local_dev is not None:
+        local = local_dev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

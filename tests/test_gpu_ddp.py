@@ -25,3 +25,23 @@ def test_two_rank_training_step_matches_the_whole_batch():
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     print(out.stdout[-3000:], out.stderr[-3000:])
     assert out.returncode == 0 and "DDP_GPU_OK" in out.stdout
+
+
+def test_bench_multi_rank_flow_on_one_device():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, barrier + max-over-ranks timing, rank 0 prints
+    ONE JSON line), here with two ranks sharing the box's single GPU over gloo (DFH_DIST_BACKEND): the value is meaningless,
+    the flow is what is checked."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", DFH_DIST_BACKEND="gloo",
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    print(out.stdout[-2000:], out.stderr[-2000:])
+    assert out.returncode == 0
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["value"] > 0 and rec["scaling"] == "weak"
+    assert rec["roofline"]["bound"] == "mfma" and rec["cpu_baseline"] is None

@@ -162,6 +162,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a
   const bool hi_wave = wave < PB_REM;
 
   const unsigned cc = (unsigned)a.conv_c;
+  // Lean tap staging (stride-1 3x3 convs over whole 64-channel slices), see gemm_wide.hip: centre-pixel offset + 9-bit
+  // tap-validity mask per staging piece, fixed for the kernel
+  const bool leanc = a.ntaps == 9 && a.stride == 1 && a.ups == 0 && !a.pad0 && (a.conv_c % BK) == 0;
+  unsigned c_pre[IA], c_mask[IA];
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    c_pre[i] = 0; c_mask[i] = 0;
+    if (leanc && a_pix[i] >= 0) {
+      c_pre[i] = (unsigned)(a_bbase[i] + (a_y[i] + 1) * a.Win + (a_x[i] + 1)) * cc + (unsigned)sslot * 8;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = a_y[i] + t / 3, xx = a_x[i] + t % 3;
+        if ((unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win) c_mask[i] |= 1u << t;
+      }
+    }
+  }
   // Plain-segment pointers pinned in SGPRs: left to itself hipcc re-loads them from the kernel-argument segment with an
   // s_load + s_waitcnt lgkmcnt(0) in EVERY k-step of a linear layer (it selects the argument offset, not the value).
   const bf16_t* psrc0 = a.p_src[0];
@@ -178,7 +194,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a
     unsigned char* Bs = As + A_BYTES;
     const int ch = it.c0 + sslot * 8;                 // channel of this lane's 16-byte chunk
     const bool kin = ch < it.seglen;
-    if (it.seg < a.ntaps) {
+    if (it.seg < a.ntaps && leanc) {
+      const int ky = it.seg / 3, kx = it.seg - ky * 3;
+      const unsigned delta = (unsigned)(((ky - 1) * a.Win + (kx - 1)) * (int)cc + it.c0);     // wave-uniform
+      const unsigned bit = 1u << it.seg;
+#pragma unroll
+      for (int i = 0; i < IA; ++i)
+        glds((c_mask[i] & bit) ? a.conv_src + (c_pre[i] + delta) : a.zero, As + i * NWV * 1024);
+    } else if (it.seg < a.ntaps) {
       const int ky = it.seg / 3, kx = it.seg - ky * 3;
 #pragma unroll
       for (int i = 0; i < IA; ++i) {

@@ -121,6 +121,24 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
   const bool hi_wave = wave < PB_REM;
 
   const unsigned cc = (unsigned)a.conv_c;
+  // Lean tap staging (stride-1 3x3 convs over whole 32-channel slices: every resnet conv): the centre-pixel offset and a
+  // 9-bit tap-validity mask per staging piece are fixed for the kernel, so a k-step is one add, one bit test and the
+  // zero-page select per piece instead of the coordinate arithmetic and four bounds compares of the general path.
+  const bool leanc = a.ntaps == 9 && a.stride == 1 && a.ups == 0 && !a.pad0 && (a.conv_c % BKW) == 0;
+  unsigned c_pre[IA], c_mask[IA];
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    c_pre[i] = 0; c_mask[i] = 0;
+    if (leanc && a_pix[i] >= 0) {
+      const int cy = a_y[i] + 1, cx = a_x[i] + 1;                    // the output pixel = centre tap
+      c_pre[i] = (unsigned)(a_bbase[i] + cy * a.Win + cx) * cc + (unsigned)schunk * 8;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = a_y[i] + t / 3, xx = a_x[i] + t % 3;
+        if ((unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win) c_mask[i] |= 1u << t;
+      }
+    }
+  }
   const bf16_t* psrc0 = a.p_src[0];
   const bf16_t* psrc1 = a.p_src[1];
   asm volatile("" : "+s"(psrc0), "+s"(psrc1));      // keep them in SGPRs (see gemm.hip)
@@ -133,7 +151,14 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
     unsigned char* Bs = As + A_BYTES;
     const int ch = it.c0 + schunk * 8;
     const bool kin = ch < it.seglen;
-    if (it.seg < a.ntaps) {
+    if (it.seg < a.ntaps && leanc) {
+      const int ky = it.seg / 3, kx = it.seg - ky * 3;
+      const unsigned delta = (unsigned)(((ky - 1) * a.Win + (kx - 1)) * (int)cc + it.c0);     // wave-uniform
+      const unsigned bit = 1u << it.seg;
+#pragma unroll
+      for (int i = 0; i < IA; ++i)
+        glds((c_mask[i] & bit) ? a.conv_src + (c_pre[i] + delta) : a.zero, As + i * NWV * 1024);
+    } else if (it.seg < a.ntaps) {
       const int ky = it.seg / 3, kx = it.seg - ky * 3;
 #pragma unroll
       for (int i = 0; i < IA; ++i) {

@@ -114,6 +114,22 @@ def test_conv3x3(cin, cout, H, stride, ups, glds):
     gu.assert_close_bf16(gu.nchw(out.view(B, Ho, Ho, cout)), ref, f"conv {cin}->{cout}@{H} s{stride} u{ups}")
 
 
+@pytest.mark.parametrize("tile", [0, 1, 6, 10])
+@pytest.mark.parametrize("cin,H,W", [(64, 12, 20), (128, 5, 3), (192, 16, 1)])
+def test_conv3x3_lean_tap_staging_on_non_square_inputs(cin, H, W, tile):
+    """The lean tap staging (centre-pixel offset + 9-bit validity mask per staging piece) on inputs whose height and
+    width differ, incl. one-pixel-wide images where most taps of every pixel are padding; 3 images so that tiles straddle
+    image boundaries."""
+    B, cout = 3, 96
+    x = bf(rnd(B, cin, H, W, seed=23))
+    w = rnd(cout, cin, 3, 3, seed=24, scale=0.05)
+    bias = rnd(cout, seed=25)
+    out = gu.gemm(M=B * H * W, N=cout, W=gu.pack_conv(w), ldw=9 * cin, conv_src=gu.nhwc(x), conv_c=cin, batch=B,
+                  Hin=H, Win=W, stride=1, upsample=0, bias=bias, force_tile=tile)
+    ref = F.conv2d(x.float(), bf(w).float(), bias, padding=1)
+    gu.assert_close_bf16(gu.nchw(out.view(B, H, W, cout)), ref, f"conv {cin}->{cout}@{H}x{W} tile{tile}")
+
+
 @pytest.mark.parametrize("tile", [0, 6, 7, 8, 9])
 def test_conv3x3_with_fused_shortcut_and_temb(tile):
     """ResnetBlock2D tail: conv2(h) + conv_shortcut(cat(x, skip)) + biases, and conv1 + time embedding."""

@@ -27,6 +27,7 @@
 #include "dfh_common.h"
 #include "attention.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -300,10 +301,16 @@ int launch(const AttnArgs& a, hipStream_t stream) {
 
 namespace dfh {
 
+// attention_x32.hip: the 32x32x16 kernel for the long self-attention launches (d = 40 / 80)
+bool attention_x32_eligible(const AttnArgs& a);
+int attention_x32_launch(const AttnArgs& a, hipStream_t stream);
+
 int attention_launch(const AttnArgs& a, hipStream_t stream) {
   DFH_REQUIRE(a.Nq > 0 && a.Nk > 0 && a.B > 0 && a.H > 0, "empty attention");
   DFH_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 4 == 0, "leading dims must be 16-byte aligned");
   DFH_REQUIRE(a.ldvt >= ((a.Nk + 7) / 8) * 8, "V^T rows must be padded to a multiple of 8 keys");
+  static const bool x32_off = [] { const char* e = getenv("DFH_ATTN_X32"); return e && e[0] == '0'; }();   // A/B switch for the microbenchmarks
+  if (!x32_off && attention_x32_eligible(a)) return attention_x32_launch(a, stream);
   switch (a.D) {
     case 32: return launch<32>(a, stream);
     case 40: return launch<40>(a, stream);

@@ -1,0 +1,458 @@
+// Fused softmax(Q K^T / sqrt(d)) V on v_mfma_f32_32x32x16_bf16 for the U-Net's long self-attention launches
+// (SD-1.5: (N, d) = (4096, 40) and (1024, 80): 90 % of the attention time of a sampling step).
+// Reference call sites: diffusers Attention (attn1 of BasicTransformerBlock) reached via
+// DiFashion/models/difashion.py:249-253,518-523 (xformers memory_efficient_attention there, difashion.py:118).
+//
+// Why a second kernel (attention.hip stays for head dims > 80, short / ragged key ranges and the training LSE path it
+// was tuned for): at d = 40 the 16x16x32 kernel pads the contraction 40 -> 64 and spends 165 VALU instructions per 32 x 64
+// score tile -- the softmax VALU work, not the MFMA pipe, paces it (round-1 PMC: VALU active 70 %, MFMA busy 34 %).
+// This kernel removes both costs:
+//   * 32x32x16 MFMA: the contraction is padded to a multiple of 16 (40 -> 48), a 32x32x16 issues at 32 cycles
+//     (1024 flop/cycle/SIMD) where the 16x16x32 measured 19.5-20 (820 flop/cycle) -- profiles/r02/mfma_rate2.txt.
+//   * scores are computed transposed, S^T = K . Q^T (keys = rows): a lane owns ONE query (column lane & 31) and
+//     16 keys per 32-key block, so the softmax needs no cross-lane traffic, and the C layout of S^T IS the B layout of
+//     the P^T operand of O^T = V^T . P^T (lane half hi holds k-slots 8 hi .. 8 hi + 7 of every 16-key MFMA) once the K
+//     rows of a block are read in the order key = swap_bits_2_3(slot): probabilities never leave registers and need
+//     no permutes at all.
+//   * the two free contraction slots of the padding carry the softmax bookkeeping: K column d = D is 1.0 and
+//     Q column D is -m (the running max, kept bf16-exact), Q is pre-scaled by scale * log2(e) -> the MFMA delivers
+//     s * c - m directly: no multiply / subtract per score.  K column D+1 is 1.0 for keys beyond Nk and Q column D+1 is
+//     -30000 -> ragged key ranges are masked by the MFMA as well.  V^T row D is all ones, so O^T row D accumulates the
+//     softmax denominator: no per-score add.
+//   * what is left per score: one v_exp_f32, half a v_cvt_pk_bf16_f32, half a v_max3_f32 (the deferred-max check:
+//     the running max only moves when some score exceeds it by 2^8, a wave-uniform rare branch).
+//   * 4 waves x 64 queries (two 32-query blocks: every K / V^T fragment read feeds two MFMAs) = 256 queries per
+//     workgroup, ~250 VGPRs, two workgroups per CU: while one wave of a SIMD is in its exp / pack phase its neighbour
+//     issues MFMAs.  K / V^T tiles of 64 keys are double-buffered in LDS (issue-early / write-late register staging,
+//     one barrier per tile), 16-byte slots XOR-swizzled so every ds_read_b128 fragment read is conflict-free.
+#include "dfh_common.h"
+#include "attention.h"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int KVT = 64;               // keys per LDS tile (two 32-key MFMA blocks)
+constexpr float THR = 8.0f;           // deferred max: rescale when a score exceeds the running max by 2^8 (log2 domain)
+constexpr float MASK_Q = -30000.0f;   // Q-side value of the mask slot (bf16-representable to 3 digits; exp2 -> 0)
+
+template <int D> struct X32Geom {
+  static_assert(D % 8 == 0, "head dim must be a multiple of 8");
+  static constexpr int DCH = D / 8;                        // 16-byte data chunks per K row
+  static constexpr int KS = (D + 2 + 15) / 16;             // 16-deep contraction steps incl. the two bookkeeping slots
+  static constexpr int NCH = 2 * KS;                       // chunks per K row in LDS (data + pad chunk + zero chunks)
+  static constexpr int DB = (D + 1 + 31) / 32;             // 32-row blocks of O^T incl. the ones row
+  static constexpr int KROW = NCH <= 8 ? 128 : 256;        // K row stride (bytes)
+  static constexpr int K_BYTES = KVT * KROW;
+  static constexpr int VROWS = D + 2;                      // data rows, the ones row (D), the zero row (D + 1)
+  static constexpr int V_BYTES = VROWS * 128;
+  static constexpr int BUF = K_BYTES + V_BYTES;
+  static constexpr int PAD_KS = DCH / 2, PAD_HI = DCH & 1; // fragment (k-step, lane half) holding slots D, D + 1
+  static constexpr int NKI = (KVT * DCH + 255) / 256;      // K staging chunks per thread
+  static constexpr int NVI = (D * 8 + 255) / 256;          // V^T staging chunks per thread
+  static constexpr int LR = D % 32;                        // row of the softmax denominator inside O^T block D / 32
+  static constexpr int L_HI = (LR >> 2) & 1, L_REG = (LR & 3) | ((LR >> 3) << 2);
+  static_assert((D % 8) == 0 && (D + 1) / 8 == DCH, "slots D, D+1 must share one chunk");
+};
+
+template <int KROW> DFH_DEVICE int k_swz(int key) { return KROW == 128 ? ((key >> 1) & 7) : (key & 15); }
+DFH_DEVICE int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+// QB = 32-query blocks per wave (2: 256 queries per workgroup; 1: 128, for head dims whose accumulators would not fit)
+template <int D, int QB, int MINW>
+__global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs a) {
+  using G = X32Geom<D>;
+  constexpr int KS = G::KS, DB = G::DB, DCH = G::DCH, NCH = G::NCH, KROW = G::KROW, NKI = G::NKI, NVI = G::NVI;
+  constexpr int WQ = QB * 32;                              // queries per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, hi = lane >> 5;
+
+  // one (batch, head) per group of consecutive logical blocks, and consecutive logical blocks on ONE XCD: the 16 workgroups
+  // of a (batch, head) share its K / V^T through one L2 instead of fetching them on all eight
+  const int nqb = (a.Nq + 4 * WQ - 1) / (4 * WQ);
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lb / nqb, qblk = lb - bh * nqb;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int q0 = qblk * 4 * WQ + wave * WQ;
+
+  const bf16_t* Qb = a.Q + (long)b * a.Nq * a.ldq + h * D;
+  const bf16_t* Kb = a.K + (long)b * a.Nk * a.ldk + h * D;
+  const bf16_t* Vb = a.Vt + (long)b * (a.vt_bstride ? a.vt_bstride : (long)a.H * D * a.ldvt) + (long)h * D * a.ldvt;
+
+  // ---- Q fragments (B operand of S^T = K . Q^T): lane (query ql, half hi) holds d = 16 ks + 8 hi .. + 8,
+  //      pre-scaled by scale * log2(e); the pad chunk holds {-m, MASK_Q, 0 ...}
+  const float c = a.scale * 1.44269504088896340736f;
+  uint4 qf[QB][KS];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int q = q0 + qb * 32 + ql;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 v = uint4{0u, 0u, 0u, 0u};
+      const int ch = 2 * ks + hi;
+      if (ch < DCH && q < a.Nq) {
+        const uint4 raw = *(const uint4*)(Qb + (long)q * a.ldq + ch * 8);
+        float f[8];
+        unpack8(raw, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= c;
+        v = pack8(f);
+      } else if (ch == DCH) {
+        v.x = pack2bf(0.0f, MASK_Q);
+      }
+      qf[qb][ks] = v;
+    }
+  }
+
+  // ---- staging bookkeeping (fixed per thread).  Chunk ids wrap around the tile: the threads left over in the last round
+  //      re-stage a chunk another thread stages too (same bytes to the same address) -- no divergent branch in the loop
+  int k_key[NKI], k_goff[NKI], k_lds[NKI];
+#pragma unroll
+  for (int i = 0; i < NKI; ++i) {
+    const int idx = (tid + i * 256) % (KVT * DCH);
+    k_key[i] = idx / DCH;
+    const int ch = idx - k_key[i] * DCH;
+    k_goff[i] = k_key[i] * a.ldk + ch * 8;
+    k_lds[i] = k_key[i] * KROW + ((ch ^ k_swz<KROW>(k_key[i])) << 4);
+  }
+  int v_goff[NVI], v_lds[NVI], v_k0[NVI];
+#pragma unroll
+  for (int i = 0; i < NVI; ++i) {
+    const int idx = (tid + i * 256) % (D * 8);
+    const int row = idx >> 3, ch = idx & 7;
+    v_goff[i] = row * a.ldvt + ch * 8;
+    v_k0[i] = ch * 8;
+    v_lds[i] = G::K_BYTES + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+  }
+  uint4 kreg[NKI], vreg[NVI];
+
+  auto load_tile = [&](int kv0, auto full_c) {   // global -> registers (zeros beyond Nk)
+    constexpr bool FULL = decltype(full_c)::value;
+    const bf16_t* kt = Kb + (long)kv0 * a.ldk;
+    const bf16_t* vt = Vb + kv0;
+#pragma unroll
+    for (int i = 0; i < NKI; ++i) {
+      if (FULL) kreg[i] = *(const uint4*)(kt + k_goff[i]);
+      else {
+        kreg[i] = uint4{0u, 0u, 0u, 0u};
+        if (kv0 + k_key[i] < a.Nk) kreg[i] = *(const uint4*)(kt + k_goff[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NVI; ++i) {
+      if (FULL) vreg[i] = *(const uint4*)(vt + v_goff[i]);
+      else {
+        const int k0 = kv0 + v_k0[i];
+        uint4 v = uint4{0u, 0u, 0u, 0u};
+        if (k0 < a.Nk) {
+          v = *(const uint4*)(vt + v_goff[i]);
+          if (k0 + 8 > a.Nk) {   // ragged tail: zero the padding keys (they may hold anything, NaN included)
+            const int valid = a.Nk - k0;
+            uint32_t* w = (uint32_t*)&v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (e >= valid) w[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+          }
+        }
+        vreg[i] = v;
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {               // registers -> swizzled LDS image
+    unsigned char* Bs = smem + buf * G::BUF;
+#pragma unroll
+    for (int i = 0; i < NKI; ++i) *(uint4*)(Bs + k_lds[i]) = kreg[i];
+#pragma unroll
+    for (int i = 0; i < NVI; ++i) *(uint4*)(Bs + v_lds[i]) = vreg[i];
+  };
+  // constant parts of a buffer: K chunks DCH .. NCH-1 ({1, mask, 0 ..} then zeros), V^T ones row and zero row.
+  // first_masked = first key of the tile that lies beyond Nk (KVT: none)
+  auto store_const = [&](int buf, int first_masked) {
+    unsigned char* Ks = smem + buf * G::BUF;
+    unsigned char* Vs = Ks + G::K_BYTES;
+    for (int idx = tid; idx < KVT * (NCH - DCH); idx += 256) {
+      const int key = idx / (NCH - DCH), ch = DCH + (idx - key * (NCH - DCH));
+      uint4 v = uint4{0u, 0u, 0u, 0u};
+      if (ch == DCH) v.x = key >= first_masked ? 0x3f803f80u : 0x00003f80u;      // {1.0, mask}
+      *(uint4*)(Ks + key * KROW + ((ch ^ k_swz<KROW>(key)) << 4)) = v;
+    }
+    if (tid < 16) {
+      const int row = D + (tid >> 3), ch = tid & 7;
+      const uint32_t w = row == D ? 0x3f803f80u : 0u;
+      *(uint4*)(Vs + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = uint4{w, w, w, w};
+    }
+  };
+
+  // ---- fragment read offsets (fixed per lane)
+  const int kkey = swap23(ql);                    // K row of S^T row slot ql inside a 32-key block
+  int k_off[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) k_off[ks] = kkey * KROW + (((2 * ks + hi) ^ k_swz<KROW>(kkey)) << 4);
+  int v_row[DB], v_sw[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db) {
+    const int pr = min(db * 32 + ql, D + 1);      // rows beyond the ones row read the zero row
+    v_row[db] = pr * 128; v_sw[db] = (pr >> 1) & 7;
+  }
+
+  f32x16_t o[DB][QB];
+  float m_run[QB];
+  const int ntiles = (a.Nk + KVT - 1) / KVT;
+  const int tail_valid = a.Nk - (ntiles - 1) * KVT;          // valid keys of the last tile (KVT when Nk % 64 == 0)
+  const int nfast = a.Nk / KVT - 1;                          // tiles whose successor is a full tile
+  unsigned* poison_flag = (unsigned*)(smem + 2 * G::BUF);    // one word behind the tile buffers
+  if (tid == 0) *poison_flag = 0u;
+
+  // One pass over the keys.  SAFE = false (the fast pass): after the first tile there is NO per-score max -- the running
+  // offset m only has to keep 2^(s - m) inside the fp32 / bf16 exponent range (both carry 8 exponent bits, so the relative
+  // precision of P does not depend on its magnitude), which one compare per tile on the softmax denominator (row D of O^T)
+  // guarantees: when it passes 2^24 the wave divides O by an exact power of two and raises m by that integer (m stays an
+  // integer, hence bf16-exact in its contraction slot).  A score more than ~100 log2 units above m inside ONE tile would
+  // overflow the exp before the compare sees it: the denominator then reads >= 2^100 / inf / NaN, the wave raises the
+  // workgroup's poison flag and the whole workgroup repeats the pass with SAFE = true -- the exact deferred-max scheme
+  // (lane-local v_max3 tree before the exp, rescale when a score exceeds m by 2^8) that is also used for tile 0.
+  auto pass = [&](auto safe_c) {
+    constexpr bool SAFE = decltype(safe_c)::value;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][qb][r] = 0.f;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      m_run[qb] = 0.f;
+      if (hi == G::PAD_HI) qf[qb][G::PAD_KS].x = pack2bf(0.0f, MASK_Q);
+    }
+    bool poison = false;
+    store_const(0, ntiles == 1 ? tail_valid : KVT);
+    store_const(1, ntiles == 2 ? tail_valid : KVT);
+    load_tile(0, std::false_type{});
+    store_tile(0);
+    __syncthreads();
+
+    // precheck_c: lane-local max tree + deferred-max rescale BEFORE the exp (tile 0 and the SAFE pass)
+    auto tile = [&](int t, auto fast_c, auto precheck_c) {
+      constexpr bool FAST = decltype(fast_c)::value;            // this tile's successor exists and is a full tile
+      constexpr bool PRE = decltype(precheck_c)::value;
+      const int kv0 = t * KVT;
+      const bool more = FAST || t + 1 < ntiles;
+      if (FAST) load_tile(kv0 + KVT, std::true_type{});
+      else if (more) load_tile(kv0 + KVT, std::false_type{});
+      const unsigned char* Ks = smem + (t & 1) * G::BUF;
+      const unsigned char* Vs = Ks + G::K_BYTES;
+
+      // ---- S^T = K . Q'^T - m : [kb] 32 keys x [qb] 32 queries
+      f32x16_t s[2][QB];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8_t kf = *(const bf16x8_t*)(Ks + kb * 32 * KROW + k_off[ks]);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            if (ks == 0) {
+              f32x16_t z;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) z[r] = 0.f;
+              s[kb][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, __builtin_bit_cast(bf16x8_t, qf[qb][ks]), z, 0, 0, 0);
+            } else {
+              s[kb][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, __builtin_bit_cast(bf16x8_t, qf[qb][ks]), s[kb][qb], 0, 0, 0);
+            }
+          }
+        }
+      }
+      if (PRE) {
+        // ---- deferred max: lane-local maxima (a tree: four independent chains per query block), one wave-uniform test
+        float mx[QB];
+        bool over = false;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          float c4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            c4[j] = fmaxf(s[0][qb][4 * j], s[1][qb][4 * j]);
+#pragma unroll
+            for (int r = 1; r < 4; ++r) c4[j] = fmaxf(fmaxf(c4[j], s[0][qb][4 * j + r]), s[1][qb][4 * j + r]);
+          }
+          mx[qb] = fmaxf(fmaxf(c4[0], c4[1]), fmaxf(c4[2], c4[3]));
+          over |= mx[qb] > THR;
+        }
+        if (t == 0 || __any(over)) {
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            const float ml = fmaxf(mx[qb], lane_xor32(mx[qb]));       // both halves of the query's column
+            float m_new = m_run[qb] + ml;
+            if (t > 0) m_new = fmaxf(m_new, m_run[qb]);
+            // the running offset rides in a bf16 contraction slot of Q: keep it bf16-exact; the fast pass needs an integer
+            m_new = bf2f(f2bf(SAFE ? m_new : ceilf(m_new)));
+            const float delta = m_new - m_run[qb];
+            m_run[qb] = m_new;
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) s[kb][qb][r] -= delta;
+            if (t > 0) {                                               // tile 0: O is still zero (and alpha may overflow)
+#pragma unroll
+              for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][qb][r] *= alpha;
+            }
+            if (hi == G::PAD_HI) qf[qb][G::PAD_KS].x = pack2bf(-m_new, MASK_Q);
+          }
+        }
+      }
+      // ---- P = 2^S, packed in place into the B fragments of O^T += V^T . P^T
+      uint32_t pw[2][QB][8];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2)
+            pw[kb][qb][r >> 1] = pack2bf(__builtin_amdgcn_exp2f(s[kb][qb][r]), __builtin_amdgcn_exp2f(s[kb][qb][r + 1]));
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+          for (int db = 0; db < DB; ++db) {
+            const bf16x8_t vf = *(const bf16x8_t*)(Vs + v_row[db] + (((kb * 4 + m2 * 2 + hi) ^ v_sw[db]) << 4));
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+              const uint4 pv = uint4{pw[kb][qb][4 * m2], pw[kb][qb][4 * m2 + 1], pw[kb][qb][4 * m2 + 2], pw[kb][qb][4 * m2 + 3]};
+              o[db][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8_t, pv), o[db][qb], 0, 0, 0);
+            }
+          }
+      if (more) {
+        store_tile((t + 1) & 1);                     // the other buffer: last read one barrier ago
+        // a ragged last tile changes the mask column of the buffer it lands in (buffers 0 / 1 were initialised for tiles 0 / 1)
+        if (!FAST && t + 2 == ntiles && t + 1 >= 2 && tail_valid != KVT) store_const((t + 1) & 1, tail_valid);
+      }
+      if (!PRE) {
+        // ---- fast pass: watch the denominator (lanes of half L_HI hold it; the other half holds a zero row of O^T)
+        bool big = false;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const float lv = o[D / 32][qb][G::L_REG];
+          big |= !(lv <= 16777216.0f);               // 2^24; also true for NaN
+        }
+        if (__any(big)) {
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            const float lv = o[D / 32][qb][G::L_REG];
+            const float lo = lane_xor32(lv);
+            const float l = hi == G::L_HI ? lv : lo;
+            poison |= !(l < 1.2676506e30f);          // 2^100: an exp may already have overflowed
+            // exponent of l as an integer-valued float, kept a multiple of the bf16 spacing of the new m
+            float m_new = m_run[qb] + (l > 2.0f ? floorf(__builtin_amdgcn_logf(l)) : 0.0f);      // v_log_f32 = log2
+            m_new = bf2f(f2bf(m_new));
+            const float delta = m_new - m_run[qb];   // an integer >= 0 (both are bf16-exact integers)
+            m_run[qb] = m_new;
+            const float alpha = __builtin_amdgcn_exp2f(-delta);       // exact power of two
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) o[db][qb][r] *= alpha;
+            if (hi == G::PAD_HI) qf[qb][G::PAD_KS].x = pack2bf(-m_new, MASK_Q);
+          }
+        }
+      }
+      __syncthreads();
+    };
+    if (SAFE) {
+      int t = 0;
+      for (; t < nfast; ++t) tile(t, std::true_type{}, std::true_type{});
+      for (; t < ntiles; ++t) tile(t, std::false_type{}, std::true_type{});
+    } else {
+      if (nfast > 0) tile(0, std::true_type{}, std::true_type{});
+      else tile(0, std::false_type{}, std::true_type{});
+      int t = 1;
+      for (; t < nfast; ++t) tile(t, std::true_type{}, std::false_type{});
+      for (; t < ntiles; ++t) tile(t, std::false_type{}, std::false_type{});
+    }
+    return poison;
+  };
+
+  const bool poisoned = pass(std::false_type{});
+  if (__any(poisoned) && lane == 0) *poison_flag = 1u;
+  __syncthreads();
+  if (*poison_flag) {            // workgroup-uniform and essentially never: an in-tile score jump of > 2^100
+    __syncthreads();
+    (void)pass(std::true_type{});
+  }
+
+  // ---- normalise and store: lane (query ql, half hi) holds O[q][d = 32 db + 8 (r >> 2) + 4 hi + (r & 3)]
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const float lv = o[D / 32][qb][G::L_REG];
+    const float lo = lane_xor32(lv);
+    const float l = hi == G::L_HI ? lv : lo;
+    const float inv = 1.0f / l;
+    const int q = q0 + qb * 32 + ql;
+    if (q >= a.Nq) continue;
+    if (a.lse && hi == 0) a.lse[((long)b * a.H + h) * a.Nq + q] = m_run[qb] + __builtin_amdgcn_logf(l);   // v_log_f32 = log2
+    bf16_t* orow = a.O + ((long)b * a.Nq + q) * a.ldo + h * D;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = db * 32 + g * 8 + hi * 4;
+        if (d0 < D) {
+          uint2 w;
+          w.x = pack2bf(o[db][qb][4 * g] * inv, o[db][qb][4 * g + 1] * inv);
+          w.y = pack2bf(o[db][qb][4 * g + 2] * inv, o[db][qb][4 * g + 3] * inv);
+          *(uint2*)(orow + d0) = w;
+        }
+      }
+  }
+}
+
+template <int D, int QB, int MINW>
+int launch_x32(const AttnArgs& a, hipStream_t stream) {
+  constexpr int lds = 2 * X32Geom<D>::BUF + 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attention_x32_kernel<D, QB, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const int nqb = (a.Nq + 128 * QB - 1) / (128 * QB);
+  dfh::ProfScope ps(dfh::PC_ATTN, 4.0 * a.B * a.H * (double)a.Nq * a.Nk * D,
+                    2.0 * a.B * a.H * D * (2.0 * a.Nq + 2.0 * a.Nk), stream);
+  hipLaunchKernelGGL((attention_x32_kernel<D, QB, MINW>), dim3(nqb * a.H * a.B), dim3(256), lds, stream, a);
+  return dfh::check_launch("attention_x32_kernel");
+}
+
+}  // namespace
+
+namespace dfh {
+
+// 0 = not handled here (the caller falls back to attention_kernel)
+bool attention_x32_eligible(const AttnArgs& a) {
+  if (a.D != 40 && a.D != 80) return false;
+  return a.Nq >= 256 && a.Nk >= 64;
+}
+
+int attention_x32_launch(const AttnArgs& a, hipStream_t stream) {
+  static const int variant = [] { const char* e = getenv("DFH_ATTN_VARIANT"); return e ? atoi(e) : 0; }();   // experiments
+  switch (a.D) {
+    case 40:
+      if (variant == 1) return launch_x32<40, 1, 3>(a, stream);
+      if (variant == 2) return launch_x32<40, 1, 4>(a, stream);
+      return launch_x32<40, 2, 2>(a, stream);
+    case 80:
+      if (variant == 1) return launch_x32<80, 1, 3>(a, stream);
+      return launch_x32<80, 1, 2>(a, stream);
+    default: break;
+  }
+  set_error("attention_x32_launch: unsupported head dim");
+  return -1;
+}
+
+}  // namespace dfh

@@ -116,8 +116,10 @@ class DiFashion(nn.Module):
         else:
             category_prompts = self.text_encoder(input_ids[fill_idx[:, 0], fill_idx[:, 1]].to(dev))[0]
         null_prompt = self._null_prompt(category_prompts.shape[1])
-        if init_latents is None:
-            init_latents = torch.randn((fill_num, self.vae.config.latent_channels, S, S), generator=generator,
+        if init_latents is None:                      # prepare_latents (difashion.py:618-633): pixel height / width // vae_scale_factor
+            lh = (height or S * self.vae_scale_factor) // self.vae_scale_factor
+            lw = (width or S * self.vae_scale_factor) // self.vae_scale_factor
+            init_latents = torch.randn((fill_num, self.vae.config.latent_channels, lh, lw), generator=generator,
                                        device=dev if generator is None or generator.device.type != "cpu" else "cpu").to(dev)
             init_latents = init_latents * self.noise_scheduler.init_noise_sigma
         null_latent = self.vae.encode(null_img.unsqueeze(0).to(dev)).latent_dist.mode()[0] * sf

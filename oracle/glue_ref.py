@@ -254,6 +254,9 @@ def sample_outfits(unet: Callable, enc_params: Dict[str, torch.Tensor], sched, *
         if taps is not None:
             taps[f"x_in_{i}"] = x
             taps[f"eps_{i}"] = eps
+            taps[f"unet_out_{i}"] = eps_all
+            taps[f"t_{i}"] = t
+            taps["ehs"] = ehs
         latents = sched.step(eps, t, latents, **kwargs, return_dict=False)[0]
         prev = latents
     return latents

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes on the 64x64-level attention launch.  Usage: bash scripts/pmc_attn.sh
 set -u
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_attn
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-pmc_attn}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT" "SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES"; do
@@ -16,7 +16,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "attention_kernel" not in k: continue
+        if "attention_" not in k: continue
         agg[k[:60]][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k[:60], r["Counter_Name"])] += 1
 for k, v in agg.items():
     print(k)

@@ -158,3 +158,40 @@ def test_difashion_fashion_generation_from_raw_inputs(name, bsz, ol, scales, ste
     slot = res[uid0][oid0]
     assert set(slot) == {"images", "cates", "full_cates", "outfits"} and slot["images"][0].shape == (4, H, H)
     assert float(slot["images"][0].min()) >= 0.0 and float(slot["images"][0].max()) <= 1.0      # postprocess: [-1,1] -> [0,1]
+
+
+def test_fashion_generation_draws_its_own_initial_latents(unet):
+    """SURVEY.md 8 row a11 (difashion.py:361-371 -> prepare_latents :618-633): called WITHOUT ``init_latents`` the sampler
+    draws them from the caller's generator -- ``randn(F, C, h, w) * init_noise_sigma`` -- and returns them.  Golden from the
+    real class with the same CPU generator seed (tests/golden/make_golden_autoinit.py): the draw must be bit-identical,
+    the trajectory it starts within the sampler tolerance."""
+    name = "autoinit_gor_ddim6"
+    rec = load(f"sample_{name}.npz")
+    olists = torch.tensor([[0, 0, 0, 0], [4, 0, 0, 9]])
+    images, null_img, cats, ids, uids, oids, _init, hist = sample_inputs(2, olists, seed=sum(map(ord, name)))
+    if not torch.equal(images.reshape(8, 4, H, H), rec["all_latents"]):
+        pytest.skip("torch CPU RNG stream differs from the capture container")
+    args = types.SimpleNamespace(use_history=True, use_mutual_guidance=True, eta=0.1)
+    m = DiFashion(args, vae=IdentityVAE(), unet=unet, fashion_encoder=encoder(rec), noise_scheduler=da.DDIMScheduler(),
+                  text_encoder=TableText(), tokenizer=ZeroTok())
+    d = lambda t: t.to(DEV)
+    hist_dev = {u: TensorKeyDict({c: d(v) for c, v in h.items()}) for u, h in hist.items()}
+    sc, sh, sm = (float(v) for v in rec["scales"])
+    out = m.fashion_generation(uids=uids, oids=oids, input_ids=ids, olists=olists, outfit_images=d(images.reshape(8, 4, H, H)),
+                               category=cats, history=hist_dev, num_inference_steps=int(rec["steps"]), category_guidance_scale=sc,
+                               hist_guidance_scale=sh, mutual_guidance_scale=sm, null_img=d(null_img), eta=0.0, init_latents=None,
+                               generator=torch.Generator().manual_seed(int(rec["generator_seed"])), output_type="latent",
+                               return_dict=True)
+    final, init_out = out[0].images, out[-1]
+    assert init_out.shape == rec["init_latents"].shape and init_out.device.type == "cuda"
+    assert torch.equal(init_out.cpu(), rec["init_latents"])          # same generator, same draw order, * init_noise_sigma
+    e = rel_err(final.cpu(), rec["final"])
+    print(name, f"final latents rel err {e:.2e}")
+    assert e <= 8e-2
+    # an explicit height / width (pixels) sets the latent size exactly as prepare_latents does: // vae_scale_factor
+    out2 = m.fashion_generation(uids=uids, oids=oids, input_ids=ids, olists=olists, outfit_images=d(images.reshape(8, 4, H, H)),
+                                category=cats, history=hist_dev, height=H * m.vae_scale_factor, width=H * m.vae_scale_factor,
+                                num_inference_steps=1, category_guidance_scale=sc, hist_guidance_scale=sh, mutual_guidance_scale=sm,
+                                null_img=d(null_img), init_latents=None, generator=torch.Generator().manual_seed(int(rec["generator_seed"])),
+                                output_type="latent", return_dict=True)
+    assert torch.equal(out2[-1].cpu(), rec["init_latents"])

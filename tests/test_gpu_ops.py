@@ -229,6 +229,55 @@ def test_attention_online_softmax_rescale_is_exercised():
     gu.assert_close_bf16(o, ref, "rescale", rel=1e-2, max_rel=4e-2)
 
 
+@pytest.mark.parametrize("d,heads", [(40, 8), (80, 4)])
+@pytest.mark.parametrize("Nq,Nk", [(256, 64), (512, 77), (300, 200), (2048, 2048), (512, 640), (1024, 129)])
+def test_attention_x32_shapes(d, heads, Nq, Nk):
+    """The 32x32x16 kernel (attention_x32.hip) takes d = 40 / 80 with Nq >= 256, Nk >= 64: full tiles, ragged key
+    tails in the first / second / a later LDS buffer (masked through the spare contraction slot), ragged query blocks."""
+    B, Cc = 2, d * heads
+    q, k, v = bf(rnd(B, Nq, Cc, seed=60)), bf(rnd(B, Nk, Cc, seed=61)), bf(rnd(B, Nk, Cc, seed=62))
+    o = _attention(q, k, v, heads)
+    qh, kh, vh = (t.float().view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Nq, Cc)
+    gu.assert_close_bf16(o, ref, f"attention_x32 d={d} {Nq}x{Nk}", rel=1e-2, max_rel=4e-2)
+
+
+@pytest.mark.parametrize("d", [40, 80])
+@pytest.mark.parametrize("gain", [1.0, 4.0])
+def test_attention_x32_running_max_moves(d, gain):
+    """Keys of a late tile carry far larger scores than the first tile for some queries, far smaller for the rest
+    (guide rule 26: force the rare rescale branch); gain 4 puts the running max near 60 log2 units, where its bf16
+    rounding (it rides in a contraction slot of Q) is 0.25 -- the result must not depend on that rounding."""
+    B, heads, N = 1, 2, 512
+    Cc = d * heads
+    q, k, v = bf(rnd(B, N, Cc, seed=63) * gain), bf(rnd(B, N, Cc, seed=64) * gain), bf(rnd(B, N, Cc, seed=65))
+    k[:, 300] = q[:, 7] * 3.0          # key 300 (tile 4) aligned with query 7, both heads
+    k[:, 450] = q[:, 260] * 5.0        # key 450 (tile 7) aligned with query 260 (second wave)
+    o = _attention(q, k, v, heads)
+    qh, kh, vh = (t.float().view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, N, Cc)
+    # gain 4: near one-hot rows over scores of ~+-70 log2 units -- the standalone op re-rounds Q after its pre-scale by
+    # scale * log2(e) (2^-9 relative per element, i.e. ~0.03 log2 units on such scores); inside the U-Net the scale is folded
+    # into the to_q projection's epilogue instead (one rounding)
+    gu.assert_close_bf16(o, ref, f"x32 rescale d={d} gain={gain}", rel=1.5e-2, max_rel=6e-2 if gain == 1.0 else 0.12)
+
+
+def test_attention_x32_matches_the_16x16_kernel_lse():
+    """Training reads the forward's log-sum-exp: both kernels must report the same one."""
+    B, heads, d, N = 1, 2, 40, 512
+    Cc = d * heads
+    q, k, v = bf(rnd(B, N, Cc, seed=66)), bf(rnd(B, N, Cc, seed=67)), bf(rnd(B, N, Cc, seed=68))
+    vt = v.transpose(1, 2).contiguous()
+    o = torch.empty_like(q)
+    lse = torch.empty((B, heads, N), device=DEV)
+    _lib.call("dfh_attention_lse", _lib.ptr(q), Cc, _lib.ptr(k), Cc, _lib.ptr(vt), N, _lib.ptr(o), Cc, B, heads, d, N, N,
+              d ** -0.5, _lib.ptr(lse), gu.stream())
+    torch.cuda.synchronize()
+    qh, kh = (t.float().view(B, -1, heads, d).transpose(1, 2) for t in (q, k))
+    ref = torch.logsumexp(qh @ kh.transpose(-1, -2) * d ** -0.5, dim=-1) * 1.4426950408889634     # log2 domain
+    assert (lse - ref).abs().max().item() <= 2e-2
+
+
 # ----------------------------------------------------------------------------- small kernels
 def test_timestep_embedding():
     t = torch.tensor([0.0, 1.0, 481.0, 999.0], device=DEV)

@@ -3,9 +3,9 @@ real reference glue and (b) the oracle run on identical inputs.
 
 Tolerances: step-0 U-Net input differs from the reference only through the bf16 MutualEncoder GEMMs
 scaled by eta=0.1 -> atol 2e-3.  Later quantities pass through the bf16 U-Net and guidance scales up
-to 12, so they are compared in relative L2: raw U-Net output <= 3e-2 at step 0, combined epsilon <= 0.25
-per step (guidance amplifies branch differences ~10x), final latents <= 8e-2 after 6-10 steps and
-<= 0.15 after 50 (observed values are printed: ~1.6e-2, ~0.06-0.16, ~0.01-0.06)."""
+to 12, so they are compared in relative L2: raw U-Net output <= 3e-2 at EVERY step under teacher forcing (the oracle's
+trajectory feeds both U-Nets), final latents of the free-running sampler <= 8e-2 after 6-10 steps and <= 0.15 after 50
+(observed values are printed: ~1.6e-2 and ~0.01-0.06)."""
 import glob
 import os
 
@@ -84,28 +84,43 @@ def test_sampler_vs_reference_golden(case, unet):
     assert ef <= (8e-2 if int(rec["steps"]) <= 10 else 0.15)
 
 
-def test_sampler_vs_oracle_stepwise(unet):
-    """Same inputs through oracle.sample_outfits (fp32 CPU): per-step combined epsilon and latents."""
-    rec = load("sample_gor_full_ddim10.npz")
+@pytest.mark.parametrize("case", ["gor_full_ddim10", "mix_full_pndm10", "gor_full_ddim50"])
+def test_sampler_teacher_forced_every_step(case, unet):
+    """Teacher forcing: the fp32 oracle sampler runs the whole trajectory; at EVERY step the tensors it hands to its
+    U-Net (assembled input, timestep, text states) go through the HIP U-Net too and the raw per-branch predictions are
+    compared -- relative L2 <= 3e-2 at every step, not only at step 0.  (A free-running comparison of the COMBINED epsilon
+    mixes this per-step error with the divergence of two trajectories and with the guidance amplification
+    u + 4(a-cm) + 5(cm-c) + 12(c-u); the free-running check below therefore bounds only the latents it integrates to.)"""
+    rec = load(f"sample_{case}.npz")
     p = glue_unet_params()
-    otaps, taps = {}, {}
-    ref = glue_ref.sample_outfits(lambda x, t, e: unet_ref.unet_forward(p, GLUE_CFG, x, t, e), enc_params(rec),
-                                  sched_ref.DDIMRef(), olists=rec["olists"], all_latents=rec["all_latents"],
-                                  init_latents=rec["init_latents"], hist_latents=rec["hist_sel"],
-                                  null_latent=rec["null_latent"], category_prompts=rec["category_prompts"],
-                                  null_prompt=rec["null_prompt"], num_inference_steps=10, taps=otaps)
+    steps = int(rec["steps"])
+    sc, sh, sm = (float(v) for v in rec["scales"])
+    osched = sched_ref.PNDMRef() if str(rec["sched"]) == "pndm" else sched_ref.DDIMRef()
+    otaps = {}
+    ref = glue_ref.sample_outfits(lambda x, t, e: unet_ref.unet_forward(p, GLUE_CFG, x, t, e), enc_params(rec), osched,
+                                  olists=rec["olists"], all_latents=rec["all_latents"], init_latents=rec["init_latents"],
+                                  hist_latents=rec["hist_sel"], null_latent=rec["null_latent"],
+                                  category_prompts=rec["category_prompts"], null_prompt=rec["null_prompt"],
+                                  num_inference_steps=steps, cate_scale=sc, hist_scale=sh, mutual_scale=sm, taps=otaps)
+    n = len([k for k in otaps if k.startswith("x_in_")])
+    ehs = otaps["ehs"].to(DEV)
+    errs = []
+    with torch.no_grad():
+        for i in range(n):
+            got = unet(otaps[f"x_in_{i}"].to(DEV), otaps[f"t_{i}"], ehs, return_dict=False)[0]
+            errs.append(rel_err(got.cpu(), otaps[f"unet_out_{i}"]))
+    print(case, "teacher-forced U-Net rel err per step", [f"{e:.2e}" for e in errs])
+    assert max(errs) <= 3e-2
+    # free-running product sampler on the same inputs: the latents it integrates to
     d = lambda k: rec[k].to(DEV)
-    got = da.sample_outfits(unet, encoder(rec), da.DDIMScheduler(), olists=rec["olists"], all_latents=d("all_latents"),
+    sched = da.PNDMScheduler() if str(rec["sched"]) == "pndm" else da.DDIMScheduler()
+    got = da.sample_outfits(unet, encoder(rec), sched, olists=rec["olists"], all_latents=d("all_latents"),
                             init_latents=d("init_latents"), hist_latents=d("hist_sel"), null_latent=d("null_latent"),
                             category_prompts=d("category_prompts"), null_prompt=d("null_prompt"),
-                            num_inference_steps=10, taps=taps)
-    errs = [rel_err(taps[f"eps_{i}"].cpu(), otaps[f"eps_{i}"]) for i in range(10)]
+                            num_inference_steps=steps, cate_scale=sc, hist_scale=sh, mutual_scale=sm)
     lat_err = rel_err(got.cpu(), ref)
-    print("eps rel err per step", [f"{e:.2e}" for e in errs], "final", f"{lat_err:.2e}")
-    # The combined epsilon is u + 4(a-cm) + 5(cm-c) + 12(c-u): differences of nearly equal branch
-    # predictions scaled by up to 12, so a 1.6e-2 per-branch error is amplified ~10x in relative terms.
-    # Bound: 0.25 per step on the combined epsilon, 8e-2 on the latents it integrates to.
-    assert max(errs) <= 0.25 and lat_err <= 8e-2
+    print(case, "free-running final latents", f"{lat_err:.2e}")
+    assert lat_err <= (8e-2 if steps <= 10 else 0.15)
 
 
 @pytest.mark.parametrize("case", TRAIN)

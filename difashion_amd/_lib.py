@@ -244,3 +244,24 @@ def stream_ptr():
 def ptr(t):
     """Device pointer of a torch tensor (None -> NULL)."""
     return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+# ---- gradient epochs: FusedAdamW.zero_grad() opens an epoch; whatever writes a gradient (autograd accumulation, the native
+#      U-Net backward) stamps the parameter with the epoch it wrote in; step() updates only parameters stamped since the last
+#      zero_grad -- torch.optim.AdamW's "skip parameters whose .grad is None" for gradient views that are never None.
+_GRAD_EPOCH = [1]
+
+
+def grad_epoch() -> int:
+    return _GRAD_EPOCH[0]
+
+
+def next_grad_epoch() -> int:
+    _GRAD_EPOCH[0] += 1
+    return _GRAD_EPOCH[0]
+
+
+def stamp_grads(params) -> None:
+    e = _GRAD_EPOCH[0]
+    for p in params:
+        p._dfh_grad_epoch = e

@@ -1,7 +1,9 @@
 // Elementwise / layout kernels of the training step (reference: DiFashion/train.py:691-716 --
 // accelerator.backward, clip_grad_norm_, AdamW, EMA -- and the autograd of the glue in
 // DiFashion/models/difashion.py:160-267).  HBM-bound; bf16 data as 16-byte vectors, fp32 state as float4.
+#include <map>
 #include <mutex>
+#include <utility>
 #include <unordered_map>
 #include "dfh_common.h"
 #include "bwd_elementwise.h"
@@ -349,14 +351,17 @@ constexpr unsigned SUMSQ_MAX_BLOCKS = 2048;
 // per-stream scratch of sumsq_kernel: SUMSQ_MAX_BLOCKS partials + the ticket counter (zeroed once; the kernel resets it)
 static float* sumsq_scratch_for(hipStream_t stream) {
   static std::mutex mu;
-  static std::unordered_map<hipStream_t, float*> table;
+  static std::map<std::pair<int, hipStream_t>, float*> table;     // per (device, stream): the null stream exists on every device
   std::lock_guard<std::mutex> lock(mu);
-  auto it = table.find(stream);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  const auto key = std::make_pair(dev, stream);
+  auto it = table.find(key);
   if (it != table.end()) return it->second;
   float* p = nullptr;
   if (hipMalloc((void**)&p, (SUMSQ_MAX_BLOCKS + 1) * sizeof(float)) != hipSuccess) return nullptr;
   if (hipMemset(p, 0, (SUMSQ_MAX_BLOCKS + 1) * sizeof(float)) != hipSuccess) { (void)hipFree(p); return nullptr; }
-  table[stream] = p;
+  table[key] = p;
   return p;
 }
 int sumsq_launch(const float* g, long n, float* out, hipStream_t s) {

@@ -84,15 +84,15 @@ class MutualEncoder(nn.Module):
                   os.path.join(save_directory, self.weights_name))
 
     @classmethod
-    def from_pretrained(cls, path: str, subfolder: Optional[str] = None, **unused):
-        from safetensors.torch import load_file
+    def from_pretrained(cls, path: str, subfolder: Optional[str] = None, variant: Optional[str] = None, **unused):
+        from ._ckpt import load_weights
         d = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(d, cls.config_name)) as f:
             cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
         ctor = {k: cfg[k] for k in ("cate_num", "cate_emb_size", "latent_channels", "latent_size", "hid_dim")}
         model = cls(**ctor)
         model.register_to_config(**cfg)          # extra keys (e.g. EMA state written by EMAModel.save_pretrained) survive
-        model.load_state_dict(load_file(os.path.join(d, cls.weights_name)))
+        model.load_state_dict(load_weights(d, variant))
         return model
 
     def _pack(self):

@@ -64,11 +64,43 @@ class FusedAdamW(torch.optim.Optimizer):
                 p.grad = gv if p.requires_grad else None
                 self._slices[id(p)] = (off, n)
                 off += _align(n)
+                if p.requires_grad:       # autograd-accumulated gradients (MutualEncoder, anything outside the native U-Net)
+                    p.register_post_accumulate_grad_hook(lambda q: setattr(q, "_dfh_grad_epoch", _lib.grad_epoch()))
             self._group_ranges.append((start, off))
         self._step = 0
+        self._zero_epoch = _lib.grad_epoch()      # gradients stamped at or after this epoch are fresh
+        self._all_fresh = False                   # zero_grad(set_to_none=False): torch's "zeros, not None" -> everything updates
+
+    def _fresh(self, p) -> bool:
+        """torch.optim.AdamW skips parameters whose ``.grad`` is None.  The gradient views here are never None, so freshness
+        is tracked instead: a parameter is updated (weight decay and moments included) only if something wrote its gradient
+        since the last ``zero_grad`` -- never-used parameters (``MutualEncoder.category_embedding``, reference
+        difashion.py:28), frozen ones, a module whose backward did not run this step (its lazily kept stale gradients must not
+        be re-applied) all stay untouched, exactly as with the reference's optimizer."""
+        return p.requires_grad and (self._all_fresh or getattr(p, "_dfh_grad_epoch", -1) >= self._zero_epoch)
+
+    def mark_fresh(self, params=None) -> None:
+        """Declare gradients written by hand (``p.grad.copy_(g)``, a kernel writing into ``flat_grad``) as this step's:
+        autograd accumulation and the native U-Net backward stamp their parameters themselves."""
+        _lib.stamp_grads(params if params is not None else [p for g in self.param_groups for p in g["params"]])
+
+    def _fresh_ranges(self, a: int, b: int) -> List[tuple]:
+        """Merged [start, end) ranges of fresh parameters inside the flat range [a, b)."""
+        runs = []
+        for g in self.param_groups:
+            for p in g["params"]:
+                off, n = self._slices[id(p)]
+                if off < a or off >= b or not self._fresh(p):
+                    continue
+                end = off + _align(n)
+                if runs and runs[-1][1] == off:
+                    runs[-1][1] = end
+                else:
+                    runs.append([off, end])
+        return [tuple(r) for r in runs]
 
     # the gradient views are permanent: zero_grad never drops them (the native backward accumulates in place)
-    def zero_grad(self, set_to_none: bool = False, lazy_modules=()):
+    def zero_grad(self, set_to_none: bool = True, lazy_modules=()):
         """``lazy_modules``: modules whose native backward can OVERWRITE its gradients (UNet2DConditionModel): their slices
         are not zero-filled here, the module is told that its gradient views hold stale values (``grads_cleared``) and the
         next backward stores instead of accumulating -- 3.4 GB less memset and 3.4 GB less read-modify-write per step."""
@@ -77,6 +109,8 @@ class FusedAdamW(torch.optim.Optimizer):
             if all(p.grad is not None and id(p) in self._slices for p in mod.parameters() if p.requires_grad):
                 lazy.update(id(p) for p in mod.parameters())
                 mod.grads_cleared = True
+        self._zero_epoch = _lib.next_grad_epoch()
+        self._all_fresh = not set_to_none         # the views are kept either way; only the update rule differs (see _fresh)
         if not lazy:
             self.flat_grad.zero_()
         else:
@@ -130,9 +164,11 @@ class FusedAdamW(torch.optim.Optimizer):
                 raise _lib.DfhError("FusedAdamW.step(ema=...): the EMA must cover a prefix of the optimizer's parameters")
         s = _lib.stream_ptr()
         self._step += 1
-        n = self.flat_grad.numel()
+        total = self.flat_grad.numel()
+        fresh_all = self._fresh_ranges(0, total)
         self._sumsq.zero_()
-        _lib.call("dfh_sumsq", _lib.ptr(self.flat_grad), n, _lib.ptr(self._sumsq), s)
+        for lo, hi in fresh_all:               # the clip norm counts fresh gradients only (clip_grad_norm_ skips grad None);
+            _lib.call("dfh_sumsq", self.flat_grad.data_ptr() + 4 * lo, hi - lo, _lib.ptr(self._sumsq), s)   # fixed order: deterministic
         clip = self.max_grad_norm is not None
         for g, (a, b) in zip(self.param_groups, self._group_ranges):
             if b == a:
@@ -140,15 +176,22 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = g["betas"]
             hyper = (float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), self._step,
                      _lib.ptr(self._sumsq) if clip else None, float(self.max_grad_norm or 0.0))
-            fe = min(b, ema_end)                   # [a, fe): fused with the EMA update, [fe, b): plain
-            if fe > a:
-                _lib.call("dfh_adamw_ema", self.flat_param.data_ptr() + 4 * a, self.flat_grad.data_ptr() + 4 * a,
-                          self.exp_avg.data_ptr() + 4 * a, self.exp_avg_sq.data_ptr() + 4 * a, ema.flat.data_ptr() + 4 * a,
-                          fe - a, *hyper, float(ema_decay), s)
-            lo = max(a, fe)
-            if b > lo:
-                _lib.call("dfh_adamw", self.flat_param.data_ptr() + 4 * lo, self.flat_grad.data_ptr() + 4 * lo,
-                          self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo, b - lo, *hyper, s)
+            cursor = a
+            for lo, hi in self._fresh_ranges(a, b) + [(b, b)]:
+                # [cursor, lo): not updated -- but an EMA over them still tracks the (unchanged) parameters, as EMAModel.step does
+                if lo > cursor and ema_end > cursor:
+                    e = min(lo, ema_end)
+                    _lib.call("dfh_ema", ema.flat.data_ptr() + 4 * cursor, self.flat_param.data_ptr() + 4 * cursor, e - cursor,
+                              float(ema_decay), s)
+                cursor = hi
+                fe = min(hi, max(lo, ema_end))         # [lo, fe): fused with the EMA update, [fe, hi): plain
+                if fe > lo:
+                    _lib.call("dfh_adamw_ema", self.flat_param.data_ptr() + 4 * lo, self.flat_grad.data_ptr() + 4 * lo,
+                              self.exp_avg.data_ptr() + 4 * lo, self.exp_avg_sq.data_ptr() + 4 * lo, ema.flat.data_ptr() + 4 * lo,
+                              fe - lo, *hyper, float(ema_decay), s)
+                if hi > fe:
+                    _lib.call("dfh_adamw", self.flat_param.data_ptr() + 4 * fe, self.flat_grad.data_ptr() + 4 * fe,
+                              self.exp_avg.data_ptr() + 4 * fe, self.exp_avg_sq.data_ptr() + 4 * fe, hi - fe, *hyper, s)
         _lib.bump_weight_epoch()          # packed bf16 copies of these weights are stale now
         return loss
 

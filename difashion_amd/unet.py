@@ -74,6 +74,36 @@ _DEFAULT_DOWN = ("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownB
 _DEFAULT_UP = ("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D")
 
 
+# diffusers UNet2DConditionModel config switches the native walk does not implement: the value the walk assumes (= the SD-1.x /
+# SD-2-base value).  Anything else would run silently wrong, so the constructor refuses it.
+_FIXED_CONFIG = {
+    "act_fn": ("silu", "swish"), "upcast_attention": (False, None), "only_cross_attention": (False, None),
+    "dual_cross_attention": (False, None), "class_embed_type": (None,), "num_class_embeds": (None,),
+    "resnet_time_scale_shift": ("default", None), "flip_sin_to_cos": (True,), "freq_shift": (0,),
+    "mid_block_type": ("UNetMidBlock2DCrossAttn", None), "num_attention_heads": (None,), "center_input_sample": (False, None),
+    "downsample_padding": (1, None), "mid_block_scale_factor": (1, 1.0, None), "time_embedding_type": ("positional", None),
+    "addition_embed_type": (None,), "encoder_hid_dim": (None,), "encoder_hid_dim_type": (None,), "timestep_post_act": (None,),
+    "time_cond_proj_dim": (None,), "conv_in_kernel": (3, None), "conv_out_kernel": (3, None), "class_embeddings_concat": (False, None),
+    "resnet_skip_time_act": (False, None), "resnet_out_scale_factor": (1.0, 1, None), "cross_attention_norm": (None,),
+    "time_embedding_dim": (None,), "time_embedding_act_fn": (None,), "projection_class_embeddings_input_dim": (None,),
+    "mid_block_only_cross_attention": (None, False), "addition_embed_type_num_heads": (64, None),
+}
+
+
+def _reject_unsupported_config(extra: dict):
+    bad = []
+    for k, v in extra.items():
+        if k in _FIXED_CONFIG:
+            vv = tuple(v) if isinstance(v, list) else v
+            ok = _FIXED_CONFIG[k]
+            if isinstance(vv, tuple) and k == "only_cross_attention":
+                vv = any(vv)
+            if vv not in ok:
+                bad.append(f"{k}={v!r} (supported: {ok[0]!r})")
+    if bad:
+        raise _lib.DfhError("UNet2DConditionModel: config not implemented by the HIP walk: " + "; ".join(bad))
+
+
 class UNet2DConditionModel(nn.Module):
     config_name = "config.json"
     weights_name = "diffusion_pytorch_model.safetensors"
@@ -86,6 +116,7 @@ class UNet2DConditionModel(nn.Module):
                  text_len: int = 77, max_batch: int = 16, init_seed: Optional[int] = 0, init_std: float = 0.02,
                  **unused):
         super().__init__()
+        _reject_unsupported_config(unused)
         nb = len(block_out_channels)
         if isinstance(attention_head_dim, int):
             attention_head_dim = (attention_head_dim,) * nb
@@ -354,6 +385,7 @@ class UNet2DConditionModel(nn.Module):
         overwrite = 1 if getattr(self, "grads_cleared", False) else 0
         self.grads_cleared = False
         self.grads_synced = False
+        _lib.stamp_grads(plist)           # FusedAdamW.step() updates only parameters whose gradient was written this epoch
         import torch.distributed as tdist
         if self.sync_grads_in_backward and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
             self._backward_overlapped(d_out, d_sample, arr, len(plist), overwrite, tdist)
@@ -484,8 +516,8 @@ class UNet2DConditionModel(nn.Module):
                   os.path.join(save_directory, self.weights_name))
 
     @classmethod
-    def from_pretrained(cls, path: str, subfolder: Optional[str] = None, **kwargs):
-        from safetensors.torch import load_file
+    def from_pretrained(cls, path: str, subfolder: Optional[str] = None, variant: Optional[str] = None, **kwargs):
+        from ._ckpt import load_weights
         d = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(d, cls.config_name)) as f:
             cfg = json.load(f)
@@ -494,5 +526,5 @@ class UNet2DConditionModel(nn.Module):
         model = cls(init_seed=None, **cfg)
         # keys the constructor does not know (e.g. the EMA state diffusers' EMAModel.save_pretrained adds) stay in .config
         model.register_to_config(**{k: v for k, v in cfg.items() if k not in model.config and k != "max_batch"})
-        model.load_state_dict(load_file(os.path.join(d, cls.weights_name)))
+        model.load_state_dict(load_weights(d, variant))      # .safetensors, else the .bin diffusers 0.18.2 writes by default
         return model

@@ -224,11 +224,12 @@ class AutoencoderKL(nn.Module):
                   os.path.join(save_directory, self.weights_name))
 
     @classmethod
-    def from_pretrained(cls, path: str, subfolder: Optional[str] = None, **unused):
-        from safetensors.torch import load_file
+    def from_pretrained(cls, path: str, subfolder: Optional[str] = None, variant: Optional[str] = None, **unused):
+        from ._ckpt import load_weights, remap_deprecated_vae_attention
         d = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(d, cls.config_name)) as f:
             cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
         model = cls(init_seed=None, **cfg)
-        model.load_state_dict(load_file(os.path.join(d, cls.weights_name)))
+        # published SD VAE weights still name the mid-block attention query / key / value / proj_attn (diffusers renames on load)
+        model.load_state_dict(remap_deprecated_vae_attention(load_weights(d, variant)))
         return model

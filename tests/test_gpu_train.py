@@ -188,6 +188,7 @@ def test_fused_adamw_and_clip_match_torch():
         for p, q, g in zip(ps, qs, gs):
             p.grad.copy_(g)
             q.grad = g.clone()
+        opt.mark_fresh()
         norm_ref = torch.nn.utils.clip_grad_norm_(qs, 1.0)
         opt.step()
         ref.step()
@@ -243,6 +244,67 @@ def test_training_loop_reduces_the_loss_on_a_fixed_batch():
     assert float(opt.grad_norm()) > 0
 
 
+def test_adamw_skips_parameters_without_a_fresh_gradient_like_torch():
+    """torch.optim.AdamW (the reference's optimizer, train.py:586-593) skips parameters whose .grad is None: a parameter no
+    backward reached this step (MutualEncoder.category_embedding is never used in forward, difashion.py:28,39-46), a frozen
+    one, or a module whose backward did not run.  The gradient views of FusedAdamW are never None -- freshness is tracked
+    instead.  Weight decay must NOT shrink the skipped parameters; an EMA over them still tracks the (unchanged) values."""
+    torch.manual_seed(3)
+    used = torch.nn.Parameter(torch.randn(33, 17, device=DEV))
+    unused = torch.nn.Parameter(torch.randn(50, device=DEV))
+    frozen = torch.nn.Parameter(torch.randn(20, device=DEV), requires_grad=False)
+    late = torch.nn.Parameter(torch.randn(9, 9, device=DEV))
+    ps = [used, unused, frozen, late]
+    qs = [torch.nn.Parameter(p.detach().clone(), requires_grad=p.requires_grad) for p in ps]
+    opt = da.FusedAdamW(ps, lr=1e-2, weight_decay=0.1, max_grad_norm=1.0)
+    ref = torch.optim.AdamW(qs, lr=1e-2, weight_decay=0.1)
+    ema = da.EMAModel(ps[:2], decay=0.5)
+    shadow0 = [t.clone() for t in ema.shadow_params]
+    for it in range(3):
+        x = torch.randn(17, device=DEV)
+        (used @ x).square().sum().backward()             # autograd accumulation stamps ``used``
+        (qs[0] @ x).square().sum().backward()
+        if it == 2:                                       # ``late`` receives a gradient only in the last step
+            late.square().sum().backward()
+            qs[3].square().sum().backward()
+        torch.nn.utils.clip_grad_norm_([q for q in qs if q.grad is not None], 1.0)
+        opt.step(ema=ema)
+        ref.step()
+        opt.zero_grad()
+        ref.zero_grad()                                   # set_to_none=True: the default of the reference's torch
+        for p, q in zip(ps, qs):
+            torch.testing.assert_close(p.data, q.data, rtol=2e-5, atol=2e-6)
+    assert torch.equal(unused.data, qs[1].data) and torch.equal(frozen.data, qs[2].data)       # untouched, no decay
+    want = shadow0[1]
+    for _ in range(3):
+        want = want - (1 - ema.get_decay(_ + 1)) * (want - unused.data)
+    torch.testing.assert_close(ema.shadow_params[1], want, rtol=1e-6, atol=1e-7)
+    # zero_grad(set_to_none=False) is torch's "zeros, not None": every trainable parameter decays again
+    opt.zero_grad(set_to_none=False)
+    before = unused.data.clone()
+    opt.step()
+    assert float((unused.data - before).abs().max()) > 0
+
+
+def test_stale_lazy_gradients_are_not_applied_when_the_backward_did_not_run():
+    """zero_grad(lazy_modules=[unet]) leaves the previous step's U-Net gradients in place for the next backward to overwrite.
+    If that backward never runs (an encoder-only / skipped step), step() must not re-apply them."""
+    cfg = unet_ref.TINY
+    m = hip_unet(cfg, unet_ref.init_params(cfg, seed=3), max_batch=2).train()
+    extra = torch.nn.Parameter(torch.randn(8, device=DEV))
+    opt = da.FusedAdamW(list(m.parameters()) + [extra], lr=1e-2, weight_decay=0.0)
+    x, e = inputs(cfg, 2, 21)
+    m(x.to(DEV), torch.tensor([3, 700], device=DEV), e.to(DEV)).sample.square().mean().backward()
+    opt.step()
+    opt.zero_grad(lazy_modules=(m,))
+    snap = [p.data.clone() for p in m.parameters()]
+    extra.square().sum().backward()                       # a step in which only ``extra`` gets a gradient
+    e0 = extra.data.clone()
+    opt.step()
+    assert all(torch.equal(a, p.data) for a, p in zip(snap, m.parameters()))
+    assert not torch.equal(e0, extra.data)
+
+
 def test_adamw_with_folded_ema_equals_separate_updates():
     torch.manual_seed(2)
     shapes = [(40, 24), (130,), (7, 9)]
@@ -255,6 +317,7 @@ def test_adamw_with_folded_ema_equals_separate_updates():
             g = torch.randn_like(p)
             p.grad.copy_(g)
             q.grad.copy_(g)
+        opt_a.mark_fresh(); opt_b.mark_fresh()
         opt_a.step(ema=ema_a)          # one launch for the covered range
         opt_b.step()
         ema_b.step(qs[:2])

@@ -268,6 +268,48 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
     }
   }
 
+  // ---------------------------------------------------------------- GEGLU epilogue in registers (column tiles whose waves own
+  // whole (value, gate) block pairs: FN even).  The packed weight rows interleave values and gates in 16-row blocks, so
+  // acc[i][j] / acc[i][j + 1] hold value and gate of the SAME four hidden units of one pixel in one lane: bias, exact-erf GELU and
+  // the product run on the accumulators, and only the bf16 result (half the columns) is staged through LDS for full-row
+  // 16-byte stores.  (The four fp32 passes below cost 22k of the 48k cycles of a K = 320 tile -- more than its k-loop.)
+  if constexpr (FN % 2 == 0) {
+    if (a.act == ACT_GEGLU) {
+      constexpr int RSG = BN + 16;                     // bf16 row stride of the staged [BM][BN / 2] tile (bytes)
+      static_assert(BM * RSG <= NSTAGE * STAGE, "staged GEGLU tile must fit the pipeline buffers");
+      __syncthreads();                                 // every wave is done reading the last pipeline stage
+      float4 bv[FN / 2], bg[FN / 2];
+#pragma unroll
+      for (int jj = 0; jj < FN / 2; ++jj) {
+        const int n = n0 + wn * TN + jj * 32 + fg * 4;
+        bv[jj] = float4{0, 0, 0, 0}; bg[jj] = float4{0, 0, 0, 0};
+        if (a.bias && n + 16 < a.N) { bv[jj] = *(const float4*)(a.bias + n); bg[jj] = *(const float4*)(a.bias + n + 16); }
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = wm * TM + i * 16 + fr;
+#pragma unroll
+        for (int jj = 0; jj < FN / 2; ++jj) {
+          const f32x4_t v = acc[i][2 * jj], g = acc[i][2 * jj + 1];
+          uint2 o;
+          o.x = pack2bf((v[0] + bv[jj].x) * gelu_erf_f(g[0] + bg[jj].x), (v[1] + bv[jj].y) * gelu_erf_f(g[1] + bg[jj].y));
+          o.y = pack2bf((v[2] + bv[jj].z) * gelu_erf_f(g[2] + bg[jj].z), (v[3] + bv[jj].w) * gelu_erf_f(g[3] + bg[jj].w));
+          const int ocl = ((wn * TN) >> 1) + jj * 16 + fg * 4;           // output column inside the tile
+          *(uint2*)(smem + row * RSG + ocl * 2) = o;
+        }
+      }
+      __syncthreads();
+      constexpr int CPRG = BN / 16;                    // 16-byte chunks per output row of the tile
+      for (int c = tid; c < BM * CPRG; c += NWV * 64) {
+        const int row = c / CPRG, cc = c - row * CPRG;
+        const int m = m0 + row, oc = (n0 >> 1) + cc * 8;
+        if (m < a.M && oc < (a.N >> 1))
+          *(uint4*)((bf16_t*)a.out + (long)m * a.ld_out + oc) = *(const uint4*)(smem + row * RSG + cc * 16);
+      }
+      return;
+    }
+  }
+
   // ---------------------------------------------------------------- epilogue: four 64-row passes through fp32 LDS
   constexpr int RSF = BN * 4 + 16;                 // fp32 row stride (bytes); 64 rows = 42 KB
   constexpr int CPR = BN / 8;                      // 8-column chunks per row
@@ -398,10 +440,12 @@ int gemm_wide_ksteps(const GemmArgs& a) {
 // 1 = 256 x 160, 4 = 256 x 128 (N a multiple of 128 but not of 160), 0 = not eligible; 2 / 3 are experiment variants
 int gemm_wide_pick(const GemmArgs& a) {
   if (a.out_mode != OUT_BF16) return 0;
-  if (a.act == ACT_GEGLU && (a.N % 160 != 0 || a.resid || a.rowvec)) return 0;
+  if (a.act == ACT_GEGLU && (a.resid || a.rowvec)) return 0;
   if ((a.N & 7) || (a.ld_out & 7) || (a.resid && (a.ld_res & 7))) return 0;
+  // GEGLU: the 256 x 128 sibling keeps whole (value, gate) block pairs inside a wave -> epilogue in registers
+  if (a.act == ACT_GEGLU && a.N % 128 == 0) return (long)((a.M + 255) / 256) * (a.N / 128) >= 448 ? 4 : 0;
+  if (a.act == ACT_GEGLU && a.N % 160 != 0) return 0;
   if (a.N % 160 != 0 && a.N % 128 == 0) {       // 128 / 256 / 512 / 1024 output channels (the VAE): the 256 x 128 sibling
-    if (a.act == ACT_GEGLU) return 0;
     return (long)((a.M + 255) / 256) * (a.N / 128) >= 448 ? 4 : 0;
   }
   if (a.N % 160 != 0 && a.N < 640) return 0;

@@ -46,8 +46,10 @@ def main():
               init_latents=init_drawn, hist_sel=hist_sel, category_prompts=prompts, null_prompt=null_prompt,
               scales=np.array([sc, sh, sm]), steps=steps, sched="ddim", use_history=True, use_mutual=True,
               timesteps=torch.stack([c["t"] for c in m.unet.calls]), n_calls=len(m.unet.calls), final=final,
-              generator_seed=SEED, x_in_0=m.unet.calls[0]["x"], unet_out_0=m.unet.calls[0]["out"],
-              unet_out_last=m.unet.calls[-1]["out"], unet_checksum=mg.checksum(mg.tiny_weights()),
+              generator_seed=SEED, unet_checksum=mg.checksum(mg.tiny_weights()),
+              **{f"{key}_{tag}": m.unet.calls[i][src] if key != "ehs_rows" else m.unet.calls[i]["ehs"][:, 0, :4]
+                 for tag, i in (("0", 0), ("1", 1), ("last", len(m.unet.calls) - 1))
+                 for key, src in (("x_in", "x"), ("ehs_rows", "ehs"), ("unet_out", "out"))},
               **{f"enc.{k}": v for k, v in mg.enc_state(m).items()})
     print("init drawn", tuple(init_drawn.shape), "final", tuple(final.shape), "calls", len(m.unet.calls))
 

@@ -63,7 +63,8 @@ def test_gemm_activations_and_rowvec(act, fn, tile):
     gu.assert_close_bf16(out, ref, f"act{act}")
 
 
-@pytest.mark.parametrize("M,C,tile", [(200, 64, 0), (300, 40, 0), (300, 40, 6), (520, 80, 6), (300, 40, 7), (300, 40, 8), (700, 80, 8)])
+@pytest.mark.parametrize("M,C,tile", [(200, 64, 0), (300, 40, 0), (300, 40, 6), (520, 80, 6), (300, 40, 7), (300, 40, 8), (700, 80, 8),
+                                         (300, 64, 9), (700, 80, 9), (256, 16, 9)])
 def test_gemm_geglu_epilogue(M, C, tile):
     """FeedForward GEGLU: proj -> chunk(2) -> a * gelu(gate); weights/bias interleaved by dfh_pack_*."""
     x = bf(rnd(M, C, seed=15))

@@ -287,3 +287,71 @@ def test_prompt_table_equals_per_batch_encoding():
     assert torch.equal(got, encoder(ids)[0])
     null_ids = StubTokenizer()([""], max_length=16, padding="max_length", truncation=True, return_tensors="pt").input_ids
     assert torch.equal(table.null_prompt, encoder(null_ids)[0])
+
+
+def test_checkpoints_written_by_the_reference_stack_load(tmp_path):
+    """diffusers 0.18.2 (the reference's pin) saves ``diffusion_pytorch_model.bin`` by default, so the directories the
+    reference's save hook writes (train.py:518-524) hold .bin files; published SD VAE weights name the mid-block attention
+    query / key / value / proj_attn (diffusers renames on load).  Both must load; unsupported U-Net config switches must be
+    refused instead of silently ignored."""
+    import json
+
+    import difashion_amd as da
+    from difashion_amd._lib import DfhError
+    kw = dict(sample_size=16, in_channels=8, block_out_channels=(32, 64, 64, 64), cross_attention_dim=64, attention_head_dim=(1, 2, 2, 2))
+    unet = da.UNet2DConditionModel(init_seed=5, **kw)
+    d = os.path.join(str(tmp_path), "unet")
+    unet.save_pretrained(d)
+    os.remove(os.path.join(d, "diffusion_pytorch_model.safetensors"))
+    with pytest.raises(FileNotFoundError, match="diffusion_pytorch_model.safetensors, diffusion_pytorch_model.bin"):
+        da.UNet2DConditionModel.from_pretrained(str(tmp_path), subfolder="unet")
+    torch.save({k: v.clone() for k, v in unet.state_dict().items()}, os.path.join(d, "diffusion_pytorch_model.bin"))
+    u2 = da.UNet2DConditionModel.from_pretrained(str(tmp_path), subfolder="unet")
+    assert all(torch.equal(a, b) for a, b in zip(unet.state_dict().values(), u2.state_dict().values()))
+    # variant infix: diffusion_pytorch_model.fp16.bin wins over the plain file when asked for
+    sd16 = {k: (v + 1).clone() for k, v in unet.state_dict().items()}
+    torch.save(sd16, os.path.join(d, "diffusion_pytorch_model.fp16.bin"))
+    u3 = da.UNet2DConditionModel.from_pretrained(str(tmp_path), subfolder="unet", variant="fp16")
+    assert torch.equal(u3.state_dict()["conv_in.bias"], unet.state_dict()["conv_in.bias"] + 1)
+    # EMA directory as the reference's hook writes it (.bin) -> EMAModel.from_pretrained
+    ema = da.EMAModel(unet.parameters(), decay=0.99, model_cls=da.UNet2DConditionModel, model_config=unet.config)
+    ed = os.path.join(str(tmp_path), "unet_ema")
+    ema.save_pretrained(ed)
+    from safetensors.torch import load_file
+    sd = load_file(os.path.join(ed, "diffusion_pytorch_model.safetensors"))
+    os.remove(os.path.join(ed, "diffusion_pytorch_model.safetensors"))
+    torch.save(sd, os.path.join(ed, "diffusion_pytorch_model.bin"))
+    e2 = da.EMAModel.from_pretrained(ed, da.UNet2DConditionModel)
+    assert all(torch.equal(a, b) for a, b in zip(ema.shadow_params, e2.shadow_params))
+
+    # VAE: old attention key names, projections stored as 1x1 convs in some exports
+    vae = da.AutoencoderKL(block_out_channels=(32, 64, 64, 64), sample_size=32, init_seed=6)
+    vd = os.path.join(str(tmp_path), "vae")
+    vae.save_pretrained(vd)
+    os.remove(os.path.join(vd, "diffusion_pytorch_model.safetensors"))
+    old = {}
+    ren = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_attn"}
+    for k, v in vae.state_dict().items():
+        for new_name, old_name in ren.items():
+            if f".attentions.0.{new_name}." in k:
+                k = k.replace(f".attentions.0.{new_name}.", f".attentions.0.{old_name}.")
+                if k.endswith("weight") and "encoder" in k:
+                    v = v[:, :, None, None]
+        old[k] = v.clone()
+    assert any(".query." in k for k in old) and any(v.dim() == 4 and ".key." in k for k, v in old.items())
+    torch.save(old, os.path.join(vd, "diffusion_pytorch_model.bin"))
+    v2 = da.AutoencoderKL.from_pretrained(str(tmp_path), subfolder="vae")
+    assert all(torch.equal(a, b) for a, b in zip(vae.state_dict().values(), v2.state_dict().values()))
+
+    # config switches the native walk does not implement are refused
+    for bad in (dict(act_fn="gelu"), dict(upcast_attention=True), dict(class_embed_type="timestep"), dict(resnet_time_scale_shift="scale_shift"),
+                dict(only_cross_attention=[True, False, False, False]), dict(flip_sin_to_cos=False), dict(num_class_embeds=10)):
+        with pytest.raises(DfhError, match="not implemented"):
+            da.UNet2DConditionModel(init_seed=None, **kw, **bad)
+    # ... and the SD defaults a real config.json carries are accepted
+    cfg = json.load(open(os.path.join(d, "config.json")))
+    cfg.update(act_fn="silu", upcast_attention=False, only_cross_attention=False, dual_cross_attention=False, class_embed_type=None,
+               num_class_embeds=None, resnet_time_scale_shift="default", flip_sin_to_cos=True, freq_shift=0, center_input_sample=False,
+               downsample_padding=1, mid_block_scale_factor=1, mid_block_type="UNetMidBlock2DCrossAttn")
+    json.dump(cfg, open(os.path.join(d, "config.json"), "w"))
+    da.UNet2DConditionModel.from_pretrained(str(tmp_path), subfolder="unet")

@@ -142,6 +142,12 @@ SIGNATURES = {
     "dfh_ema": (_i, [_vp, _vp, _sz, _f, _vp]),
     "dfh_adamw_ema": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp]),
     "dfh_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "dfh_quantize_rows_fp8": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
+    "dfh_layernorm_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "dfh_gemm_fp8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "dfh_unet_enable_fp8": (_i, [_vp]),
+    "dfh_unet_arena8_bytes": (_sz, [_vp]),
+    "dfh_unet_bind_fp8": (_i, [_vp, _vp]),
     "dfh_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "dfh_timestep_embedding": (_i, [_vp, _vp, _i, _i, _vp]),
     "dfh_nchw_to_nhwc_bf16": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),

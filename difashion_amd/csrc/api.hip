@@ -82,7 +82,7 @@ int dfh_prof_end(dfh_prof_class* out, int max_classes) {
   dfh::g_prof = false;
   DFH_REQUIRE(out != nullptr && max_classes >= dfh::PC_COUNT, "need room for every kernel class");
   static const char* names[dfh::PC_COUNT] = {"gemm_conv3x3", "gemm_linear", "attention", "groupnorm", "layernorm", "splitk_reduce", "other",
-                                                  "gemm_wgrad", "attention_bwd", "norm_bwd", "optimizer"};
+                                                  "gemm_wgrad", "attention_bwd", "norm_bwd", "optimizer", "gemm_linear_fp8"};
   for (int i = 0; i < dfh::PC_COUNT; ++i) {
     std::memset(&out[i], 0, sizeof(out[i]));
     std::strncpy(out[i].name, names[i], sizeof(out[i].name) - 1);
@@ -273,6 +273,22 @@ int dfh_ema(float* shadow, const float* p, size_t n, float decay, void* stream) 
 
 int dfh_layernorm(const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps, void* stream) {
   return dfh::layernorm_launch((const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps, (hipStream_t)stream);
+}
+
+int dfh_gemm_fp8(const void* A, const float* sA, const void* W, const float* sW, int M, int N, int K, const float* bias,
+                 const void* resid, int ld_res, int act, void* out, int ld_out, int out_mode, int rows_per_b, const void* zero_page,
+                 void* stream) {
+  Fp8GemmArgs g; std::memset(&g, 0, sizeof(g));
+  g.A = (const uint8_t*)A; g.sA = sA; g.W = (const uint8_t*)W; g.sW = sW; g.M = M; g.N = N; g.K = K; g.bias = bias;
+  g.resid = (const bf16_t*)resid; g.ld_res = ld_res; g.act = act; g.out = out; g.ld_out = ld_out; g.out_mode = out_mode;
+  g.rows_per_b = rows_per_b; g.zero = (const uint8_t*)zero_page;
+  return dfh::gemm_fp8_launch(g, (hipStream_t)stream);
+}
+int dfh_quantize_rows_fp8(const void* x, int ldx, void* q, float* scale, int R, int K, void* stream) {
+  return dfh::quant_rows_fp8_launch((const bf16_t*)x, ldx, (uint8_t*)q, scale, R, K, (hipStream_t)stream);
+}
+int dfh_layernorm_fp8(const void* x, const float* gamma, const float* beta, void* q, float* scale, int M, int C, float eps, void* stream) {
+  return dfh::layernorm_fp8_launch((const bf16_t*)x, gamma, beta, (uint8_t*)q, scale, M, C, eps, (hipStream_t)stream);
 }
 
 int dfh_attention(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo, int batch,

@@ -101,7 +101,7 @@ void set_error(const std::string& msg);  // api.cpp
 int check_launch(const char* what);     // returns 0 or negative and records the message
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline).
 enum ProfClass { PC_CONV3 = 0, PC_LINEAR = 1, PC_ATTN = 2, PC_GNORM = 3, PC_LNORM = 4, PC_SPLITK = 5, PC_OTHER = 6,
-                 PC_WGRAD = 7, PC_ATTN_BWD = 8, PC_NORM_BWD = 9, PC_OPTIM = 10, PC_COUNT = 11 };
+                 PC_WGRAD = 7, PC_ATTN_BWD = 8, PC_NORM_BWD = 9, PC_OPTIM = 10, PC_LINEAR_FP8 = 11, PC_COUNT = 12 };
 bool prof_enabled();
 void prof_open(int cls, double flops, double bytes, hipStream_t s);   // no-ops unless enabled
 void prof_close(hipStream_t s);

@@ -40,7 +40,26 @@ struct GemmArgs {
   float* partial;  // [ksplit][M][N] fp32 when ksplit > 1
 };
 
+// fp8 (OCP e4m3fn) linear: out[m][n] = epilogue(sA[m] * sW[n] * sum_k A8[m][k] * W8[n][k]); gemm_fp8.hip
+struct Fp8GemmArgs {
+  const uint8_t* A; const float* sA;   // [M][K] e4m3 activations, one scale per row (token)
+  const uint8_t* W; const float* sW;   // [N][K] e4m3 weights, one scale per row (output channel)
+  int M, N, K;                          // K a multiple of 64
+  const float* bias;                    // [N] or null
+  const bf16_t* resid; int ld_res;      // optional residual (OUT_BF16 only)
+  int act;                              // ACT_NONE / ACT_GEGLU (packed rows interleaved in 16-row value / gate blocks)
+  void* out; int ld_out; int out_mode;  // OUT_BF16 / OUT_BF16_T
+  int rows_per_b;                       // OUT_BF16_T: rows per batch element
+  const uint8_t* zero;                  // >= 16 bytes of zeros in device memory
+};
+
 namespace dfh {
+int gemm_fp8_launch(const Fp8GemmArgs& a, hipStream_t stream);
+// bf16 [R][K] (row stride ldx) -> e4m3 [R][K] + one scale per row (amax / 448)
+int quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, float* scale, int R, int K, hipStream_t stream);
+// LayerNorm whose output is quantised per token: q [M][C] e4m3, scale [M]
+int layernorm_fp8_launch(const bf16_t* x, const float* gamma, const float* beta, uint8_t* q, float* scale, int M, int C, float eps,
+                         hipStream_t stream);
 // Picks a tile shape + split-K factor, launches, and (if split) launches the reduce.  ``partial``
 // must hold gemm_partial_floats(...) floats when the heuristic splits.
 int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile = 0, int force_split = 0, int force_glds = -1);

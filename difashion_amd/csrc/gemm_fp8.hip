@@ -1,0 +1,377 @@
+// fp8 (OCP e4m3fn) linear layers on the block-scaled MFMA of gfx950 -- BASELINE.json configs[4]: "fp8 MFMA attention +
+// 1x1-conv path".  Covers the LayerNorm-fed projections of every transformer block (self-attention q | k and v, cross-attention
+// q, the GEGLU feed-forward input projection: 60 % of the linear-class FLOPs; reference call sites
+// DiFashion/models/difashion.py:249-253,518-523 -> diffusers BasicTransformerBlock attn1 / attn2 / ff.net.0).  The reference runs
+// these in fp16 autocast (run_inf4eval.sh:1); fp8 is this project's own target, parity-tested against the fp32 oracle.
+//
+// Scaling: activations per TOKEN (the LayerNorm kernel that produces them sees the whole row: amax -> scale, one extra float
+// per row), weights per OUTPUT CHANNEL (quantised once per weight update from the packed bf16 matrix); the product of the two
+// scales is applied to the fp32 accumulator in the epilogue.  The hardware block scales (E8M0 per 32 contraction elements) are
+// held at 1.0: v_mfma_scale_f32_32x32x64_f8f6f4 is used for its 2x rate (2048 flop / cycle / SIMD, 4.6 PFLOP/s measured chip
+// wide) -- there is no non-scaled fp8 MFMA with K = 64.
+//
+// Kernel: 4 waves side by side along the pixels (wave = PB x 32 pixels x 160 channels, 5 x PB 32x32 accumulator blocks), 64-byte
+// (= 64-element) k-steps, 3-stage LDS ring filled by global_load_lds_dwordx4 (lane-linear image, 16-byte slots XOR-swizzled by
+// (row >> 2) & 3 on the SOURCE address and on the fragment read: conflict-free for the 32-row fragments), counted vmcnt + one raw
+// barrier per k-step, weights as the MFMA A operand so a lane ends with 4 consecutive output channels of one pixel; epilogue in
+// registers (scales, bias, GEGLU on the (value, gate) rows a lane holds of one 32-row block, residual), bf16 tile staged per wave
+// through LDS for full-row 16-byte stores.
+#include "gemm.h"
+
+#include <algorithm>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int KB8 = 64;          // bytes (= fp8 elements) per k-step = one MFMA contraction
+constexpr int BN8 = 160;
+constexpr int NST8 = 3;
+
+template <int N> DFH_DEVICE void f8_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int PB>
+__global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
+  constexpr int BM = 4 * PB * 32;
+  constexpr int PA = BM / 16, PW = BN8 / 16;                 // 1-KiB staging pieces (16 rows x 64 B)
+  constexpr int IA = PA / 4, IW = (PW + 3) / 4;
+  constexpr int A_BYTES = BM * KB8, W_BYTES = BN8 * KB8, STAGE = A_BYTES + W_BYTES;
+  constexpr int N_LO = IA + PW / 4, N_HI = N_LO + 1, PW_REM = PW % 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ql = lane & 31, kh = lane >> 5;
+  const int ntn = (a.N + BN8 - 1) / BN8, ntm = (a.M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN8;
+  const int nk = a.K / KB8;
+  const bool hi_wave = wave < PW_REM;
+
+  // ---- staging: piece p = i * 4 + wave holds tile rows p*16 + lane/4; slot s of row r holds source chunk s ^ ((r >> 2) & 3)
+  const int srow = lane >> 2;
+  const int schunk = (lane & 3) ^ ((srow >> 2) & 3);
+  const uint8_t* lp_a[IA]; const uint8_t* lp_w[IW];
+  unsigned ls_a[IA], ls_w[IW];
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    const int m = m0 + (i * 4 + wave) * 16 + srow;
+    const bool ok = m < a.M;
+    lp_a[i] = ok ? a.A + ((size_t)m * a.K + schunk * 16) : a.zero;
+    ls_a[i] = ok ? KB8 : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < IW; ++i) {
+    const int n = n0 + (i * 4 + wave) * 16 + srow;
+    const bool ok = n < a.N && i * 4 + wave < PW;
+    lp_w[i] = ok ? a.W + ((size_t)n * a.K + schunk * 16) : a.zero;
+    ls_w[i] = ok ? KB8 : 0;
+  }
+  auto glds = [&](const uint8_t* src, unsigned char* dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto issue = [&](int buf) {
+    unsigned char* As = smem + buf * STAGE + wave * 1024;
+    unsigned char* Ws = As + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) { glds(lp_a[i], As + i * 4096); lp_a[i] += ls_a[i]; }
+#pragma unroll
+    for (int i = 0; i < IW; ++i) {
+      if (i * 4 + wave >= PW) continue;                      // wave-uniform
+      glds(lp_w[i], Ws + i * 4096); lp_w[i] += ls_w[i];
+    }
+  };
+
+  f32x16_t acc[5][PB];
+#pragma unroll
+  for (int ci = 0; ci < 5; ++ci)
+#pragma unroll
+    for (int pj = 0; pj < PB; ++pj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ci][pj][r] = 0.f;
+
+  // fragment read offsets inside a stage: row * 64 + ((2 kh + c) ^ ((row >> 2) & 3)) * 16; (row >> 2) & 3 depends on ql only
+  const int sw = (ql >> 2) & 3;
+  const int f0 = ((2 * kh) ^ sw) << 4, f1 = ((2 * kh + 1) ^ sw) << 4;
+  const int x_row = (wave * PB * 32 + ql) * KB8;
+  const int w_row = A_BYTES + ql * KB8;
+  const int unit_scale = 0x7f7f7f7f;                         // E8M0 127 = 2^0 in every block-scale slot
+
+  if (nk > 0) {
+    int issued = 0;
+#pragma unroll
+    for (int s = 0; s < NST8 - 1; ++s)
+      if (s < nk) { issue(s); ++issued; }
+    int buf = 0;
+    for (int t = 0; t < nk; ++t) {
+      const int ahead = issued - 1 - t;
+      if (ahead == 0) f8_vmcnt<0>();
+      else if (ahead == 1) { if (hi_wave) f8_vmcnt<N_HI>(); else f8_vmcnt<N_LO>(); }
+      else { if (hi_wave) f8_vmcnt<2 * N_HI>(); else f8_vmcnt<2 * N_LO>(); }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (issued < nk) {
+        int nb = buf - 1; if (nb < 0) nb += NST8;
+        issue(nb);
+        ++issued;
+      }
+      const unsigned char* S = smem + buf * STAGE;
+      i32x8_t xf[PB];
+#pragma unroll
+      for (int pj = 0; pj < PB; ++pj) {
+        const uint4 lo = *(const uint4*)(S + x_row + pj * 32 * KB8 + f0), hi4 = *(const uint4*)(S + x_row + pj * 32 * KB8 + f1);
+        xf[pj] = i32x8_t{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi4.x, (int)hi4.y, (int)hi4.z, (int)hi4.w};
+      }
+#pragma unroll
+      for (int ci = 0; ci < 5; ++ci) {
+        const uint4 lo = *(const uint4*)(S + w_row + ci * 32 * KB8 + f0), hi4 = *(const uint4*)(S + w_row + ci * 32 * KB8 + f1);
+        const i32x8_t wf = i32x8_t{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi4.x, (int)hi4.y, (int)hi4.z, (int)hi4.w};
+#pragma unroll
+        for (int pj = 0; pj < PB; ++pj)
+          acc[ci][pj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf, xf[pj], acc[ci][pj], 0, 0, 0, unit_scale, 0, unit_scale);
+      }
+      if (++buf == NST8) buf = 0;
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  // lane (pixel ql, half kh) holds of block (ci, pj): channels ci*32 + 8 (r >> 2) + 4 kh + (r & 3), r = 0..15
+  __syncthreads();                                           // pipeline buffers free: per-wave staging regions below
+  const bool geglu = a.act == ACT_GEGLU;
+  constexpr int RS = BN8 * 2 + 16;                           // bf16 row stride of a wave's staged 32-row block
+  unsigned char* stage = smem + wave * (32 * RS);
+#pragma unroll
+  for (int pj = 0; pj < PB; ++pj) {
+    const int m = m0 + wave * PB * 32 + pj * 32 + ql;
+    const float sa = m < a.M ? a.sA[m] : 0.f;
+    if (a.out_mode == OUT_BF16_T) {                          // attention V^T: out[b][n][mm], scattered 2-byte stores
+      if (m < a.M) {
+        const int b = m / a.rows_per_b, mm = m - b * a.rows_per_b;
+#pragma unroll
+        for (int ci = 0; ci < 5; ++ci)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = n0 + ci * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+            if (n < a.N) {
+              float v = acc[ci][pj][r] * sa * a.sW[n];
+              if (a.bias) v += a.bias[n];
+              ((bf16_t*)a.out)[((long)b * a.N + n) * a.ld_out + mm] = f2bf(v);
+            }
+          }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int ci = 0; ci < 5; ++ci) {
+      if (geglu) {
+        // rows 0..15 of a 32-row block are values, 16..31 the gates of the same 16 hidden units (packed in 16-row blocks)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int nv = n0 + ci * 32 + 8 * g + 4 * kh;      // packed row of the value; its gate is 16 rows further
+          float4 swv = float4{0, 0, 0, 0}, swg = swv, bv = swv, bg = swv;
+          if (nv + 16 < a.N) {
+            swv = *(const float4*)(a.sW + nv); swg = *(const float4*)(a.sW + nv + 16);
+            if (a.bias) { bv = *(const float4*)(a.bias + nv); bg = *(const float4*)(a.bias + nv + 16); }
+          }
+          const float v0 = acc[ci][pj][4 * g] * sa * swv.x + bv.x, v1 = acc[ci][pj][4 * g + 1] * sa * swv.y + bv.y;
+          const float v2 = acc[ci][pj][4 * g + 2] * sa * swv.z + bv.z, v3 = acc[ci][pj][4 * g + 3] * sa * swv.w + bv.w;
+          const float g0 = acc[ci][pj][8 + 4 * g] * sa * swg.x + bg.x, g1 = acc[ci][pj][9 + 4 * g] * sa * swg.y + bg.y;
+          const float g2 = acc[ci][pj][10 + 4 * g] * sa * swg.z + bg.z, g3 = acc[ci][pj][11 + 4 * g] * sa * swg.w + bg.w;
+          uint2 o;
+          o.x = pack2bf(v0 * gelu_erf_f(g0), v1 * gelu_erf_f(g1));
+          o.y = pack2bf(v2 * gelu_erf_f(g2), v3 * gelu_erf_f(g3));
+          *(uint2*)(stage + ql * RS + (ci * 16 + 8 * g + 4 * kh) * 2) = o;
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = ci * 32 + 8 * g + 4 * kh, n = n0 + col;
+          float4 sw4 = float4{0, 0, 0, 0}, b4 = sw4;
+          if (n < a.N) { sw4 = *(const float4*)(a.sW + n); if (a.bias) b4 = *(const float4*)(a.bias + n); }
+          float v[4] = {acc[ci][pj][4 * g] * sa * sw4.x + b4.x, acc[ci][pj][4 * g + 1] * sa * sw4.y + b4.y,
+                        acc[ci][pj][4 * g + 2] * sa * sw4.z + b4.z, acc[ci][pj][4 * g + 3] * sa * sw4.w + b4.w};
+          if (a.resid && m < a.M && n < a.N) {
+            const uint2 rr = *(const uint2*)(a.resid + (long)m * a.ld_res + n);
+            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+          }
+          uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+          *(uint2*)(stage + ql * RS + col * 2) = o;
+        }
+      }
+    }
+    // the wave's own 32-row block -> full rows, 16 bytes per lane (LDS accesses of one wave complete in order)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int ocols = geglu ? BN8 / 2 : BN8;                 // output columns of this tile
+    const int cpr = ocols / 8;
+    const int obase = geglu ? (n0 >> 1) : n0, olim = geglu ? (a.N >> 1) : a.N;
+    for (int c = lane; c < 32 * cpr; c += 64) {
+      const int row = c / cpr, cc = c - row * cpr;
+      const int mr = m0 + wave * PB * 32 + pj * 32 + row, oc = obase + cc * 8;
+      if (mr < a.M && oc < olim)
+        *(uint4*)((bf16_t*)a.out + (long)mr * a.ld_out + oc) = *(const uint4*)(stage + row * RS + cc * 16);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next block overwrites the region
+  }
+}
+
+// ---- quantisers -------------------------------------------------------------------------------------------------------------
+DFH_DEVICE unsigned pack4_fp8(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (unsigned)w;
+}
+constexpr float FP8_MAX = 448.0f;
+
+// one wave per row of a bf16 [R][K] matrix: scale[r] = amax / 448 (1 for an all-zero row), q = round(x / scale) as e4m3
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, int ldx, uint8_t* __restrict__ q,
+                                                             float* __restrict__ scale, int R, int K) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const bf16_t* xr = x + (long)row * ldx;
+  float amax = 0.f;
+  for (int o = lane * 8; o < K; o += 512) {
+    float f[8];
+    unpack8(*(const uint4*)(xr + o), f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(f[k]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  const float sc = amax > 0.f ? amax / FP8_MAX : 1.0f;
+  const float inv = 1.0f / sc;
+  if (lane == 0) scale[row] = sc;
+  for (int o = lane * 8; o < K; o += 512) {
+    float f[8];
+    unpack8(*(const uint4*)(xr + o), f);
+    uint2 w;
+    w.x = pack4_fp8(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv);
+    w.y = pack4_fp8(f[4] * inv, f[5] * inv, f[6] * inv, f[7] * inv);
+    *(uint2*)(q + (long)row * K + o) = w;
+  }
+}
+
+// LayerNorm with the fp8 quantisation of its output fused: one wave per token row (C <= 2048), exact two-pass variance in
+// registers like layernorm_kernel (norm.hip); the row maximum of |y| gives the token's scale.
+template <int MAXO>
+__global__ __launch_bounds__(256) void layernorm_fp8_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, uint8_t* __restrict__ q,
+                                                            float* __restrict__ scale, int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int C8 = C >> 3;
+  float v[MAXO][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXO; ++i) {
+    const int o = lane + i * 64;
+    if (o < C8) {
+      unpack8(*(const uint4*)(x + (long)row * C + o * 8), v[i]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[i][k];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float qq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXO; ++i) {
+    const int o = lane + i * 64;
+    if (o < C8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; qq += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(qq) / (float)C + eps);
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXO; ++i) {
+    const int o = lane + i * 64;
+    if (o < C8) {
+      const float4 g0 = *(const float4*)(gamma + o * 8), g1 = *(const float4*)(gamma + o * 8 + 4);
+      const float4 b0 = *(const float4*)(beta + o * 8), b1 = *(const float4*)(beta + o * 8 + 4);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        // the bf16 path rounds the normalised value to bf16 before the GEMM reads it; quantise that same value
+        v[i][k] = bf2f(f2bf((v[i][k] - mean) * rstd * gg[k] + bb[k]));
+        amax = fmaxf(amax, fabsf(v[i][k]));
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  const float sc = amax > 0.f ? amax / FP8_MAX : 1.0f;
+  const float inv = 1.0f / sc;
+  if (lane == 0) scale[row] = sc;
+#pragma unroll
+  for (int i = 0; i < MAXO; ++i) {
+    const int o = lane + i * 64;
+    if (o < C8) {
+      uint2 w;
+      w.x = pack4_fp8(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv);
+      w.y = pack4_fp8(v[i][4] * inv, v[i][5] * inv, v[i][6] * inv, v[i][7] * inv);
+      *(uint2*)(q + (long)row * C + o * 8) = w;
+    }
+  }
+}
+
+template <int PB>
+int launch_fp8(const Fp8GemmArgs& a, hipStream_t s) {
+  constexpr int BM = 4 * PB * 32;
+  constexpr int lds = NST8 * (BM + BN8) * KB8;
+  static_assert(4 * 32 * (BN8 * 2 + 16) <= lds, "per-wave epilogue staging must fit the pipeline buffers");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_fp8_kernel<PB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN8 - 1) / BN8);
+  hipLaunchKernelGGL((gemm_fp8_kernel<PB>), dim3(tiles), dim3(256), lds, s, a);
+  return dfh::check_launch("gemm_fp8_kernel");
+}
+
+}  // namespace
+
+namespace dfh {
+
+int gemm_fp8_launch(const Fp8GemmArgs& a, hipStream_t stream) {
+  DFH_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "empty fp8 GEMM");
+  DFH_REQUIRE(a.K % KB8 == 0, "fp8 GEMM: K must be a multiple of 64");
+  DFH_REQUIRE(a.N % 8 == 0, "fp8 GEMM: N must be a multiple of 8");
+  DFH_REQUIRE(a.A && a.W && a.sA && a.sW && a.zero && a.out, "fp8 GEMM: null operand");
+  DFH_REQUIRE(a.out_mode == OUT_BF16 || a.out_mode == OUT_BF16_T, "fp8 GEMM: bf16 outputs only");
+  DFH_REQUIRE(a.act == ACT_NONE || a.act == ACT_GEGLU, "fp8 GEMM: no activation or GEGLU");
+  if (a.act == ACT_GEGLU) DFH_REQUIRE(a.N % 32 == 0 && !a.resid && a.out_mode == OUT_BF16, "fp8 GEGLU: N % 32 == 0, bias only, bf16 out");
+  if (a.out_mode == OUT_BF16) DFH_REQUIRE(a.ld_out % 8 == 0, "fp8 GEMM: output rows must be 16-byte aligned");
+  if (a.out_mode == OUT_BF16_T) DFH_REQUIRE(a.rows_per_b > 0 && !a.resid, "fp8 GEMM: transposed output needs rows_per_b, no residual");
+  ProfScope ps(PC_LINEAR_FP8, 2.0 * a.M * a.N * (double)a.K,
+               (double)a.M * a.K + (double)a.N * a.K + 2.0 * a.M * (a.act == ACT_GEGLU ? a.N / 2 : a.N), stream);
+  // 256-row tiles while they still give every CU two workgroups, 128-row tiles below
+  const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + BN8 - 1) / BN8);
+  return tiles256 >= 384 ? launch_fp8<2>(a, stream) : launch_fp8<1>(a, stream);
+}
+
+int quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, float* scale, int R, int K, hipStream_t stream) {
+  DFH_REQUIRE(R > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0, "fp8 row quantiser: K and the row stride must be multiples of 8");
+  hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, x, ldx, q, scale, R, K);
+  return check_launch("quant_rows_fp8_kernel");
+}
+
+int layernorm_fp8_launch(const bf16_t* x, const float* gamma, const float* beta, uint8_t* q, float* scale, int M, int C, float eps,
+                         hipStream_t stream) {
+  DFH_REQUIRE(C % 8 == 0 && C <= 8 * 64 * 4, "LayerNorm width must be a multiple of 8 and <= 2048");
+  const dim3 grid((M + 3) / 4), block(256);
+  ProfScope ps(PC_LNORM, 0.0, 3.0 * (double)M * C + 4.0 * M, stream);
+  if (C <= 512) hipLaunchKernelGGL(layernorm_fp8_kernel<1>, grid, block, 0, stream, x, gamma, beta, q, scale, M, C, eps);
+  else if (C <= 1024) hipLaunchKernelGGL(layernorm_fp8_kernel<2>, grid, block, 0, stream, x, gamma, beta, q, scale, M, C, eps);
+  else hipLaunchKernelGGL(layernorm_fp8_kernel<4>, grid, block, 0, stream, x, gamma, beta, q, scale, M, C, eps);
+  return check_launch("layernorm_fp8_kernel");
+}
+
+}  // namespace dfh

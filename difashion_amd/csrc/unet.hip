@@ -64,6 +64,20 @@ int dfh_unet_bind(dfh_unet* u, void* arena16, void* arena32, void* workspace, si
   return 0;
 }
 
+int dfh_unet_enable_fp8(dfh_unet* u) {
+  DFH_REQUIRE(u != nullptr, "null argument");
+  DFH_REQUIRE(u->ws == nullptr, "dfh_unet_enable_fp8 must precede dfh_unet_workspace_bytes / dfh_unet_bind");
+  return u->enable_fp8();
+}
+size_t dfh_unet_arena8_bytes(const dfh_unet* u) { return u && u->fp8 ? u->a8 : 0; }
+int dfh_unet_bind_fp8(dfh_unet* u, void* arena8) {
+  DFH_REQUIRE(u && arena8, "null argument");
+  DFH_REQUIRE(u->fp8, "dfh_unet_enable_fp8 not called");
+  DFH_REQUIRE((uintptr_t)arena8 % 256 == 0, "buffers must be 256-byte aligned");
+  u->arena8 = (unsigned char*)arena8;
+  return 0;
+}
+
 int dfh_unet_pack(dfh_unet* u, const float* const* master_params, int count, void* stream) {
   DFH_REQUIRE(u && master_params, "null argument");
   return u->pack(master_params, count, (hipStream_t)stream);
@@ -74,6 +88,7 @@ int dfh_unet_forward(dfh_unet* u, const void* sample, int sample_bf16, const flo
   DFH_REQUIRE(u && sample && timestep && ehs && out, "null argument");
   DFH_REQUIRE(u->ws != nullptr, "dfh_unet_bind not called");
   DFH_REQUIRE(batch > 0 && batch <= u->max_batch, "batch exceeds the bound max_batch");
+  DFH_REQUIRE(!u->fp8 || u->arena8, "fp8 enabled but dfh_unet_bind_fp8 not called");
   if (batch != u->plan_batch) u->run(nullptr, 0, nullptr, nullptr, 0, nullptr, batch, nullptr, true);
   DFH_REQUIRE(u->plan_total <= u->ws_bytes, "workspace too small for this batch");
   return u->run(sample, sample_bf16, timestep, ehs, ehs_bf16, out, batch, (hipStream_t)stream, false);

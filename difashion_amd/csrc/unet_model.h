@@ -34,6 +34,8 @@ struct ParamDesc { std::string name; std::vector<int> shape; };
 // transposed pack (training): master weight -> arena16t, see bwd_elementwise.hip pack_*_t kernels
 struct TPackOp { int param, conv; size_t dst; int N, K, ldt, t_row_off, t_col_off, geglu, o_pad; };
 
+struct Mat8 { size_t off = 0, soff = 0; int N = 0, K = 0; bool on = false; };   // fp8 [N][K] at arena8 + off, scales (floats) at arena8 + soff
+
 struct ResL {
   int cin = 0, cout = 0, temb_off = 0; bool shortcut = false;
   Vec n1w, n1b, b1, n2w, n2b, b2; Mat w1, w2;
@@ -44,6 +46,7 @@ struct AttL {
   Vec nw, nb, pinb, l1w, l1b, o1b, l2w, l2b, o2b, l3w, l3b, ff1b, ff2b, poutb;
   Mat pin, qk, v, o1, q2, o2, ff1, ff2, pout;
   std::string pre; Mat pint, qkvt, o1t, q2t, o2t, ff1t, ff2t, poutt;
+  Mat8 qk8, v8, q28, ff18;           // fp8 copies of the LayerNorm-fed projections (gemm_fp8.hip), when enabled
 };
 struct ConvL { Mat w; Vec b; int cin = 0, cout = 0; std::string pre; Mat wt; };
 
@@ -112,6 +115,8 @@ struct dfh_unet {
   char* ws = nullptr; size_t ws_bytes = 0; int max_batch = 0;
   // planning results (bytes) for the last planned batch
   size_t plan_persist = 0, plan_temp = 0, plan_partial = 0, plan_total = 0; int plan_batch = 0;
+  // fp8 linears (BASELINE configs[4]): e4m3 copies of qk / v / q2 / ff1 + per-row scales, in one caller-owned arena
+  bool fp8 = false; unsigned char* arena8 = nullptr; size_t a8 = 0;
   // taps of the last forward
   std::map<std::string, Tensor> taps; int last_batch = 0;
   // ---- training state (unet_train.hip)
@@ -330,6 +335,44 @@ struct dfh_unet {
     return 0;
   }
 
+  // ---------------------------------------------------------------- fp8
+  std::vector<AttL*> all_att() {
+    std::vector<AttL*> v;
+    for (auto& lv : down_att) for (auto& a : lv) v.push_back(&a);
+    v.push_back(&mid_att);
+    for (auto& lv : up_att) for (auto& a : lv) v.push_back(&a);
+    return v;
+  }
+  // fp8 copies exist for the transformer layers whose width the 64-deep contraction divides
+  int enable_fp8() {
+    if (fp8) return 0;
+    a8 = 0;
+    auto take = [&](const Mat& m, Mat8& q) {
+      q.N = m.N; q.K = m.K; q.on = true;
+      q.off = a8; a8 += ((size_t)m.N * m.K + 255) & ~(size_t)255;
+      q.soff = a8; a8 += ((size_t)m.N * sizeof(float) + 255) & ~(size_t)255;
+    };
+    for (AttL* a : all_att()) {
+      if (a->C % 64) continue;
+      take(a->qk, a->qk8); take(a->v, a->v8); take(a->q2, a->q28); take(a->ff1, a->ff18);
+    }
+    fp8 = true;
+    return 0;
+  }
+  int quantize_fp8(hipStream_t s) {
+    if (!fp8 || !arena8) return 0;
+    for (AttL* a : all_att()) {
+      const Mat* src[4] = {&a->qk, &a->v, &a->q2, &a->ff1};
+      const Mat8* dst[4] = {&a->qk8, &a->v8, &a->q28, &a->ff18};
+      for (int i = 0; i < 4; ++i) {
+        if (!dst[i]->on) continue;
+        if (int rc = dfh::quant_rows_fp8_launch(arena16 + src[i]->off, src[i]->K, arena8 + dst[i]->off, (float*)(arena8 + dst[i]->soff),
+                                                src[i]->N, src[i]->K, s)) return rc;
+      }
+    }
+    return 0;
+  }
+
   // ---------------------------------------------------------------- run
   struct Run {
     dfh_unet* u; int B; hipStream_t s; bool dry;
@@ -374,6 +417,22 @@ struct dfh_unet {
       a.B = B; a.HW = x0.H * x0.W; a.G = u->cfg.norm_num_groups;
       a.gamma = v32(w); a.beta = v32(b); a.eps = eps; a.silu = silu; a.out = out.p; a.partial = gn_partial;
       rc = dfh::groupnorm_launch(a, s);
+    }
+    bool use8(const Mat8& m) const { return u->fp8 && m.on; }        // the forward entry checks that arena8 is bound
+    // LayerNorm whose output is quantised per token + the fp8 GEMM that consumes it (gemm_fp8.hip)
+    void layernorm8(const bf16_t* x, const Vec& w, const Vec& b, uint8_t* q, float* sc, int M, int C) {
+      if (rc || dry) return;
+      rc = dfh::layernorm_fp8_launch(x, v32(w), v32(b), q, sc, M, C, 1e-5f, s);
+    }
+    void linear8(const uint8_t* q, const float* sc, int M, const Mat8& W, const Vec* bias, int act, void* out, int out_mode = OUT_BF16,
+                 int ld_out = -1, int rows_per_b = 0) {
+      if (rc || dry) return;
+      Fp8GemmArgs g; std::memset(&g, 0, sizeof(g));
+      g.A = q; g.sA = sc; g.W = u->arena8 + W.off; g.sW = (const float*)(u->arena8 + W.soff);
+      g.M = M; g.N = W.N; g.K = W.K; g.bias = bias ? v32(*bias) : nullptr; g.act = act;
+      g.out = out; g.out_mode = out_mode; g.ld_out = ld_out < 0 ? (act == ACT_GEGLU ? W.N / 2 : W.N) : ld_out;
+      g.rows_per_b = rows_per_b; g.zero = (const uint8_t*)zero;
+      rc = dfh::gemm_fp8_launch(g, s);
     }
     void layernorm(const bf16_t* x, const Vec& w, const Vec& b, bf16_t* y, int M, int C) {
       if (rc || dry) return;
@@ -450,29 +509,41 @@ struct dfh_unet {
       linear(gn.p, M, C, a.pin, &a.pinb, ACT_NONE, nullptr, h0.p, C);
       // --- self attention
       Tensor n1 = talloc(H, W, C);
-      layernorm(h0.p, a.l1w, a.l1b, n1.p, M, C);
+      const bool f8 = use8(a.qk8);                    // fp8 path: LayerNorm -> e4m3 + token scales -> block-scaled MFMA GEMM
+      uint8_t* n8 = f8 ? (uint8_t*)temp.alloc((size_t)M * C) : nullptr;
+      float* s8 = f8 ? (float*)temp.alloc((size_t)M * sizeof(float)) : nullptr;
+      if (f8) layernorm8(h0.p, a.l1w, a.l1b, n8, s8, M, C);
+      else layernorm(h0.p, a.l1w, a.l1b, n1.p, M, C);
       Tensor qk = talloc(H, W, 2 * C);
-      linear(n1.p, M, C, a.qk, nullptr, ACT_NONE, nullptr, qk.p, 2 * C);
+      if (f8) linear8(n8, s8, M, a.qk8, nullptr, ACT_NONE, qk.p);
+      else linear(n1.p, M, C, a.qk, nullptr, ACT_NONE, nullptr, qk.p, 2 * C);
       const int Np = (N + 7) & ~7;    // V^T rows padded to 8 keys (the 2x2 level of tiny configs has N = 4)
       bf16_t* vt = (bf16_t*)temp.alloc((size_t)B * C * Np * 2);   // [B][C][Np]
-      linear(n1.p, M, C, a.v, nullptr, ACT_NONE, nullptr, vt, C, OUT_BF16_T, Np, N);
+      if (f8) linear8(n8, s8, M, a.v8, nullptr, ACT_NONE, vt, OUT_BF16_T, Np, N);
+      else linear(n1.p, M, C, a.v, nullptr, ACT_NONE, nullptr, vt, C, OUT_BF16_T, Np, N);
       Tensor at = talloc(H, W, C);
       attention(qk.p, 2 * C, qk.p + C, 2 * C, vt, Np, at.p, C, a.heads, N, N);
       Tensor h1 = talloc(H, W, C);
       linear(at.p, M, C, a.o1, &a.o1b, ACT_NONE, h0.p, h1.p, C);
       // --- cross attention over the T text tokens
       const int Tp = (T + 7) & ~7;
-      layernorm(h1.p, a.l2w, a.l2b, n1.p, M, C);
-      linear(n1.p, M, C, a.q2, nullptr, ACT_NONE, nullptr, qk.p, C);
+      if (f8) { layernorm8(h1.p, a.l2w, a.l2b, n8, s8, M, C); linear8(n8, s8, M, a.q28, nullptr, ACT_NONE, qk.p); }
+      else {
+        layernorm(h1.p, a.l2w, a.l2b, n1.p, M, C);
+        linear(n1.p, M, C, a.q2, nullptr, ACT_NONE, nullptr, qk.p, C);
+      }
       // text K / V^T of this layer live inside the batched projections computed once per forward
       const int XT = u->x_total;
       attention(qk.p, C, kx + a.x_off, XT, vxt + (size_t)a.x_off * Tp, Tp, at.p, C, a.heads, N, T, (long)XT * Tp);
       Tensor h2 = talloc(H, W, C);
       linear(at.p, M, C, a.o2, &a.o2b, ACT_NONE, h1.p, h2.p, C);
       // --- GEGLU feed-forward
-      layernorm(h2.p, a.l3w, a.l3b, n1.p, M, C);
       Tensor ff = talloc(H, W, 4 * C);
-      linear(n1.p, M, C, a.ff1, &a.ff1b, ACT_GEGLU, nullptr, ff.p, 8 * C);
+      if (f8) { layernorm8(h2.p, a.l3w, a.l3b, n8, s8, M, C); linear8(n8, s8, M, a.ff18, &a.ff1b, ACT_GEGLU, ff.p); }
+      else {
+        layernorm(h2.p, a.l3w, a.l3b, n1.p, M, C);
+        linear(n1.p, M, C, a.ff1, &a.ff1b, ACT_GEGLU, nullptr, ff.p, 8 * C);
+      }
       linear(ff.p, M, 4 * C, a.ff2, &a.ff2b, ACT_NONE, h2.p, h0.p, C);   // h0 is dead by now: reuse
       linear(h0.p, M, C, a.pout, &a.poutb, ACT_NONE, x.p, out.p, C);
       temp.off = mark;
@@ -592,6 +663,7 @@ struct dfh_unet {
       else tab_pack.add(src, TAB_PACK_CONV, (long)op.dst, op.N, op.K, op.ldw, 0, op.col_off, 0, op.cin_pad, (long)op.N * op.K * 9);
     }
     if (int rc = tab_pack.launch(arena32, arena16, s)) return rc;
-    return tab_pack_acc.launch(arena32, arena16, s);
+    if (int rc = tab_pack_acc.launch(arena32, arena16, s)) return rc;
+    return quantize_fp8(s);          // e4m3 copies of the LayerNorm-fed projections from the freshly packed bf16 matrices
   }
 };

@@ -114,7 +114,7 @@ class UNet2DConditionModel(nn.Module):
                  cross_attention_dim: int = 768, attention_head_dim: Union[int, Sequence[int]] = 8,
                  use_linear_projection: bool = False, norm_num_groups: int = 32, norm_eps: float = 1e-5,
                  text_len: int = 77, max_batch: int = 16, init_seed: Optional[int] = 0, init_std: float = 0.02,
-                 **unused):
+                 fp8: bool = False, **unused):
         super().__init__()
         _reject_unsupported_config(unused)
         nb = len(block_out_channels)
@@ -133,6 +133,7 @@ class UNet2DConditionModel(nn.Module):
             use_linear_projection=bool(use_linear_projection), norm_num_groups=norm_num_groups,
             norm_eps=norm_eps, text_len=text_len)
         self.max_batch = int(max_batch)
+        self.fp8 = bool(fp8)             # e4m3 LayerNorm-fed linears (BASELINE configs[4]); inference walk only, not a config key
         self.assume_static_weights = False   # set by the sampler inside its loop: skip the dirty check
         self._ctx = None
         self._ctx_key = None
@@ -186,6 +187,13 @@ class UNet2DConditionModel(nn.Module):
 
     def enable_gradient_checkpointing(self):
         return None
+
+    def enable_fp8(self, on: bool = True):
+        """Run the LayerNorm-fed projections of every transformer block (attn1 q|k, v, attn2 q, GEGLU input) in OCP e4m3 on the
+        block-scaled MFMA: per-token activation scales, per-output-channel weight scales, fp32 accumulation (csrc/gemm_fp8.hip).
+        Sampling path only -- the training forward keeps bf16.  Takes effect at the next forward (the context is rebuilt)."""
+        self.fp8 = bool(on)
+        return self
 
     def enable_xformers_memory_efficient_attention(self, *a, **k):
         return None
@@ -253,7 +261,7 @@ class UNet2DConditionModel(nn.Module):
             raise _lib.DfhError("conv_in must be a 3x3 / stride 1 / padding 1 convolution")
         if batch > self.max_batch:
             self.max_batch = batch
-        key = (in_ch, self.max_batch, dev.index, tuple(sorted((k, str(v)) for k, v in self.config.items())))
+        key = (in_ch, self.max_batch, dev.index, self.fp8, tuple(sorted((k, str(v)) for k, v in self.config.items())))
         if self._ctx is not None and key == self._ctx_key:
             return
         if self._ctx is not None:
@@ -268,15 +276,21 @@ class UNet2DConditionModel(nn.Module):
                 lib.dfh_unet_destroy(ctx)
                 raise _lib.DfhError(f"parameter {name}: expected shape {shape}, module has "
                                     f"{tuple(params[name].shape) if name in params else None}")
+        if self.fp8:
+            _lib.call("dfh_unet_enable_fp8", ctx)        # before the workspace is planned
         # zero-filled: padded weight columns (conv_in with 4 input channels -> 8) must read as 0
         a16 = torch.zeros(lib.dfh_unet_arena16_bytes(ctx), dtype=torch.uint8, device=dev)
         a32 = torch.zeros(lib.dfh_unet_arena32_bytes(ctx), dtype=torch.uint8, device=dev)
         wsb = lib.dfh_unet_workspace_bytes(ctx, self.max_batch)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
         _lib.call("dfh_unet_bind", ctx, _lib.ptr(a16), _lib.ptr(a32), _lib.ptr(ws), wsb, self.max_batch)
+        a8 = None
+        if self.fp8:
+            a8 = torch.zeros(max(256, lib.dfh_unet_arena8_bytes(ctx)), dtype=torch.uint8, device=dev)
+            _lib.call("dfh_unet_bind_fp8", ctx, _lib.ptr(a8))
         self._ctx, self._ctx_key = ctx, key
         self._names = [n for n, _ in table]
-        self._buffers_dev = (a16, a32, ws)
+        self._buffers_dev = (a16, a32, ws) if a8 is None else (a16, a32, ws, a8)
         self._packed_sig = None
         self._train_buffers = None
         self._train_batch = 0

@@ -84,6 +84,12 @@ size_t dfh_unet_arena32_bytes(const dfh_unet* u);
 size_t dfh_unet_workspace_bytes(dfh_unet* u, int batch);
 int dfh_unet_bind(dfh_unet* u, void* arena16, void* arena32, void* workspace, size_t workspace_bytes, int max_batch);
 
+/* fp8 linears inside the U-Net walk (inference): call dfh_unet_enable_fp8 right after create (it changes the workspace plan),
+ * allocate dfh_unet_arena8_bytes, bind it; dfh_unet_pack then also refreshes the e4m3 copies + per-channel scales. */
+int dfh_unet_enable_fp8(dfh_unet* u);
+size_t dfh_unet_arena8_bytes(const dfh_unet* u);
+int dfh_unet_bind_fp8(dfh_unet* u, void* arena8);
+
 /* fp32 master parameters (device pointers, table order) -> packed arenas.  Call after every
  * weight update (optimizer step / load_state_dict). */
 int dfh_unet_pack(dfh_unet* u, const float* const* master_params, int count, void* stream);
@@ -209,6 +215,18 @@ int dfh_groupnorm(const void* src0, int c0, const void* src1, int c1, int batch,
                   const float* gamma, const float* beta, float eps, int silu, void* out, float* partial, void* stream);
 /* LayerNorm over the last dim of [M][C] bf16 (BasicTransformerBlock.norm1/2/3) */
 int dfh_layernorm(const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps, void* stream);
+/* ---- fp8 (OCP e4m3fn) linears: BASELINE configs[4].  The reference has no fp8 path (fp16 autocast, run_inf4eval.sh:1); these
+ * replace the same diffusers linears as dfh_gemm (BasicTransformerBlock attn1.to_q/k/v, attn2.to_q, ff.net.0.proj reached from
+ * df.py:249-253,518-523) when the caller opts in.
+ *   dfh_quantize_rows_fp8 : bf16 [R][K] (row stride ldx) -> e4m3 [R][K] + scale[R] = amax / 448 (weights: one scale per output channel)
+ *   dfh_layernorm_fp8     : dfh_layernorm whose output is quantised per token: q [M][C] e4m3, scale [M]
+ *   dfh_gemm_fp8          : out = epilogue(sA[m] * sW[n] * sum_k A[m][k] W[n][k]); K % 64 == 0; act 0 or 4 (GEGLU, packed rows);
+ *                           out_mode 0 (bf16 [M][ld_out]) or 1 (bf16 transposed per batch of rows_per_b rows) */
+int dfh_quantize_rows_fp8(const void* x, int ldx, void* q, float* scale, int R, int K, void* stream);
+int dfh_layernorm_fp8(const void* x, const float* gamma, const float* beta, void* q, float* scale, int M, int C, float eps, void* stream);
+int dfh_gemm_fp8(const void* A, const float* sA, const void* W, const float* sW, int M, int N, int K, const float* bias,
+                 const void* resid, int ld_res, int act, void* out, int ld_out, int out_mode, int rows_per_b, const void* zero_page,
+                 void* stream);
 /* softmax(Q K^T * scale) V; Q [B][Nq][ldq], K [B][Nk][ldk], Vt [B][H*D][ldvt] (V transposed), O [B][Nq][ldo]; bf16 */
 int dfh_attention(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
                   int batch, int heads, int head_dim, int Nq, int Nk, float scale, void* stream);

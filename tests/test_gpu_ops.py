@@ -423,3 +423,96 @@ def test_error_reporting_is_loud():
     with pytest.raises(_lib.DfhError, match="unsupported head dim"):
         q = bf(rnd(1, 16, 48))
         _lib.call("dfh_attention", _lib.ptr(q), 48, _lib.ptr(q), 48, _lib.ptr(q), 16, _lib.ptr(q), 48, 1, 1, 48, 16, 16, 1.0, gu.stream())
+
+
+# ----------------------------------------------------------------------------- fp8 linears (BASELINE configs[4])
+def _fp8_dequant(q, scale):
+    return q.view(torch.float8_e4m3fn).float() * scale[:, None]
+
+
+def test_fp8_row_quantiser_matches_torch_e4m3():
+    x = bf(rnd(70, 192, seed=80) * 3)
+    x[5] = 0                                                   # an all-zero row keeps scale 1
+    q = torch.empty((70, 192), dtype=torch.uint8, device=DEV)
+    sc = torch.empty(70, device=DEV)
+    _lib.call("dfh_quantize_rows_fp8", _lib.ptr(x), 192, _lib.ptr(q), _lib.ptr(sc), 70, 192, gu.stream())
+    torch.cuda.synchronize()
+    want_sc = x.float().abs().amax(dim=1) / 448.0
+    want_sc[5] = 1.0
+    torch.testing.assert_close(sc, want_sc, rtol=1e-6, atol=0)
+    want_q = (x.float() / want_sc[:, None]).to(torch.float8_e4m3fn)         # OCP e4m3fn, round to nearest even
+    assert torch.equal(q.view(torch.float8_e4m3fn).float(), want_q.float())
+    assert gu.rel_err(_fp8_dequant(q, sc), x.float()) <= 4e-2                  # 3 mantissa bits: 2^-4 relative per element
+
+
+@pytest.mark.parametrize("M,C", [(300, 320), (64, 1280), (128, 640)])
+def test_layernorm_fp8_matches_layernorm_then_quantise(M, C):
+    x = bf(rnd(M, C, seed=81) * 3 + 1.5)
+    gamma, beta = rnd(C, seed=82) * 0.3 + 1, rnd(C, seed=83) * 0.2
+    q = torch.empty((M, C), dtype=torch.uint8, device=DEV)
+    sc = torch.empty(M, device=DEV)
+    _lib.call("dfh_layernorm_fp8", _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(q), _lib.ptr(sc), M, C, 1e-5, gu.stream())
+    torch.cuda.synchronize()
+    ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
+    assert gu.rel_err(_fp8_dequant(q, sc), ref) <= 4e-2
+    torch.testing.assert_close(sc, bf(ref).float().abs().amax(dim=1) / 448.0, rtol=2e-2, atol=1e-6)
+
+
+def _fp8_gemm(x, w, bias=None, resid=None, act=0, out_mode=0, rows_per_b=0):
+    """x [M][K], w [N][K] bf16 -> quantised by the library -> dfh_gemm_fp8; returns (out, dequantised x, dequantised w)."""
+    M, K = x.shape
+    N = w.shape[0]
+    xq, wq = torch.empty((M, K), dtype=torch.uint8, device=DEV), torch.empty((N, K), dtype=torch.uint8, device=DEV)
+    xs, ws = torch.empty(M, device=DEV), torch.empty(N, device=DEV)
+    _lib.call("dfh_quantize_rows_fp8", _lib.ptr(x), K, _lib.ptr(xq), _lib.ptr(xs), M, K, gu.stream())
+    _lib.call("dfh_quantize_rows_fp8", _lib.ptr(w), K, _lib.ptr(wq), _lib.ptr(ws), N, K, gu.stream())
+    n_out = N // 2 if act == 4 else N
+    if out_mode == 1:
+        nb = M // rows_per_b
+        out = torch.full((nb, N, rows_per_b), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ld = rows_per_b
+    else:
+        out = torch.full((M, n_out), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ld = n_out
+    z = gu.zero_page()
+    _lib.call("dfh_gemm_fp8", _lib.ptr(xq), _lib.ptr(xs), _lib.ptr(wq), _lib.ptr(ws), M, N, K, _lib.ptr(bias), _lib.ptr(resid), N,
+              act, _lib.ptr(out), ld, out_mode, rows_per_b, _lib.ptr(z), gu.stream())
+    torch.cuda.synchronize()
+    return out, _fp8_dequant(xq, xs), _fp8_dequant(wq, ws)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 160, 64), (300, 320, 320), (1000, 640, 128), (4096, 2560, 320), (77, 24, 192), (12000, 960, 320)])
+def test_gemm_fp8_exact_on_its_quantised_operands(M, N, K):
+    """Against the product of the DEQUANTISED operands the kernel is an fp32-accumulating GEMM: only accumulation order and
+    the final bf16 rounding remain (asymmetric random operands: a swapped operand / row / column map cannot pass)."""
+    x, w = bf(rnd(M, K, seed=84)), bf(rnd(N, K, seed=85, scale=0.1))
+    bias, resid = rnd(N, seed=86), bf(rnd(M, N, seed=87))
+    out, xd, wd = _fp8_gemm(x, w, bias=bias, resid=resid)
+    gu.assert_close_bf16(out, xd @ wd.T + bias + resid.float(), f"fp8 gemm {M}x{N}x{K}")
+    # and the quantisation error itself against the bf16 operands: the stated fp8 tolerance (per-token x per-channel scales)
+    assert gu.rel_err(out.float(), x.float() @ w.float().T + bias + resid.float()) <= 5e-2
+
+
+@pytest.mark.parametrize("M,C", [(300, 64), (4096, 320), (520, 640)])
+def test_gemm_fp8_geglu(M, C):
+    x = bf(rnd(M, C, seed=88))
+    w = rnd(8 * C, C, seed=89, scale=0.1)
+    b = rnd(8 * C, seed=90, scale=0.5)
+    wp = torch.empty((8 * C, C), dtype=torch.bfloat16, device=DEV)
+    bp = torch.empty(8 * C, dtype=torch.float32, device=DEV)
+    _lib.call("dfh_pack_matrix", _lib.ptr(w), _lib.ptr(wp), 8 * C, C, C, 0, 0, 1, gu.stream())       # value / gate rows interleaved
+    _lib.call("dfh_pack_vector", _lib.ptr(b), _lib.ptr(bp), 8 * C, 0, 1, 0, gu.stream())
+    out, xd, wd = _fp8_gemm(x, wp, bias=bp, act=4)
+    # undo the 16-row interleave on the dequantised packed weights: packed row 32 j + i = value 16 j + i, + 16 = its gate
+    wdv = wd.view(-1, 2, 16, C)
+    wv, wg = wdv[:, 0].reshape(-1, C), wdv[:, 1].reshape(-1, C)
+    a, gate = xd @ wv.T + b[:4 * C], xd @ wg.T + b[4 * C:]
+    gu.assert_close_bf16(out, a * F.gelu(gate), "fp8 geglu")
+
+
+def test_gemm_fp8_transposed_output():
+    B, rows, N, K = 3, 200, 320, 320
+    x, w = bf(rnd(B * rows, K, seed=91)), bf(rnd(N, K, seed=92, scale=0.1))
+    out, xd, wd = _fp8_gemm(x, w, out_mode=1, rows_per_b=rows)
+    ref = (xd @ wd.T).view(B, rows, N).transpose(1, 2)
+    gu.assert_close_bf16(out, ref, "fp8 transposed")

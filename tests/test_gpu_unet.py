@@ -169,3 +169,27 @@ def test_unet_sd2base_full_size_matches_oracle():
     err = rel_err(out.cpu(), ref)
     print("sd2base", f"{err:.2e}")
     assert err <= TOL
+
+
+@pytest.mark.parametrize("name,cfg", [("tiny", unet_ref.TINY), ("tiny_sd2", unet_ref.UNetConfig(
+    sample_size=16, block_out_channels=(64, 128, 256, 256), cross_attention_dim=64, num_heads=(1, 2, 4, 4), use_linear_projection=True))])
+def test_fp8_linears_vs_oracle(name, cfg):
+    """BASELINE configs[4]: the LayerNorm-fed projections (attn1 q|k / v, attn2 q, GEGLU input) in e4m3 with per-token x
+    per-channel scales.  Stated tolerance vs the fp32 oracle: relative L2 <= 6e-2 on the noise prediction (3 mantissa bits on
+    60 % of the linear-class operands; bf16 path: 3e-2, measured ~1.5e-2); the fp8 and bf16 walks of the SAME model must also
+    stay within 5e-2 of each other, and switching back must reproduce the bf16 result bit for bit."""
+    params = unet_ref.init_params(cfg, seed=9, w_std=0.05, affine_jitter=0.1)
+    m = hip_unet(cfg, params)
+    x, e = inputs(cfg, 3, 31)
+    t = torch.tensor([981, 500, 21], device=DEV)
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(params, cfg, x, t.cpu(), e)
+        y16 = m(x.to(DEV), t, e.to(DEV)).sample
+        m.enable_fp8()
+        y8 = m(x.to(DEV), t, e.to(DEV)).sample
+        m.enable_fp8(False)
+        y16b = m(x.to(DEV), t, e.to(DEV)).sample
+    e16, e8, d = rel_err(y16.cpu(), ref), rel_err(y8.cpu(), ref), rel_err(y8, y16)
+    print(name, f"bf16 vs oracle {e16:.2e}, fp8 vs oracle {e8:.2e}, fp8 vs bf16 {d:.2e}")
+    assert e8 <= 6e-2 and d <= 5e-2 and d > 0.0
+    assert torch.equal(y16, y16b)

@@ -30,10 +30,13 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 MFMA_BF16_PEAK = 2500.0   # TFLOP/s dense, MI355X_MICROARCH.md
-# What a register-resident loop of nothing but v_mfma_f32_16x16x32_bf16 sustains on this pool's boxes with random operands
-# (scripts/probes/mfma_rate.hip -> profiles/r01/mfma_rate.txt: 1157-1175 TFLOP/s at 2-4 waves per SIMD, 1300 zero-filled): the
-# part is power / clock limited under dense MFMA load.  Reported next to the nominal peak; roofline.frac stays against 2500.
-MFMA_BF16_SUSTAINED = 1170.0
+MFMA_FP8_PEAK = 5000.0    # TFLOP/s dense, block-scaled e4m3 (MI355X_MICROARCH.md)
+# What a register-resident loop of nothing but MFMAs sustains on this pool's boxes with RANDOM operands
+# (scripts/probes/mfma_rate2.hip -> profiles/r02/mfma_rate2.txt: v_mfma_f32_32x32x16_bf16 issues every 32.0 cycles; 2.3-2.5 PFLOP/s
+# at 2.3-2.4 GHz on zero-filled operands, 1.73-1.81 PFLOP/s on random ones because the clock drops to 1.75-1.95 GHz under dense
+# MFMA load).  Informational only -- roofline.frac is against the nominal 2500.  (Round 1 quoted 1170 here: its probe's
+# accumulator chains had been folded into one dependent chain by the compiler -- 45 cycles per MFMA instead of 16-20.)
+MFMA_BF16_SUSTAINED = 1750.0
 HBM_PEAK = 8000.0         # GB/s
 
 
@@ -80,20 +83,26 @@ def outfit_inputs(dev, cross_dim, rank):
 
 
 def cpu_baseline(threads):
-    """Oracle U-Net (fp32, torch CPU) + glue on the host cores: one timed SD-1.5 forward at B=1 after one
-    untimed warm-up, extrapolated to the 16 rows of a step (the 50-step loop is never run on CPU)."""
+    """Oracle U-Net (fp32, torch CPU) + glue on the host cores, as SURVEY.md 8d / BASELINE.md 3 prescribe: 1 warm-up + 3 timed
+    single forwards at B=1 (config 0) and ONE timed forward at B=16 (the rows of a step); steps/s = 1 / (t_fwd(B=16) + t_glue).
+    The 50-step loop is never run on CPU."""
     from oracle import glue_ref, unet_ref
     torch.set_num_threads(threads)
     cfg = unet_ref.SD15
     p = unet_ref.init_params(cfg, seed=0)
     g = torch.Generator().manual_seed(123)
-    x = torch.randn(1, 8, 64, 64, generator=g)
-    e = torch.randn(1, 77, 768, generator=g)
+    x = torch.randn(16, 8, 64, 64, generator=g)
+    e = torch.randn(16, 77, 768, generator=g)
     with torch.no_grad():
-        unet_ref.unet_forward(p, cfg, x, 481, e)
+        unet_ref.unet_forward(p, cfg, x[:1], 481, e[:1])
+        t1 = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            unet_ref.unet_forward(p, cfg, x[:1], 481, e[:1])
+            t1.append(time.perf_counter() - t0)
         t0 = time.perf_counter()
         unet_ref.unet_forward(p, cfg, x, 481, e)
-        t_fwd = time.perf_counter() - t0
+        t16 = time.perf_counter() - t0
         enc = {"mlp.0.weight": torch.randn(256, 16384, generator=g) * 0.01, "mlp.0.bias": torch.zeros(256),
                "mlp.3.weight": torch.randn(16384, 256, generator=g) * 0.01, "mlp.3.bias": torch.zeros(16384)}
         lat = torch.randn(4, 4, 64, 64, generator=g)
@@ -102,9 +111,9 @@ def cpu_baseline(threads):
         xin = torch.cat([0.9 * torch.cat([lat] * 4) + 0.1 * torch.cat([m] * 4), torch.cat([lat] * 4)], 1)
         t_glue = time.perf_counter() - t0
     del p
-    return dict(value=1.0 / (16.0 * t_fwd + t_glue), unit="steps/s", cores=threads, kind="port",
-                sample=f"oracle fp32 U-Net (SD-1.5 shape) 1 forward at B=1 = {t_fwd:.2f}s, x16 rows/step + glue {t_glue * 1e3:.0f}ms; "
-                       "1 warm-up + 1 timed forward")
+    return dict(value=1.0 / (t16 + t_glue), unit="steps/s", cores=threads, kind="port",
+                sample=f"oracle fp32 U-Net (SD-1.5 shape): 1 warm-up + 3 timed forwards at B=1 = {min(t1):.2f} / {sorted(t1)[1]:.2f} / {max(t1):.2f}s "
+                       f"(min / median / max), 1 timed forward at B=16 = {t16:.2f}s, glue {t_glue * 1e3:.0f}ms; steps/s = 1 / (t_B16 + glue)")
 
 
 def train_inputs(dev, cross_dim, rank, outfits):
@@ -268,9 +277,22 @@ def pmc_traffic():
         return None, None
     try:
         d = json.load(open(files[-1]))
+        # the summary names the kernel sources it was measured on: a stale one (kernels edited since) is not reported
+        if d.get("kernel_source_hash") != kernel_source_hash():
+            return None, os.path.relpath(files[-1], ROOT) + " (STALE: kernel sources changed since it was measured; traffic withheld)"
         return float(d["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
     except Exception:
         return None, None
+
+
+def kernel_source_hash():
+    """sha256 over the HIP kernel sources: ties a committed PMC summary to the code it was measured on."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "difashion_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "difashion_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -284,6 +306,8 @@ def main():
     ap.add_argument("--mode", default="sample", choices=["sample", "train", "vae"],
                     help="sample: the headline metric (default); train: BASELINE configs[2]/[3] training step; vae: SURVEY 8f-1")
     ap.add_argument("--outfits", type=int, default=8, help="--mode train: outfits per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: BASELINE configs[4] -- the LayerNorm-fed transformer projections in e4m3 on the block-scaled MFMA")
     args = ap.parse_args()
 
     import difashion_amd as da
@@ -308,6 +332,9 @@ def main():
     if args.mode == "vae":
         return run_vae(args, da, _lib, ddist, rank, world, dev)
     unet, enc = build_models(dev, args.config)
+    if args.dtype == "fp8":
+        unet.enable_fp8()
+        unet.pack(force=True)
     cross = unet.config.cross_attention_dim
     K, W = args.steps, args.warmup
     sampler = da.OutfitSampler(unet, enc, da.DDIMScheduler())
@@ -349,6 +376,24 @@ def main():
                         launches_per_step=gemm["launches"] // K,
                         avg_launch_us=round(gemm["ms"] * 1e3 / max(1, gemm["launches"]), 2),
                         algorithmic_tflop_per_step=round(gemm["flops"] / K / 1e12, 3))
+        # secondary kernels, same live HIP-event timing: attention against the bf16 MFMA peak, GroupNorm against HBM, and (fp8
+        # runs) the e4m3 GEMM class against the fp8 MFMA peak
+        sec = {}
+        def tf(c):
+            return classes[c]["flops"] / (classes[c]["ms"] * 1e-3) / 1e12
+        if classes["attention"]["ms"] > 0:
+            sec["attention"] = dict(bound="mfma", kernel="attention_x32_kernel + attention_kernel", achieved=round(tf("attention"), 1),
+                                    peak=MFMA_BF16_PEAK, unit="TFLOP/s", frac=round(tf("attention") / MFMA_BF16_PEAK, 4))
+        if classes["groupnorm"]["ms"] > 0:
+            gbs = classes["groupnorm"]["bytes"] / (classes["groupnorm"]["ms"] * 1e-3) / 1e9
+            sec["groupnorm"] = dict(bound="hbm", kernel="gn_stats_kernel + gn_apply_kernel + gn_small_kernel", achieved=round(gbs, 1),
+                                    peak=HBM_PEAK, unit="GB/s", frac=round(gbs / HBM_PEAK, 4))
+        if classes.get("gemm_linear_fp8", {}).get("ms", 0) > 0:
+            sec["gemm_linear_fp8"] = dict(bound="mfma", kernel="gemm_fp8_kernel (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3)",
+                                          achieved=round(tf("gemm_linear_fp8"), 1), peak=MFMA_FP8_PEAK, unit="TFLOP/s",
+                                          frac=round(tf("gemm_linear_fp8") / MFMA_FP8_PEAK, 4),
+                                          launches_per_step=classes["gemm_linear_fp8"]["launches"] // K)
+        roofline["secondary"] = sec
 
     if world > 1:
         ddist.barrier()
@@ -358,8 +403,11 @@ def main():
     out = {
         "metric": "U-Net denoise steps/sec, 4-item outfit @ 64x64x4 latent", "value": round(value, 3), "unit": "steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed * 1e3 / K, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: one 4-item outfit, CFG on (4 branches) -> U-Net batch 16, DDIM-50 schedule, "
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if args.dtype == "bf16" else "fp8 e4m3 (attn1 q|k|v, attn2 q, GEGLU input projections) + bf16 (everything else)",
+        "data": "synthetic",
+        "config": {"workload": ("BASELINE configs[1]" if args.dtype == "bf16" else "BASELINE configs[4] on one GPU (fp8 linears)") +
+                               ": one 4-item outfit, CFG on (4 branches) -> U-Net batch 16, DDIM-50 schedule, "
                                f"{args.config} shape in_channels=8, 64x64x4 latents, 77 text tokens; one outfit per GPU",
                    "unet_batch": 16, "latent": "64x64x4", "parallelism": f"outfit-replicas x{world} (no data-path collective)"},
         "roofline": roofline,

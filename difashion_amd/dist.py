@@ -83,7 +83,47 @@ def gather_mean(value: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def all_reduce_gradients(flat_grad: torch.Tensor, average: bool = True) -> torch.Tensor:
+def exchange_bf16(t: torch.Tensor) -> torch.Tensor:
+    """Gradient average with a bf16 WIRE format and fp32 accumulation, in place on the fp32 range ``t``: half the bytes of an
+    fp32 all-reduce on every xGMI link.  Direct reduce-scatter + all-gather, the natural pattern of the fully connected 8-GPU
+    mesh (each pair of GPUs owns a link):
+      1. every rank rounds its range to bf16 and sends shard j to rank j (all_to_all: (W-1)/W of the bf16 range leaves the GPU);
+      2. rank j sums the W bf16 contributions of its shard IN FP32, in rank order (deterministic), divides by W, rounds to bf16;
+      3. the averaged shards are all-gathered in bf16 ((W-1)/W of the bf16 range arrives) and widened back to fp32.
+    Every rank ends with the SAME values (each shard is computed by exactly one rank), so the replicas stay bit-identical.
+    gloo has no all_to_all: there step 1 is an all_gather of the whole bf16 range (test path only, same arithmetic)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return t
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = t.numel()
+    per = (n + world - 1) // world
+    wire = torch.zeros(world * per, dtype=torch.bfloat16, device=t.device)
+    wire[:n].copy_(t.reshape(-1))
+    if dist.get_backend() == "nccl":
+        recv = torch.empty_like(wire)
+        dist.all_to_all_single(recv, wire)                       # recv[r * per:(r + 1) * per] = rank r's copy of MY shard
+        mine = recv.view(world, per)
+    else:
+        stage = (wire.cpu() if wire.is_cuda else wire).view(torch.int16)          # raw 16-bit words: no dtype support needed
+        bufs = [torch.empty_like(stage) for _ in range(world)]
+        dist.all_gather(bufs, stage)
+        mine = torch.stack([b[rank * per:(rank + 1) * per] for b in bufs]).view(torch.bfloat16).to(t.device)
+    acc = mine[0].float()
+    for r in range(1, world):                                    # fixed order: deterministic
+        acc += mine[r].float()
+    shard = (acc / world).to(torch.bfloat16)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(wire, shard)
+    else:
+        stage = (shard.cpu() if shard.is_cuda else shard).view(torch.int16)
+        bufs = [torch.empty_like(stage) for _ in range(world)]
+        dist.all_gather(bufs, stage)
+        wire = torch.cat(bufs).view(torch.bfloat16).to(t.device)
+    t.reshape(-1).copy_(wire[:n])
+    return t
+
+
+def all_reduce_gradients(flat_grad: torch.Tensor, average: bool = True, wire: str = "fp32") -> torch.Tensor:
     """Data-parallel gradient exchange of the training step (the reference: accelerate's DDP wrapper around
     accelerator.backward, train.py:611/:699).  Every rank holds a full replica and a different slice of the global
     batch of outfits; the gradients of ALL parameters live in one flat fp32 buffer (training.FusedAdamW.flat_grad /
@@ -91,6 +131,10 @@ def all_reduce_gradients(flat_grad: torch.Tensor, average: bool = True) -> torch
     25 MB buckets: a ring over 8 GPUs moves 2 * 7/8 of the buffer per link once, with no per-bucket launch latency."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return flat_grad
+    if wire == "bf16":
+        if not average:
+            raise ValueError("the bf16 wire format averages")
+        return exchange_bf16(flat_grad)
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     if average:
         flat_grad.div_(dist.get_world_size())

@@ -370,12 +370,13 @@ def train_step(unet, fashion_encoder, scheduler, optimizer: FusedAdamW, *, lr_sc
     from .pipeline import train_forward
     loss = train_forward(unet, fashion_encoder, scheduler, **batch)
     loss.backward()
+    wire = getattr(unet, "grad_wire_dtype", "fp32")       # "bf16": half the bytes per xGMI link, fp32 accumulation
     if getattr(unet, "grads_synced", False):
         # the U-Net averaged its gradients inside backward (overlapped with the walk): reduce what lies outside it
         for lo, hi in optimizer.ranges_excluding(unet):
-            _dist.all_reduce_gradients(optimizer.flat_grad[lo:hi])
+            _dist.all_reduce_gradients(optimizer.flat_grad[lo:hi], wire=wire)
     else:
-        _dist.all_reduce_gradients(optimizer.flat_grad)
+        _dist.all_reduce_gradients(optimizer.flat_grad, wire=wire)
     # EMA of the U-Net folded into the AdamW launch when it covers the head of the flat parameter buffer
     first = next(iter(unet.parameters()))
     fuse_ema = (ema_unet is not None and ema_unet.flat.device.type == "cuda"

@@ -414,6 +414,18 @@ class UNet2DConditionModel(nn.Module):
     sync_grads_in_backward = True
     grads_synced = False
     grad_bucket_bytes = 256 << 20         # few, large buckets: xGMI rings are per-link bound, not latency bound
+    grad_wire_dtype = "fp32"              # "bf16": half the bytes per link, fp32 accumulation (dist.exchange_bf16)
+    measure_comm = False                  # record how long the compute stream waits for the gradient exchange (bench.py --mode train)
+    _comm_events = None
+
+    def last_comm_exposed_ms(self):
+        """Time the compute stream spent waiting for the side-stream gradient exchange in the last overlapped backward (ms; the
+        part of the exchange the backward walk did NOT hide).  None when nothing was measured.  Synchronises."""
+        if self._comm_events is None:
+            return None
+        e0, e1 = self._comm_events
+        e1.synchronize()
+        return e0.elapsed_time(e1)
 
     def _backward_overlapped(self, d_out, d_sample, grad_ptrs, count, overwrite, tdist):
         """The backward walk in pieces (dfh_unet_backward_begin / _next / _finish): whenever a range of the packed fp32
@@ -440,8 +452,12 @@ class UNet2DConditionModel(nn.Module):
                 comm.wait_event(ev)
                 # RCCL: enqueued behind ``comm``, which then waits for the collective -- the host returns at once and goes
                 # on enqueuing the next layers on the compute stream.  (gloo, CPU-staged, blocks the host instead.)
-                tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
-                t.div_(world)
+                if self.grad_wire_dtype == "bf16":
+                    from .dist import exchange_bf16
+                    exchange_bf16(t)
+                else:
+                    tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
+                    t.div_(world)
 
         while True:
             rc = lib.dfh_unet_backward_next(self._ctx, C.byref(lo), C.byref(hi), sp)
@@ -451,7 +467,14 @@ class UNet2DConditionModel(nn.Module):
                 break
             reduce_range(g16[lo.value:hi.value])
         reduce_range(g32[: g32.numel()])          # bias / affine gradients: complete only now, a few MB
-        compute.wait_stream(comm)
+        if self.measure_comm:                     # compute-stream idle time = the part of the exchange the walk did not hide
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(compute)
+            compute.wait_stream(comm)
+            e1.record(compute)
+            self._comm_events = (e0, e1)
+        else:
+            compute.wait_stream(comm)
         _lib.call("dfh_unet_backward_finish", self._ctx, grad_ptrs, count, overwrite, sp)
 
     # ------------------------------------------------------------------ forward

@@ -22,7 +22,10 @@ from tests.test_gpu_train import batch_kwargs, make_encoder
 from tests.test_gpu_unet import hip_unet
 
 RTOL = 2e-2
-DEV = "cuda:0"
+# RCCL ("nccl") with one rank per device when the box has at least two; otherwise both ranks share cuda:0 over gloo
+# (torch.cuda.device_count() does not initialise the GPU)
+NCCL = torch.cuda.device_count() >= 2 and os.environ.get("DFH_DIST_BACKEND", "nccl") == "nccl"
+DEV = f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}" if NCCL else "cuda:0"
 
 
 def shard(kw, rank, world, olen=4):
@@ -47,9 +50,10 @@ def build(rec):
 
 
 def main():
-    rank, world, _ = ddist.init("gloo")
-    assert world == 2 and tdist.get_backend() == "gloo"
-    torch.cuda.set_device(0)
+    rank, world, _ = ddist.init("nccl" if NCCL else "gloo")
+    assert world == 2 and tdist.get_backend() == ("nccl" if NCCL else "gloo")
+    torch.cuda.set_device(torch.device(DEV))
+    print(f"[rank {rank}] backend {tdist.get_backend()} device {DEV}", flush=True)
     rec = load("train_b8_snr5.npz")
     sched = da.DDIMScheduler(prediction_type=str(rec["pred_type"]))
     kw = batch_kwargs(rec, DEV)
@@ -65,6 +69,22 @@ def main():
     # range on a side stream while the walk continues (the default; small ranges here so the tiny U-Net has many), (b) one
     # all-reduce of the flat buffer after backward
     mine = shard(kw, rank, world)
+    # the bf16 wire format (dist.exchange_bf16: all_to_all + fp32 accumulate + all_gather) against the same whole-batch gradient
+    unet, enc, opt, ema = build(rec)
+    unet.grad_wire_dtype, unet.grad_bucket_bytes, unet.measure_comm = "bf16", 64 << 10, True
+    da.train_step(unet, enc, sched, opt, ema_unet=ema, **mine)
+    err16 = float((opt.flat_grad - g_full).norm() / g_full.norm())
+    exposed = unet.last_comm_exposed_ms()
+    print(f"[rank {rank}] bf16 wire: grad rel err {err16:.3e}; compute stream waited {exposed:.3f} ms for the exchange", flush=True)
+    assert err16 < RTOL and exposed is not None and exposed >= 0.0
+
+    def digest(t):
+        return t.view(torch.int32).to(torch.int64).sum().item() if t.dtype == torch.float32 else 0
+    d16 = torch.tensor([digest(opt.flat_param), digest(ema.flat), digest(opt.flat_grad)], dtype=torch.int64, device=DEV if NCCL else "cpu")
+    both16 = [torch.zeros_like(d16) for _ in range(world)]
+    tdist.all_gather(both16, d16)
+    assert torch.equal(both16[0], both16[1]), both16          # identical averages on every rank -> identical replicas
+    del unet, enc, opt, ema
     for overlapped in (False, True):
         unet, enc, opt, ema = build(rec)
         unet.sync_grads_in_backward = overlapped
@@ -86,15 +106,13 @@ def main():
     assert err2 < 1e-5, err2
 
     # replicas stay bit-identical: compare a 64-bit digest of parameters and EMA shadows across the ranks
-    def digest(t):
-        return t.view(torch.int32).to(torch.int64).sum().item() if t.dtype == torch.float32 else 0
-    mine_d = torch.tensor([digest(opt.flat_param), digest(ema.flat)], dtype=torch.int64)
+    mine_d = torch.tensor([digest(opt.flat_param), digest(ema.flat)], dtype=torch.int64, device=DEV if NCCL else "cpu")
     both = [torch.zeros_like(mine_d) for _ in range(world)]
     tdist.all_gather(both, mine_d)
     assert torch.equal(both[0], both[1]), both
     # a second step keeps them identical and still reduces ONE flat buffer
     da.train_step(unet, enc, sched, opt, ema_unet=ema, **mine)
-    mine_d = torch.tensor([digest(opt.flat_param), digest(ema.flat)], dtype=torch.int64)
+    mine_d = torch.tensor([digest(opt.flat_param), digest(ema.flat)], dtype=torch.int64, device=DEV if NCCL else "cpu")
     tdist.all_gather(both, mine_d)
     assert torch.equal(both[0], both[1]), both
     torch.cuda.synchronize()

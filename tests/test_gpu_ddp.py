@@ -1,14 +1,18 @@
-"""-m gpu: the data-parallel training step with two real processes.  The GPU box has ONE device, so the
-two ranks share cuda:0 and the collective runs on gloo (CUDA tensors staged through the host); the step itself -- native
-backward into the flat gradient buffer, one all-reduce, fused clip + AdamW + EMA -- is the code that runs under RCCL."""
+"""-m gpu: the data-parallel training step with two real processes.  On a box with at least two GPUs the
+ranks take one device each and the collectives run on RCCL ("nccl": side-stream all-reduce / all_to_all ordered by events
+against the backward walk -- the configuration of BASELINE configs[3]); on the usual one-GPU box both ranks share cuda:0 and the
+collective runs on gloo (CUDA tensors staged through the host).  The step itself -- native backward into the flat gradient
+buffer, the gradient exchange, fused clip + AdamW + EMA -- and every assertion are the same in both cases."""
 import os
 import socket
 import subprocess
 import sys
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
+TWO_GPUS = torch.cuda.device_count() >= 2          # does not initialise the GPU
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -32,7 +36,7 @@ def test_bench_multi_rank_flow_on_one_device():
     ONE JSON line), here with two ranks sharing the box's single GPU over gloo (DFH_DIST_BACKEND): the value is meaningless,
     the flow is what is checked."""
     import json
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", DFH_DIST_BACKEND="gloo",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", DFH_DIST_BACKEND="nccl" if TWO_GPUS else "gloo",
                PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",

@@ -355,3 +355,34 @@ def test_checkpoints_written_by_the_reference_stack_load(tmp_path):
                downsample_padding=1, mid_block_scale_factor=1, mid_block_type="UNetMidBlock2DCrossAttn")
     json.dump(cfg, open(os.path.join(d, "config.json"), "w"))
     da.UNet2DConditionModel.from_pretrained(str(tmp_path), subfolder="unet")
+
+
+def _bf16_wire_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    ddist.init("gloo")
+    g = torch.Generator().manual_seed(100 + rank)
+    grad = torch.randn(1003, generator=g) * (10.0 ** torch.randint(-3, 3, (1003,), generator=g).float())     # ragged length, wide range
+    mine = grad.clone()
+    out = ddist.all_reduce_gradients(grad, wire="bf16")
+    assert out is grad
+    q.put((rank, mine.tolist(), grad.tolist()))
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_bf16_wire_gradient_exchange():
+    """dist.exchange_bf16: bf16 on the wire, fp32 accumulation in rank order, identical results on every rank."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bf16_wire_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g0, g1 = torch.tensor(res[0][1]), torch.tensor(res[1][1])
+    want = ((g0.bfloat16().float() + g1.bfloat16().float()) / 2).bfloat16().float()        # the scheme's exact arithmetic
+    assert res[0][2] == res[1][2]                                                          # bit-identical on both ranks
+    assert torch.equal(torch.tensor(res[0][2]), want)
+    torch.testing.assert_close(want, (g0 + g1) / 2, rtol=2 ** -7, atol=1e-30)             # and bf16-close to the fp32 average

@@ -104,10 +104,10 @@ def exchange_bf16(t: torch.Tensor) -> torch.Tensor:
         dist.all_to_all_single(recv, wire)                       # recv[r * per:(r + 1) * per] = rank r's copy of MY shard
         mine = recv.view(world, per)
     else:
-        stage = (wire.cpu() if wire.is_cuda else wire).view(torch.int16)          # raw 16-bit words: no dtype support needed
+        stage = (wire.cpu() if wire.is_cuda else wire).view(torch.uint8)          # raw 16-bit words: raw bytes: gloo transports neither bf16 nor int16
         bufs = [torch.empty_like(stage) for _ in range(world)]
         dist.all_gather(bufs, stage)
-        mine = torch.stack([b[rank * per:(rank + 1) * per] for b in bufs]).view(torch.bfloat16).to(t.device)
+        mine = torch.stack([b[2 * rank * per:2 * (rank + 1) * per] for b in bufs]).view(torch.bfloat16).to(t.device)
     acc = mine[0].float()
     for r in range(1, world):                                    # fixed order: deterministic
         acc += mine[r].float()
@@ -115,7 +115,7 @@ def exchange_bf16(t: torch.Tensor) -> torch.Tensor:
     if dist.get_backend() == "nccl":
         dist.all_gather_into_tensor(wire, shard)
     else:
-        stage = (shard.cpu() if shard.is_cuda else shard).view(torch.int16)
+        stage = (shard.cpu() if shard.is_cuda else shard).view(torch.uint8)
         bufs = [torch.empty_like(stage) for _ in range(world)]
         dist.all_gather(bufs, stage)
         wire = torch.cat(bufs).view(torch.bfloat16).to(t.device)

@@ -69,6 +69,7 @@ class FusedAdamW(torch.optim.Optimizer):
             self._group_ranges.append((start, off))
         self._step = 0
         self._zero_epoch = _lib.grad_epoch()      # gradients stamped at or after this epoch are fresh
+        self._pstep = {}                          # id(param) -> number of updates it has received (torch: state[p]["step"])
         self._all_fresh = False                   # zero_grad(set_to_none=False): torch's "zeros, not None" -> everything updates
 
     def _fresh(self, p) -> bool:
@@ -85,18 +86,20 @@ class FusedAdamW(torch.optim.Optimizer):
         _lib.stamp_grads(params if params is not None else [p for g in self.param_groups for p in g["params"]])
 
     def _fresh_ranges(self, a: int, b: int) -> List[tuple]:
-        """Merged [start, end) ranges of fresh parameters inside the flat range [a, b)."""
+        """Merged (start, end, step) ranges of fresh parameters inside the flat range [a, b).  ``step`` is the per-parameter
+        update count torch.optim.AdamW keeps in ``state[p]["step"]`` (bias correction): a parameter that gets its first
+        gradient late starts at 1 while the others are further on, so a run is split where the counts differ."""
         runs = []
         for g in self.param_groups:
             for p in g["params"]:
                 off, n = self._slices[id(p)]
                 if off < a or off >= b or not self._fresh(p):
                     continue
-                end = off + _align(n)
-                if runs and runs[-1][1] == off:
+                end, st = off + _align(n), self._pstep.get(id(p), 0)
+                if runs and runs[-1][1] == off and runs[-1][2] == st:
                     runs[-1][1] = end
                 else:
-                    runs.append([off, end])
+                    runs.append([off, end, st])
         return [tuple(r) for r in runs]
 
     # the gradient views are permanent: zero_grad never drops them (the native backward accumulates in place)
@@ -165,19 +168,23 @@ class FusedAdamW(torch.optim.Optimizer):
         s = _lib.stream_ptr()
         self._step += 1
         total = self.flat_grad.numel()
+        for g in self.param_groups:            # this update's per-parameter step counts
+            for p in g["params"]:
+                if self._fresh(p):
+                    self._pstep[id(p)] = self._pstep.get(id(p), 0) + 1
         fresh_all = self._fresh_ranges(0, total)
         self._sumsq.zero_()
-        for lo, hi in fresh_all:               # the clip norm counts fresh gradients only (clip_grad_norm_ skips grad None);
+        for lo, hi, _ in fresh_all:            # the clip norm counts fresh gradients only (clip_grad_norm_ skips grad None);
             _lib.call("dfh_sumsq", self.flat_grad.data_ptr() + 4 * lo, hi - lo, _lib.ptr(self._sumsq), s)   # fixed order: deterministic
         clip = self.max_grad_norm is not None
         for g, (a, b) in zip(self.param_groups, self._group_ranges):
             if b == a:
                 continue
             b1, b2 = g["betas"]
-            hyper = (float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), self._step,
-                     _lib.ptr(self._sumsq) if clip else None, float(self.max_grad_norm or 0.0))
             cursor = a
-            for lo, hi in self._fresh_ranges(a, b) + [(b, b)]:
+            for lo, hi, pstep in self._fresh_ranges(a, b) + [(b, b, 0)]:
+                hyper = (float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), int(pstep),
+                         _lib.ptr(self._sumsq) if clip else None, float(self.max_grad_norm or 0.0))
                 # [cursor, lo): not updated -- but an EMA over them still tracks the (unchanged) parameters, as EMAModel.step does
                 if lo > cursor and ema_end > cursor:
                     e = min(lo, ema_end)
@@ -202,7 +209,7 @@ class FusedAdamW(torch.optim.Optimizer):
             ids = []
             for p in g["params"]:
                 off, n = self._slices[id(p)]
-                state[idx] = dict(step=torch.tensor(float(self._step)), exp_avg=self.exp_avg[off:off + n].view(p.shape).clone(),
+                state[idx] = dict(step=torch.tensor(float(self._pstep.get(id(p), 0))), exp_avg=self.exp_avg[off:off + n].view(p.shape).clone(),
                                   exp_avg_sq=self.exp_avg_sq[off:off + n].view(p.shape).clone())
                 ids.append(idx)
                 idx += 1
@@ -221,7 +228,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     off, n = self._slices[id(p)]
                     self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
                     self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
-                    self._step = int(float(st["step"]))
+                    self._pstep[id(p)] = int(float(st["step"]))
+                    self._step = max(self._step, self._pstep[id(p)])
                 idx += 1
 
 

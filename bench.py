@@ -140,15 +140,23 @@ def run_train(args, da, _lib, ddist, rank, world, dev):
     sched = da.DDIMScheduler()
     kw = train_inputs(dev, unet.config.cross_attention_dim, rank, args.outfits)
     K, W = args.steps, args.warmup
+    unet.grad_wire_dtype = args.wire
+    unet.measure_comm = world > 1          # two event records per step on the compute stream around its wait for the side stream
     step = lambda: da.train_step(unet, enc, sched, opt, ema_unet=ema, **kw)
     for _ in range(W):
         loss = step()
     torch.cuda.synchronize(); ddist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
+    exposed = []
     for _ in range(K):
         loss = step()
+        if world > 1:
+            exposed.append(unet._comm_events)          # read after the timed region (no host sync inside it)
     torch.cuda.synchronize(); ddist.barrier(); torch.cuda.synchronize()
     elapsed = ddist.max_over_ranks(time.perf_counter() - t0)
+    comm_exposed_ms = None
+    if exposed and all(e is not None for e in exposed):
+        comm_exposed_ms = ddist.max_over_ranks(sum(e0.elapsed_time(e1) for e0, e1 in exposed) / len(exposed))
     assert torch.isfinite(loss), "non-finite loss"
     classes = None
     if not args.no_profile and rank == 0 and world == 1:
@@ -167,7 +175,10 @@ def run_train(args, da, _lib, ddist, rank, world, dev):
            "config": {"workload": f"BASELINE configs[2]: training step, {args.outfits} outfits x 4 items per GPU, {args.config} shape in_channels=8, "
                                   "min-SNR MSE loss, mutual + history conditioning, clip 1.0 + AdamW + EMA",
                       "unet_batch": items, "parallelism": f"data-parallel x{world}, gradients all-reduced over RCCL in 256 MB ranges of the packed arena, overlapped with the backward walk"},
-           "loss": round(float(loss), 5), "hbm_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}
+           "loss": round(float(loss), 5), "hbm_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+           # time per step the compute stream waited for the side-stream gradient exchange = the part of the exchange the backward
+           # walk did not hide (max over ranks; null on one GPU: no exchange)
+           "comm_exposed_ms": None if comm_exposed_ms is None else round(comm_exposed_ms, 3), "grad_wire": args.wire}
     if classes is not None:
         tot_f = sum(v["flops"] for v in classes.values())
         out["kernel_classes"] = {c: dict(launches_per_step=v["launches"] // K, ms_per_step=round(v["ms"] / K, 3),
@@ -306,6 +317,8 @@ def main():
     ap.add_argument("--mode", default="sample", choices=["sample", "train", "vae"],
                     help="sample: the headline metric (default); train: BASELINE configs[2]/[3] training step; vae: SURVEY 8f-1")
     ap.add_argument("--outfits", type=int, default=8, help="--mode train: outfits per GPU per step")
+    ap.add_argument("--wire", default="fp32", choices=["fp32", "bf16"],
+                    help="--mode train: gradient exchange format (bf16: all_to_all + fp32 accumulate + all_gather, half the bytes per link)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: BASELINE configs[4] -- the LayerNorm-fed transformer projections in e4m3 on the block-scaled MFMA")
     args = ap.parse_args()

@@ -10,6 +10,7 @@ struct AttnArgs {
   int B, H, D, Nq, Nk;
   float scale;                  // D^-0.5
   float* lse;                   // optional [B][H][Nq] fp32: log2-domain log-sum-exp (m + log2 l) of the scaled scores, for backward
+  unsigned long long* prof;     // diagnosis only (DFH_ATTN_PROF=1): s_memtime stamps of workgroup 0 / wave 0, 8 per key tile
 };
 
 // Attention backward (training): P is recomputed from Q, K and the forward LSE; two passes of one kernel.

@@ -28,6 +28,7 @@
 #include "dfh_common.h"
 #include "attention.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -62,7 +63,7 @@ template <int KROW> DFH_DEVICE int k_swz(int key) { return KROW == 128 ? ((key >
 DFH_DEVICE int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
 // QB = 32-query blocks per wave (2: 256 queries per workgroup; 1: 128, for head dims whose accumulators would not fit)
-template <int D, int QB, int MINW>
+template <int D, int QB, int MINW, bool PROF = false>
 __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs a) {
   using G = X32Geom<D>;
   constexpr int KS = G::KS, DB = G::DB, DCH = G::DCH, NCH = G::NCH, KROW = G::KROW, NKI = G::NKI, NVI = G::NVI;
@@ -246,6 +247,11 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
       else if (more) load_tile(kv0 + KVT, std::false_type{});
       const unsigned char* Ks = smem + (t & 1) * G::BUF;
       const unsigned char* Vs = Ks + G::K_BYTES;
+      const bool stamp = PROF && a.prof && blockIdx.x == 0 && wave == 0 && lane == 0 && t < 64;
+      auto mark = [&](int i) {          // diagnosis build only: wave-issue timeline (s_memtime = shader cycles)
+        if (PROF) { __builtin_amdgcn_sched_barrier(0); if (stamp) a.prof[t * 8 + i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+      };
+      mark(0);
 
       // ---- S^T = K . Q'^T - m : [kb] 32 keys x [qb] 32 queries
       f32x16_t s[2][QB];
@@ -267,6 +273,7 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
           }
         }
       }
+      mark(1);
       if (PRE) {
         // ---- deferred max: lane-local maxima (a tree: four independent chains per query block), one wave-uniform test
         float mx[QB];
@@ -317,6 +324,7 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
 #pragma unroll
           for (int r = 0; r < 16; r += 2)
             pw[kb][qb][r >> 1] = pack2bf(__builtin_amdgcn_exp2f(s[kb][qb][r]), __builtin_amdgcn_exp2f(s[kb][qb][r + 1]));
+      mark(2);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -330,6 +338,7 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
               o[db][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8_t, pv), o[db][qb], 0, 0, 0);
             }
           }
+      mark(3);
       if (more) {
         store_tile((t + 1) & 1);                     // the other buffer: last read one barrier ago
         // a ragged last tile changes the mask column of the buffer it lands in (buffers 0 / 1 were initialised for tiles 0 / 1)
@@ -364,7 +373,9 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
           }
         }
       }
+      mark(4);
       __syncthreads();
+      mark(5);
     };
     if (SAFE) {
       int t = 0;
@@ -414,18 +425,18 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
   }
 }
 
-template <int D, int QB, int MINW>
+template <int D, int QB, int MINW, bool PROF = false>
 int launch_x32(const AttnArgs& a, hipStream_t stream) {
   constexpr int lds = 2 * X32Geom<D>::BUF + 16;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attention_x32_kernel<D, QB, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attention_x32_kernel<D, QB, MINW, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int nqb = (a.Nq + 128 * QB - 1) / (128 * QB);
   dfh::ProfScope ps(dfh::PC_ATTN, 4.0 * a.B * a.H * (double)a.Nq * a.Nk * D,
                     2.0 * a.B * a.H * D * (2.0 * a.Nq + 2.0 * a.Nk), stream);
-  hipLaunchKernelGGL((attention_x32_kernel<D, QB, MINW>), dim3(nqb * a.H * a.B), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((attention_x32_kernel<D, QB, MINW, PROF>), dim3(nqb * a.H * a.B), dim3(256), lds, stream, a);
   return dfh::check_launch("attention_x32_kernel");
 }
 
@@ -443,6 +454,25 @@ int attention_x32_launch(const AttnArgs& a, hipStream_t stream) {
   static const int variant = [] { const char* e = getenv("DFH_ATTN_VARIANT"); return e ? atoi(e) : 0; }();   // experiments
   switch (a.D) {
     case 40:
+      if (variant == 9) {      // diagnosis: one launch with the phase stamps, printed as per-phase cycle averages
+        static unsigned long long* buf = nullptr;
+        if (!buf && hipMalloc((void**)&buf, 64 * 8 * 8) != hipSuccess) return -1;
+        (void)hipMemsetAsync(buf, 0, 64 * 8 * 8, stream);
+        AttnArgs b = a; b.prof = buf;
+        const int rc = launch_x32<40, 2, 2, true>(b, stream);
+        unsigned long long h[64 * 8];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h, buf, sizeof(h), hipMemcpyDeviceToHost);
+        double ph[6] = {0, 0, 0, 0, 0, 0}; int n = 0;
+        for (int t = 4; t < 60; ++t) {
+          if (!h[t * 8] || !h[(t + 1) * 8]) continue;
+          for (int i = 0; i < 5; ++i) ph[i] += (double)(h[t * 8 + i + 1] - h[t * 8 + i]);
+          ph[5] += (double)(h[(t + 1) * 8] - h[t * 8 + 5]); ++n;
+        }
+        if (n) fprintf(stderr, "[attn prof] cycles per tile (wave 0 of workgroup 0, %d tiles): S-issue %.0f | (pre-check) %.0f | exp+pack %.0f | PV-issue %.0f | "
+                               "stage-store+check %.0f | barrier %.0f | loop-back %.0f\n", n, ph[0] / n, 0.0, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n);
+        return rc;
+      }
       if (variant == 1) return launch_x32<40, 1, 3>(a, stream);
       if (variant == 2) return launch_x32<40, 1, 4>(a, stream);
       return launch_x32<40, 2, 2>(a, stream);

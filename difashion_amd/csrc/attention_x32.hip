@@ -22,9 +22,18 @@
 //   * what is left per score: one v_exp_f32, half a v_cvt_pk_bf16_f32, half a v_max3_f32 (the deferred-max check:
 //     the running max only moves when some score exceeds it by 2^8, a wave-uniform rare branch).
 //   * 4 waves x 64 queries (two 32-query blocks: every K / V^T fragment read feeds two MFMAs) = 256 queries per
-//     workgroup, ~250 VGPRs, two workgroups per CU: while one wave of a SIMD is in its exp / pack phase its neighbour
-//     issues MFMAs.  K / V^T tiles of 64 keys are double-buffered in LDS (issue-early / write-late register staging,
-//     one barrier per tile), 16-byte slots XOR-swizzled so every ds_read_b128 fragment read is conflict-free.
+//     workgroup, ~240 VGPRs, two workgroups per CU: while one wave of a SIMD is in its exp / pack phase its neighbour
+//     issues MFMAs.  K / V^T tiles of 64 keys are double-buffered in LDS (issue-early / write-late register staging through
+//     buffer loads, one barrier per tile), 16-byte slots XOR-swizzled so every ds_read_b128 fragment read is conflict-free.
+//
+// What bounds it (profiles/r02/coissue.txt, valu_rate.txt -- scripts/probes/coissue.hip): per SIMD a v_exp_f32 occupies the
+// VALU port for ~8.7 cycles and any other VALU instruction for ~4.6, whichever wave issues it, and one wave mixing MFMAs with
+// exps overlaps them only partially (7 MFMA + 16 exp + 8 cvt: 328 cycles alone, 279 each for two co-resident waves, against
+// 224 of matrix-pipe time).  A 64-query x 64-key tile costs 28 MFMAs = 896 matrix-pipe cycles and 64 exp + 32 cvt + ~30 other
+// = ~840 VALU-port cycles: the two are balanced, so d = 40 attention cannot approach the MFMA roof the way d = 128 does
+// (one exp per 4 x 56 padded flop instead of per 4 x 128).  Measured: 2130 cycles per tile with one wave per SIMD, 1830 per SIMD
+// with two; a software-pipelined variant (S of block i+1 and P.V of block i-1 issued around the exps of block i, LDS-DMA
+// staging) and s_setprio around the MFMA clusters were both measured and were not faster (555 / 475 vs 470 us).
 #include "dfh_common.h"
 #include "attention.h"
 
@@ -65,6 +74,7 @@ DFH_DEVICE int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1
 // QB = 32-query blocks per wave (2: 256 queries per workgroup; 1: 128, for head dims whose accumulators would not fit)
 template <int D, int QB, int MINW, bool PROF = false>
 __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs a) {
+  constexpr int NBUF = 2;                                  // K / V^T tile buffers in LDS
   using G = X32Geom<D>;
   constexpr int KS = G::KS, DB = G::DB, DCH = G::DCH, NCH = G::NCH, KROW = G::KROW, NKI = G::NKI, NVI = G::NVI;
   constexpr int WQ = QB * 32;                              // queries per wave
@@ -132,36 +142,39 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
   }
   uint4 kreg[NKI], vreg[NVI];
 
+  // K / V^T tiles are fetched with buffer loads: one descriptor per operand in SGPRs (built from wave-uniform values), a
+  // 32-bit per-lane byte offset fixed for the kernel and the tile's byte offset in an SGPR -- no 64-bit address VGPRs in the
+  // loop (as pointers they cost 8 VGPRs that hipcc spilled to scratch and reloaded, ~500 cycles each, at the top of every
+  // tile).  The K descriptor ends with the last valid key row, so rows beyond Nk read as zeros without a predicate.
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  const unsigned k_bytes = a.Nk > 0 ? (unsigned)(((long)(a.Nk - 1) * a.ldk + D) * 2) : 0u;
+  const unsigned v_bytes = (unsigned)(((long)(D - 1) * a.ldvt + a.ldvt) * 2);
+  const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, k_bytes, 0x00020000);
+  const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, v_bytes, 0x00020000);
   auto load_tile = [&](int kv0, auto full_c) {   // global -> registers (zeros beyond Nk)
     constexpr bool FULL = decltype(full_c)::value;
-    const bf16_t* kt = Kb + (long)kv0 * a.ldk;
-    const bf16_t* vt = Vb + kv0;
+    const int k_soff = kv0 * a.ldk * 2, v_soff = kv0 * 2;                    // wave-uniform byte offsets of the tile
 #pragma unroll
     for (int i = 0; i < NKI; ++i) {
-      if (FULL) kreg[i] = *(const uint4*)(kt + k_goff[i]);
-      else {
-        kreg[i] = uint4{0u, 0u, 0u, 0u};
-        if (kv0 + k_key[i] < a.Nk) kreg[i] = *(const uint4*)(kt + k_goff[i]);
-      }
+      const u32x4_t r = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_goff[i] * 2, k_soff, 0);
+      kreg[i] = uint4{r[0], r[1], r[2], r[3]};
     }
 #pragma unroll
     for (int i = 0; i < NVI; ++i) {
-      if (FULL) vreg[i] = *(const uint4*)(vt + v_goff[i]);
-      else {
+      const u32x4_t r = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, v_goff[i] * 2, v_soff, 0);
+      uint4 v = uint4{r[0], r[1], r[2], r[3]};
+      if (!FULL) {
         const int k0 = kv0 + v_k0[i];
-        uint4 v = uint4{0u, 0u, 0u, 0u};
-        if (k0 < a.Nk) {
-          v = *(const uint4*)(vt + v_goff[i]);
-          if (k0 + 8 > a.Nk) {   // ragged tail: zero the padding keys (they may hold anything, NaN included)
-            const int valid = a.Nk - k0;
-            uint32_t* w = (uint32_t*)&v;
+        if (k0 >= a.Nk) v = uint4{0u, 0u, 0u, 0u};
+        else if (k0 + 8 > a.Nk) {   // ragged tail: zero the padding keys (they may hold anything, NaN included)
+          const int valid = a.Nk - k0;
+          uint32_t* w = (uint32_t*)&v;
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (e >= valid) w[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
-          }
+          for (int e = 0; e < 8; ++e)
+            if (e >= valid) w[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
         }
-        vreg[i] = v;
       }
+      vreg[i] = v;
     }
   };
   auto store_tile = [&](int buf) {               // registers -> swizzled LDS image
@@ -206,7 +219,7 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
   const int ntiles = (a.Nk + KVT - 1) / KVT;
   const int tail_valid = a.Nk - (ntiles - 1) * KVT;          // valid keys of the last tile (KVT when Nk % 64 == 0)
   const int nfast = a.Nk / KVT - 1;                          // tiles whose successor is a full tile
-  unsigned* poison_flag = (unsigned*)(smem + 2 * G::BUF);    // one word behind the tile buffers
+  unsigned* poison_flag = (unsigned*)(smem + NBUF * G::BUF); // one word behind the tile buffers
   if (tid == 0) *poison_flag = 0u;
 
   // One pass over the keys.  SAFE = false (the fast pass): after the first tile there is NO per-score max -- the running
@@ -391,6 +404,7 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
     return poison;
   };
 
+
   const bool poisoned = pass(std::false_type{});
   if (__any(poisoned) && lane == 0) *poison_flag = 1u;
   __syncthreads();
@@ -469,11 +483,11 @@ int attention_x32_launch(const AttnArgs& a, hipStream_t stream) {
           for (int i = 0; i < 5; ++i) ph[i] += (double)(h[t * 8 + i + 1] - h[t * 8 + i]);
           ph[5] += (double)(h[(t + 1) * 8] - h[t * 8 + 5]); ++n;
         }
-        if (n) fprintf(stderr, "[attn prof] cycles per tile (wave 0 of workgroup 0, %d tiles): S-issue %.0f | (pre-check) %.0f | exp+pack %.0f | PV-issue %.0f | "
-                               "stage-store+check %.0f | barrier %.0f | loop-back %.0f\n", n, ph[0] / n, 0.0, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n);
+        if (n) fprintf(stderr, "[attn prof] cycles per tile (wave 0 of workgroup 0, %d tiles): S-issue %.0f | exp+pack %.0f | PV-issue %.0f | "
+                               "stage-store+check %.0f | barrier %.0f | loop-back %.0f\n", n, ph[0] / n, ph[1] / n, ph[2] / n, ph[3] / n, ph[4] / n, ph[5] / n);
         return rc;
       }
-      if (variant == 1) return launch_x32<40, 1, 3>(a, stream);
+      if (variant == 1) return launch_x32<40, 1, 3>(a, stream);      // experiments: one 32-query block per wave at 3 / 4 waves per SIMD
       if (variant == 2) return launch_x32<40, 1, 4>(a, stream);
       return launch_x32<40, 2, 2>(a, stream);
     case 80:

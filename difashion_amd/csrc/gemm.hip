@@ -21,70 +21,13 @@
 //   * XCD-aware tile order; split-K through fp32 slabs + a deterministic reduce kernel for the
 //     8x8 / 16x16 levels whose M is too small to fill 256 CUs.
 #include "gemm.h"
+#include "gemm_kiter.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 
 namespace {
-
-constexpr int BK = 64;            // k-step depth (bf16 elements) = one 128-byte LDS row
-
-struct KIter {                    // which 64-deep slice of which K segment a k-step covers
-  int seg;                        // 0..ntaps-1 conv taps, then plain segments
-  int c0;                         // channel offset inside the segment
-  int wcol;                       // column of W where this slice starts
-  int seglen;                     // channels in the current segment
-};
-
-DFH_DEVICE int cdiv64(int x) { return (x + BK - 1) / BK; }
-
-DFH_DEVICE int seg_len(const GemmArgs& a, int seg) {
-  // selects, not a[] indexing: a runtime index into the kernel arguments becomes an s_load + lgkmcnt(0) stall in the k-loop
-  return seg < a.ntaps ? a.conv_c : (seg == a.ntaps ? a.p_c[0] : a.p_c[1]);
-}
-
-// K is walked CHANNEL-CHUNK-major over the conv taps: the nine taps of one 64-channel slice are consecutive k-steps, so
-// the shifted re-reads of a pixel tile (eight of nine taps touch rows the previous taps already fetched) come back within
-// ~1 MB of L2 traffic per XCD instead of after the whole tile x all channels (10 MB at the 64x64 level: they missed).
-// W columns stay tap-major (column = tap * Cin + c): any k order works as long as A slice and W column agree.
-DFH_DEVICE KIter kiter_at(const GemmArgs& a, int kstep) {
-  KIter it;
-  const int conv_steps = a.ntaps * cdiv64(a.conv_c);
-  if (kstep < conv_steps) {
-    const int cc = kstep / a.ntaps;
-    it.seg = kstep - cc * a.ntaps; it.c0 = cc * BK; it.seglen = a.conv_c; it.wcol = it.seg * a.conv_c + it.c0;
-    return it;
-  }
-  kstep -= conv_steps;
-  int seg = a.ntaps, base = a.ntaps * a.conv_c;
-  const int nseg = a.ntaps + a.nplain;
-  for (;;) {
-    const int len = seg_len(a, seg);
-    const int n = cdiv64(len);
-    if (kstep < n || seg == nseg - 1) { it.seglen = len; break; }
-    kstep -= n; base += len; ++seg;
-  }
-  it.seg = seg; it.c0 = kstep * BK; it.wcol = base + it.c0;
-  return it;
-}
-
-DFH_DEVICE void kiter_next(const GemmArgs& a, KIter& it) {
-  if (it.seg < a.ntaps) {                  // inside the conv part: next tap of the same channel slice
-    ++it.seg; it.wcol += a.conv_c;
-    if (it.seg < a.ntaps) return;
-    it.seg = 0; it.c0 += BK; it.wcol = it.c0;
-    if (it.c0 < a.conv_c) return;
-    it.seg = a.ntaps; it.c0 = 0; it.wcol = a.ntaps * a.conv_c;     // conv part done: first plain segment
-    if (a.nplain > 0) it.seglen = seg_len(a, it.seg);
-    return;
-  }
-  it.c0 += BK; it.wcol += BK;
-  if (it.c0 >= it.seglen) {
-    it.wcol -= it.c0 - it.seglen;        // next segment starts right after this one's real length
-    it.c0 = 0; ++it.seg;
-    if (it.seg < a.ntaps + a.nplain) it.seglen = seg_len(a, it.seg);
-  }
-}
 
 // counted wait on this wave's outstanding vector-memory operations (LDS-DMA pieces)
 template <int N> DFH_DEVICE void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -689,8 +632,21 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     ProfScope ps(a.ntaps ? PC_CONV3 : PC_LINEAR, 2.0 * a.M * a.N * kreal, abytes + (double)a.N * kreal * 2.0 + obytes, stream);
     const bool wide_ok = split == 1 && a.out_mode == OUT_BF16 && (a.act != ACT_GEGLU || a.N % 160 == 0 || a.N % 128 == 0) && (a.N & 7) == 0 &&
                          (a.ld_out & 7) == 0 && (!a.resid || (a.ld_res & 7) == 0);
-    const int wide = (!wide_ok || force_deep) ? 0 : (force_wide ? force_wide : ((force_tile == 0 && force_split == 0) ? gemm_wide_pick(a) : 0));
-    if (wide) rc = gemm_wide_launch(a, stream, wide);
+    int wide = (!wide_ok || force_deep) ? 0 : (force_wide ? force_wide : ((force_tile == 0 && force_split == 0) ? gemm_wide_pick(a) : 0));
+    // tile ids 11 / 12 (force_wide 6 / 7): the wave-specialised kernel (gemm_ws.hip) with a 160 / 128 column tile.  Measured
+    // (scripts/gemm_ws_probe.py, profiles/r02/gemm_ws_probe.txt): equal to the eight-wave 128 x 160 kernel at the 32x32 / 16x16
+    // levels, 5-20 % SLOWER than the wide kernel at the 64x64 level -- four loader waves sustain ~16 B/clk/CU of LDS-DMA (one
+    // 1-KiB piece per ~250 cycles and wave) where the tile needs 40 -- so it is opt-in: DFH_GEMM_WS=1 lets it take the launches
+    // that give every CU a 256-row tile.
+    static const bool ws_off = [] { const char* e = getenv("DFH_GEMM_WS"); return !(e && e[0] == '1'); }();
+    int ws = 0;
+    if (wide_ok && !force_deep) {
+      if (force_wide == 6 || force_wide == 7) ws = gemm_ws_pick(a, 1) ? (force_wide == 6 ? 160 : 128) : 0;
+      else if (!force_wide && force_tile == 0 && force_split == 0 && !ws_off) ws = gemm_ws_pick(a, 224);
+    }
+    if (force_wide >= 6) wide = 0;                      // not eligible (odd N, transposed / fp32 output): the default tile runs
+    if (ws) rc = gemm_ws_launch(a, stream, ws);
+    else if (wide) rc = gemm_wide_launch(a, stream, wide);
     else rc = launch_variant(tile, a, stream);
   }
   if (rc) return rc;

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 # ----------------------------------------------------------------------------- GEMM (linear / 1x1 conv)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])  # every tile / pipeline-depth variant of gemm.hip; 6-9 = gemm_wide.hip; 10 = eight-wave 128x160
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])  # every tile / pipeline-depth variant of gemm.hip; 6-9 = gemm_wide.hip; 10 = eight-wave 128x160; 11 / 12 = gemm_ws.hip
 @pytest.mark.parametrize("glds", [1])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (128, 160, 64), (77 * 3, 64, 768), (16, 1280, 200), (4, 256, 2048)])
 def test_gemm_plain(tile, glds, M, N, K):
@@ -50,7 +50,7 @@ def test_gemm_two_sources_is_channel_concat():
     gu.assert_close_bf16(out, ref, "concat")
 
 
-@pytest.mark.parametrize("tile", [0, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [0, 6, 7, 8, 9, 11, 12])
 @pytest.mark.parametrize("act,fn", [(1, F.silu), (2, lambda x: F.leaky_relu(x, 0.01)), (3, torch.tanh)])
 def test_gemm_activations_and_rowvec(act, fn, tile):
     B, rows, N, K = 3, 40, 128, 96
@@ -64,7 +64,7 @@ def test_gemm_activations_and_rowvec(act, fn, tile):
 
 
 @pytest.mark.parametrize("M,C,tile", [(200, 64, 0), (300, 40, 0), (300, 40, 6), (520, 80, 6), (300, 40, 7), (300, 40, 8), (700, 80, 8),
-                                         (300, 64, 9), (700, 80, 9), (256, 16, 9)])
+                                         (300, 64, 9), (700, 80, 9), (256, 16, 9), (300, 40, 11), (700, 80, 11), (300, 64, 12), (520, 80, 12)])
 def test_gemm_geglu_epilogue(M, C, tile):
     """FeedForward GEGLU: proj -> chunk(2) -> a * gelu(gate); weights/bias interleaved by dfh_pack_*."""
     x = bf(rnd(M, C, seed=15))
@@ -101,7 +101,7 @@ def test_gemm_transposed_outputs():
     (64, 4, 16, 1, 0),      # conv_out shape class
     (128, 128, 2, 1, 0),    # 2x2 level of the tiny configs: every tap hits padding somewhere
 ])
-@pytest.mark.parametrize("glds", [0, 1, 4, 6, 7, 8, 9, 10])   # here: forced tile variant (0 = heuristic, 1 = 256x160 ring, 4 = 128x160 2-stage, 6 = wide)
+@pytest.mark.parametrize("glds", [0, 1, 4, 6, 7, 8, 9, 10, 11, 12])   # here: forced tile variant (0 = heuristic, 1 = 256x160 ring, 4 = 128x160 2-stage, 6 = wide)
 def test_conv3x3(cin, cout, H, stride, ups, glds):
     B = 2
     x = bf(rnd(B, cin, H, H, seed=20))
@@ -115,7 +115,7 @@ def test_conv3x3(cin, cout, H, stride, ups, glds):
     gu.assert_close_bf16(gu.nchw(out.view(B, Ho, Ho, cout)), ref, f"conv {cin}->{cout}@{H} s{stride} u{ups}")
 
 
-@pytest.mark.parametrize("tile", [0, 1, 6, 10])
+@pytest.mark.parametrize("tile", [0, 1, 6, 10, 11])
 @pytest.mark.parametrize("cin,H,W", [(64, 12, 20), (128, 5, 3), (192, 16, 1)])
 def test_conv3x3_lean_tap_staging_on_non_square_inputs(cin, H, W, tile):
     """The lean tap staging (centre-pixel offset + 9-bit validity mask per staging piece) on inputs whose height and
@@ -131,7 +131,7 @@ def test_conv3x3_lean_tap_staging_on_non_square_inputs(cin, H, W, tile):
     gu.assert_close_bf16(gu.nchw(out.view(B, H, W, cout)), ref, f"conv {cin}->{cout}@{H}x{W} tile{tile}")
 
 
-@pytest.mark.parametrize("tile", [0, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [0, 6, 7, 8, 9, 11, 12])
 def test_conv3x3_with_fused_shortcut_and_temb(tile):
     """ResnetBlock2D tail: conv2(h) + conv_shortcut(cat(x, skip)) + biases, and conv1 + time embedding."""
     B, H, c0, c1, cout = 2, 8, 64, 32, 96

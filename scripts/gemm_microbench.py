@@ -22,7 +22,7 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters * 1e3   # us
 
 
-def run(name, M, N, K, conv=None, bias=True, resid=True, out_mode=0, act=0, tile=0, split=0, glds=-1, zeros=False):
+def run(name, M, N, K, conv=None, bias=True, resid=True, out_mode=0, act=0, tile=0, split=0, glds=-1, zeros=False, iters=20, warm=3):
     d = _lib.GemmDesc()
     keep = []
     if conv:
@@ -54,10 +54,13 @@ def run(name, M, N, K, conv=None, bias=True, resid=True, out_mode=0, act=0, tile
     if need:
         p = torch.empty(need, device=DEV); keep.append(p); d.partial, d.partial_floats = p.data_ptr(), need
     s = _lib.stream_ptr()
-    us = timeit(lambda: _lib.call("dfh_gemm", C.byref(d), s))
+    us = timeit(lambda: _lib.call("dfh_gemm", C.byref(d), s), iters=iters, warm=warm)
     fl = 2.0 * M * N * Kt
     by = 2.0 * (M * Kt if not conv else conv[0] * conv[1] ** 2 * conv[2]) + 2.0 * N * Kt + out.numel() * out.element_size()
+    if resid and act != 4:
+        by += 2.0 * M * N
     print(f"{name:42s} M={M:6d} N={N:5d} K={Kt:6d} {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s  {by / us / 1e3:7.1f} GB/s", flush=True)
+    return dict(us=us, read_bytes=by - out.numel() * out.element_size(), write_bytes=out.numel() * out.element_size())
 
 
 if __name__ == "__main__":

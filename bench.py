@@ -296,6 +296,36 @@ def pmc_traffic():
         return None, None
 
 
+def per_launch_bound(dump_path, steps):
+    """Per kernel class, from the per-launch dump of dfh_prof_end: sum of max(flops / MFMA peak, bytes / HBM peak) (the time a
+    launch cannot beat on this part, nominal peaks) and of the measured durations, per step; launches counted by their bound."""
+    out, table = {}, {}
+    try:
+        with open(dump_path) as f:
+            for line in f:
+                cls, flops, nbytes, ms = line.split()
+                g = table.setdefault((cls, flops, nbytes), [0, 0.0]); g[0] += 1; g[1] += float(ms)
+                t_mfma = float(flops) / (MFMA_BF16_PEAK * 1e12) * 1e3
+                t_hbm = float(nbytes) / (HBM_PEAK * 1e9) * 1e3
+                r = out.setdefault(cls, dict(attainable_ms=0.0, measured_ms=0.0, hbm_bound=0, mfma_bound=0))
+                r["attainable_ms"] += max(t_mfma, t_hbm); r["measured_ms"] += float(ms)
+                r["hbm_bound" if t_hbm >= t_mfma else "mfma_bound"] += 1
+        os.remove(dump_path)
+    except OSError:
+        return {}
+    if os.environ.get("DFH_PROF_TABLE"):          # per-shape table (diagnosis): launches with equal class / flops / bytes grouped
+        with open(os.environ["DFH_PROF_TABLE"], "w") as f:
+            f.write(f"{'class':16s} {'GFLOP':>9s} {'MB':>8s} {'n/step':>6s} {'avg us':>8s} {'ms/step':>8s} {'TFLOP/s':>8s} {'GB/s':>7s} {'bound us':>8s}\n")
+            for (cls, flops, nbytes), (n, ms) in sorted(table.items(), key=lambda kv: -kv[1][1]):
+                fl, by, us = float(flops), float(nbytes), ms / n * 1e3
+                lb = max(fl / (MFMA_BF16_PEAK * 1e12), by / (HBM_PEAK * 1e9)) * 1e6
+                f.write(f"{cls:16s} {fl / 1e9:9.2f} {by / 1e6:8.1f} {n / steps:6.1f} {us:8.1f} {ms / steps:8.3f} {fl / us / 1e6:8.1f} {by / us / 1e3:7.0f} {lb:8.1f}\n")
+    for r in out.values():
+        r["attainable_ms"] /= steps; r["measured_ms"] /= steps
+        r["hbm_bound"] //= steps; r["mfma_bound"] //= steps
+    return out
+
+
 def kernel_source_hash():
     """sha256 over the HIP kernel sources: ties a committed PMC summary to the code it was measured on."""
     import glob, hashlib
@@ -376,8 +406,13 @@ def main():
         _lib.prof_begin()
         t1 = time.perf_counter()
         run_steps(K, W)
+        import tempfile
+        dump = os.path.join(tempfile.gettempdir(), f"dfh_prof_dump_{os.getpid()}.txt")
+        os.environ["DFH_PROF_DUMP"] = dump                       # one line per launch: class, flops, bytes, ms
         classes = _lib.prof_end()
+        os.environ.pop("DFH_PROF_DUMP", None)
         prof_ms = (time.perf_counter() - t1) * 1e3 / K
+        bound = per_launch_bound(dump, K)
         gemm = {k: sum(classes[c][k] for c in ("gemm_conv3x3", "gemm_linear")) for k in ("launches", "ms", "flops", "bytes")}
         achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic()
@@ -407,6 +442,16 @@ def main():
                                           frac=round(tf("gemm_linear_fp8") / MFMA_FP8_PEAK, 4),
                                           launches_per_step=classes["gemm_linear_fp8"]["launches"] // K)
         roofline["secondary"] = sec
+        # the family is a MIX of MFMA-bound and HBM-bound launches (a 65536 x 320 x 320 linear moves 126 MB for 13 GFLOP: 16 us at
+        # 8 TB/s, 5 us at 2.5 PFLOP/s), so beside the family-wide flop rate: sum over launches of max(flops / MFMA peak, algorithmic
+        # bytes / HBM peak) against the summed measured durations
+        gb = [bound.get(c) for c in ("gemm_conv3x3", "gemm_linear") if bound.get(c)]
+        if gb:
+            att = sum(b["attainable_ms"] for b in gb); meas = sum(b["measured_ms"] for b in gb)
+            roofline["per_launch_bound"] = dict(
+                attainable_ms_per_step=round(att, 3), measured_ms_per_step=round(meas, 3), frac=round(att / meas, 4),
+                hbm_bound_launches_per_step=sum(b["hbm_bound"] for b in gb), mfma_bound_launches_per_step=sum(b["mfma_bound"] for b in gb),
+                note="sum over launches of max(flops / 2500 TFLOP/s, algorithmic bytes / 8000 GB/s) over the sum of measured durations")
 
     if world > 1:
         ddist.barrier()
@@ -430,7 +475,8 @@ def main():
             return round(classes[c][key] / (classes[c]["ms"] * 1e-3) / scale, 1) if classes[c]["ms"] > 0 else None
         out["kernel_classes"] = {
             c: dict(launches_per_step=v["launches"] // K, ms_per_step=round(v["ms"] / K, 3),
-                    tflops=rate(c, "flops", 1e12) if v["flops"] else None, algorithmic_GBps=rate(c, "bytes", 1e9))
+                    tflops=rate(c, "flops", 1e12) if v["flops"] else None, algorithmic_GBps=rate(c, "bytes", 1e9),
+                    roofline_ms_per_step=round(bound[c]["attainable_ms"], 3) if c in bound else None)
             for c, v in classes.items() if v["launches"]}
         out["profiled_pass_ms_per_step"] = round(prof_ms, 3)
         attn = classes["attention"]

@@ -11,7 +11,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libdifashion_hip.so")
+# DFH_LIB=<path>: load another build of the library (same-box A/B probes); the product path never sets it
+LIB_PATH = os.environ.get("DFH_LIB") or os.path.join(CSRC, "libdifashion_hip.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "difashion_hip.h")
 
 DFH_MAX_BLOCKS = 4

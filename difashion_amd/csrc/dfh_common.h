@@ -41,7 +41,13 @@ DFH_DEVICE uint4 pack8(const float* f) {
   return v;
 }
 
-DFH_DEVICE float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division: the division expands to ~10 VALU
+// instructions (v_div_scale / v_rcp / 4 x v_fma / v_div_fmas / v_div_fixup), which made GroupNorm+SiLU VALU-bound -- 42 M
+// elements per 64x64-level launch at ~70 wave-cycles per 64 of them is 19 us of a 27 us kernel.  The result is rounded to bf16
+// (8 mantissa bits) right after; limits as before: -0 for x -> -inf side, x for x -> +inf.
+DFH_DEVICE float silu_f(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
 // exact-erf GELU (diffusers GEGLU uses F.gelu, erf form).  erf by Abramowitz-Stegun 7.1.26:
 // |error| <= 1.5e-7 absolute -- three orders below the bf16 rounding of the result -- at 13 VALU ops
 // (one v_rcp, one v_exp) instead of libm erff's ~33.
@@ -127,4 +133,39 @@ DFH_DEVICE int xcd_remap(int bid, int nblk) {
   const int xcd = bid & 7, idx = bid >> 3;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
+}
+
+// Tile id -> (row tile, column tile) of an ntm x ntn GEMM grid.  What matters for the private 4-MiB L2 of an XCD is the set of
+// tiles it runs CONCURRENTLY (~64: two workgroups on each of its 32 CUs, marching through K roughly in lock step): a set of
+// gm row tiles x 64/gm column tiles fetches gm A panels + 64/gm W panels from the fabric, every other read is an L2 hit.
+// Plain m-major ids make that set 1-3 row tiles x ALL column tiles, so with many column tiles (GEGLU projections: 40 / 80)
+// every XCD re-streams the whole weight matrix once per row tile (measured with FETCH_SIZE: 11-12 x the algorithmic bytes at
+// the 32x32 / 16x16 levels, profiles/r02/pmc_traffic_calib.txt).  Two knobs, both chosen by the launcher:
+//   xm: the 8 XCDs form an xm x (8/xm) grid over the tile grid (only when xm | ntm and 8/xm | ntn; otherwise each XCD takes a
+//       contiguous range of the m-major id list as before), so an XCD can own a rectangle with enough rows AND columns;
+//   gm: inside its rectangle an XCD walks groups of gm row tiles column by column (ids run down a column of gm row tiles,
+//       then step to the next column tile).
+// gm == 0 keeps the legacy order (m-major, or n-major when n_major is set).  Placement never changes results.
+DFH_DEVICE void tile_coords(int bid, int ntm, int ntn, int n_major, int xm, int gm, int& mt, int& nt) {
+  if (gm <= 0) {
+    const int tile = xcd_remap(bid, ntm * ntn);
+    mt = n_major ? tile % ntm : tile / ntn;
+    nt = n_major ? tile / ntm : tile % ntn;
+    return;
+  }
+  int rm = ntm, rn = ntn, mbase = 0, nbase = 0, idx;
+  const int xn = xm > 0 ? 8 / xm : 0;
+  if (xm > 0 && ntm % xm == 0 && ntn % xn == 0) {
+    const int xcd = bid & 7;
+    rm = ntm / xm; rn = ntn / xn;
+    mbase = (xcd / xn) * rm; nbase = (xcd % xn) * rn;
+    idx = bid >> 3;
+  } else {
+    idx = xcd_remap(bid, ntm * ntn);
+  }
+  const int per = gm * rn, group = idx / per, first = group * gm;
+  const int gsz = (rm - first) < gm ? (rm - first) : gm;
+  const int w = idx - group * per;
+  mt = mbase + first + w % gsz;
+  nt = nbase + w / gsz;
 }

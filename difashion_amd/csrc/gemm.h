@@ -31,6 +31,7 @@ struct GemmArgs {
   int ksteps;      // total 64-deep k-steps over all segments
   int ksplit;      // grid.z; each z handles a contiguous range of k-steps
   int n_major;     // tile ids enumerate column tiles slowest (set by the launcher when the weights outweigh the pixels)
+  int tm_xm, tm_gm;  // XCD grid rows / row-tile group of the tile order (dfh_common.h tile_coords); 0 = legacy order
   // --- epilogue:  v = acc + bias[n] + rowvec[m / rows_per_b][rv_off + n];  v = act(v);  v += resid[m][n]
   const float* bias;
   const float* rowvec; int rv_ld; int rv_off; int rows_per_b;

@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 
 namespace {
@@ -38,7 +39,10 @@ template <int N> DFH_DEVICE void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0
 // constant -- no segment iterator, no per-piece predicates / selects / multiplies (the generic loop spends ~190 SALU and
 // ~125 VALU instructions per k-step beside 20 MFMAs; with 2 waves per SIMD that, not the MFMA pipe, paces the loop).
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool LEAN = false>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a) {
+// second launch-bound = waves per SIMD the register allocation must leave room for: the eight-wave 128-row tiles run TWO workgroups
+// per CU (4 waves per SIMD, <= 128 VGPRs); without the bound the allocator settles at 130 and silently halves the occupancy
+// (+35 % on every 32x32 / 16x16-level conv, measured)
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) void gemm_bf16_kernel(const GemmArgs a) {
   constexpr int NWV = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;       // per-wave output tile
   constexpr int FM = TM / 16, FN = TN / 16;       // 16x16 fragments per wave
@@ -62,9 +66,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a
   // group of pixel tiles: fine while the activations are the big operand (64x64 / 32x32 levels).  At the deep levels the
   // WEIGHTS are the big operand (1280 x 11520 bf16 = 29 MB against 10 MB of pixels): n-major ids give an XCD whole column
   // tiles, so each weight row is fetched by one XCD only (a.n_major, set by the launcher).
-  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (a.n_major ? tile % ntm : tile / ntn) * BM;
-  const int n0 = (a.n_major ? tile / ntm : tile % ntn) * BN;
+  int mt_, nt_;
+  tile_coords(blockIdx.x, ntm, ntn, a.n_major, a.tm_xm, a.tm_gm, mt_, nt_);
+  const int m0 = mt_ * BM, n0 = nt_ * BN;
 
   // k-step range of this split
   const int per = (a.ksteps + a.ksplit - 1) / a.ksplit;
@@ -215,24 +219,34 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a
 
   const int fr = lane & 15, fg = lane >> 4;
 
-  // Staged epilogue (plain bf16 outputs): the residual tile is fetched into registers BEFORE the k-loop (its latency
-  // hides behind the MFMAs instead of serialising the tail: 16 us of a 46 us K=320 linear at M=65536), and the output
+  // Staged epilogue (plain bf16 outputs): the residual tile is fetched into registers while the k-loop runs and the output
   // tile goes through LDS so that every global store is a full 16-byte piece of a contiguous row (the fragment layout
-  // alone writes 32-byte runs of 128-byte lines).
+  // alone writes 32-byte runs of 128-byte lines).  The residual loads are issued AFTER the pipeline prologue: vmcnt retires
+  // in order, so issued in front of it they sat between the first k-step and its operands (in-kernel stamps: 5.8k instead of
+  // 1.6k cycles from the prologue to the first MFMA); behind it only the first wait has to let them stay in flight (+NRES).
   constexpr int RS = BN * 2 + 16;                  // LDS row stride of the staged output tile (bytes)
+  constexpr int NRES = FM * FN;                    // residual loads per lane
   static_assert(BM * RS <= 2 * STAGE, "staged output tile must fit the pipeline buffers");
+  static_assert(2 * N_HI + NRES <= 63, "vmcnt is a 6-bit counter");
   const bool staged = a.ksplit == 1 && a.out_mode == OUT_BF16 && a.act != ACT_GEGLU && (a.N & 7) == 0 && (a.ld_out & 7) == 0;
   const bool staged_geglu = a.ksplit == 1 && a.act == ACT_GEGLU && (a.ld_out & 7) == 0;
+  const bool res_pre = staged && a.resid != nullptr;
   uint2 rpre[FM][FN];
-  if (staged && a.resid) {
+  auto fetch_resid = [&]() {
+    // SGPR base + 32-bit lane offset (the residual tensor is < 4 GB, checked by the launcher): ten 64-bit lane addresses would
+    // cost the 8 VGPRs that decide between one and two workgroups per CU.  Out-of-range lanes read element 0 (never stored).
+    const unsigned ldr2 = (unsigned)a.ld_res * 2u;
+    const unsigned roff0 = (unsigned)(m0 + wm * TM + fr) * ldr2 + (unsigned)(n0 + wn * TN + fg * 4) * 2u;
+    const char* rbase = (const char*)a.resid;
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int m = m0 + wm * TM + i * 16 + fr, n = n0 + wn * TN + j * 16 + fg * 4;
-        rpre[i][j] = (m < a.M && n < a.N) ? *(const uint2*)(a.resid + (long)m * a.ld_res + n) : uint2{0u, 0u};
+        const unsigned off = (m < a.M && n < a.N) ? roff0 + (unsigned)(i * 16) * ldr2 + (unsigned)(j * 32) : 0u;
+        rpre[i][j] = *(const uint2*)(rbase + off);
       }
-  }
+  };
 
   if (nk > 0) {
     KIter it;
@@ -249,11 +263,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a
         ++issued;
       }
     }
+    if (res_pre) fetch_resid();
     int buf = 0;
     for (int t = 0; t < nk; ++t) {
       // stages beyond t already in flight may stay in flight: wait only for stage t's pieces
       const int ahead = issued - 1 - t;               // 0 .. NSTAGE-2, block-uniform
-      if (ahead == 0) wait_vmcnt<0>();
+      if (t == 0 && res_pre) {                        // ... and so may the residual loads issued behind the prologue
+        if (ahead == 0) wait_vmcnt<NRES>();
+        else if (ahead == 1) { if (hi_wave) wait_vmcnt<N_HI + NRES>(); else wait_vmcnt<N_LO + NRES>(); }
+        else { if (hi_wave) wait_vmcnt<2 * N_HI + NRES>(); else wait_vmcnt<2 * N_LO + NRES>(); }
+      } else if (ahead == 0) wait_vmcnt<0>();
       else if (ahead == 1) { if (hi_wave) wait_vmcnt<N_HI>(); else wait_vmcnt<N_LO>(); }
       else { if (hi_wave) wait_vmcnt<2 * N_HI>(); else wait_vmcnt<2 * N_LO>(); }
       asm volatile("" ::: "memory");
@@ -294,7 +313,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a
   // ---------------------------------------------------------------- epilogue
   const bool partial = a.ksplit > 1;
   if (staged) {
+    if (nk <= 0 && res_pre) fetch_resid();
+    // bias / time-embedding slices of this wave's TN columns go through a wave-private LDS strip behind the output tile: ONE
+    // global load per lane, then unconditional ds_reads per fragment.  Loaded per fragment inside `if (a.bias)`, hipcc kept
+    // every load behind its branch: ten dependent L2 round trips, 4.4-5.5k cycles of a tile whose K = 320 loop takes 6.6k
+    // (in-kernel stamps); batched into registers they cost 8 VGPRs too many for two workgroups per CU.
+    constexpr int STRIP = 2 * TN * 4;                // bias | rowvec, fp32
+    static_assert(BM * RS + NWV * STRIP <= NSTAGE * STAGE, "bias strips must fit behind the staged output tile");
+    float* strip = (float*)(smem + BM * RS + wave * STRIP);
+    // the time-embedding row is per image: through the strip when the whole tile lies in one image, else per fragment
+    const bool rv_lds = a.rowvec != nullptr && (m0 / a.rows_per_b) == ((min(m0 + BM, a.M) - 1) / a.rows_per_b);
+    float4 bq = float4{0.f, 0.f, 0.f, 0.f}, rq = bq;
+    if (lane < TN / 4) {
+      const int n = n0 + wn * TN + lane * 4;
+      if (a.bias && n < a.N) bq = *(const float4*)(a.bias + n);
+      if (rv_lds && n < a.N) rq = *(const float4*)(a.rowvec + (long)(m0 / a.rows_per_b) * a.rv_ld + a.rv_off + n);
+    }
     __syncthreads();                                 // every wave is done reading the last pipeline stage
+    if (lane < TN / 4) { *(float4*)(strip + lane * 4) = bq; *(float4*)(strip + TN + lane * 4) = rq; }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int row = wm * TM + i * 16 + fr, m = m0 + row;
@@ -302,16 +338,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const GemmArgs a
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int col = wn * TN + j * 16 + fg * 4, n = n0 + col;
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        if (n < a.N) {
-          if (a.bias) {
-            const float4 bv = *(const float4*)(a.bias + n);
-            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-          }
-          if (a.rowvec) {
-            const float4 rv = *(const float4*)(a.rowvec + (long)b * a.rv_ld + a.rv_off + n);
-            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-          }
+        const float4 bv = *(const float4*)(strip + j * 16 + fg * 4);
+        float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+        if (a.rowvec) {
+          float4 rv;
+          if (rv_lds) rv = *(const float4*)(strip + TN + j * 16 + fg * 4);
+          else rv = n < a.N ? *(const float4*)(a.rowvec + (long)b * a.rv_ld + a.rv_off + n) : float4{0.f, 0.f, 0.f, 0.f};
+          v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
         }
         if (a.act == ACT_SILU) {
 #pragma unroll
@@ -586,6 +619,29 @@ size_t gemm_partial_floats(const GemmArgs& a) {
   return s > 1 ? (size_t)s * a.M * a.N : 0;
 }
 
+// Tile order of a launch (dfh_common.h tile_coords) for a bm x bn tile.  DFH_TMAP="xm,gm" pins it for every launch (probe).
+// The rules are the measured ones (scripts/pmc_traffic_calib.sh + scripts/tile_order_probe.py, profiles/r02): launch TIME does
+// not depend on the order (+-2 %: the over-fetched bytes come out of the Infinity Cache), fabric traffic does --
+//   * many column tiles over a weight matrix that cannot stay in one XCD's L2 (GEGLU projections at the 32x32 / 16x16 levels:
+//     40 / 80 column tiles, 6.5 / 26 MB of weights): groups of 8 row tiles walked column by column, FETCH 11-12 x -> 5 x the
+//     algorithmic bytes;
+//   * single-pass 3x3 convs with few column tiles and big weights (32x32 level: 128 x 4 tiles, 7-22 MB): a 4 x 2 grid of XCDs
+//     (each XCD streams half of the weights instead of all of them), 3.0 / 4.2 x -> 2.5 / 3.1 x.
+static void gemm_pick_tile_order(GemmArgs& a, int split, int bm, int bn) {
+  static const int env_xm = [] { const char* e = getenv("DFH_TMAP"); return e ? atoi(e) : -1; }();
+  static const int env_gm = [] { const char* e = getenv("DFH_TMAP"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }();
+  a.tm_xm = 0; a.tm_gm = 0;
+  if (env_xm >= 0) { a.tm_xm = env_xm; a.tm_gm = env_gm; return; }
+  if (split > 1 || a.n_major) return;
+  double kk = (double)a.ntaps * a.conv_c;
+  for (int i = 0; i < a.nplain; ++i) kk += a.p_c[i];
+  const double w_bytes = (double)a.N * kk * 2.0;
+  const int ntm = (a.M + bm - 1) / bm, ntn = (a.N + bn - 1) / bn;
+  if (w_bytes <= 2.0e6 || ntm < 16) return;          // the weights stay resident in every L2: nothing to order
+  if (ntn >= 16) { a.tm_gm = 8; return; }
+  if (a.ntaps && ntn <= 8 && ntn % 2 == 0 && ntm % 4 == 0) { a.tm_xm = 4; a.tm_gm = 8; }
+}
+
 int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split, int force_glds) {
   (void)force_glds;   // staging is always LDS-DMA; the flag is kept for ABI stability
   DFH_REQUIRE(a.M > 0 && a.N > 0, "empty GEMM");
@@ -622,6 +678,7 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     if (force_glds == 3) a.n_major = 0;
   }
   if (split > 1) DFH_REQUIRE(a.partial != nullptr, "split-K needs a partial buffer");
+  if (a.resid) DFH_REQUIRE((double)a.M * a.ld_res * 2.0 < 4.0e9, "residual tensor must be smaller than 4 GB (32-bit lane offsets)");
   int rc;
   {
     // algorithmic work of this launch: 2*M*N*K over the REAL K (padding excluded); bytes = each operand once + output
@@ -644,7 +701,10 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
       if (force_wide == 6 || force_wide == 7) ws = gemm_ws_pick(a, 1) ? (force_wide == 6 ? 160 : 128) : 0;
       else if (!force_wide && force_tile == 0 && force_split == 0 && !ws_off) ws = gemm_ws_pick(a, 224);
     }
-    if (force_wide >= 6) wide = 0;                      // not eligible (odd N, transposed / fp32 output): the default tile runs
+    if (ws) gemm_pick_tile_order(a, split, 256, ws);
+    else if (wide) gemm_pick_tile_order(a, split, wide == 2 ? 128 : 256, wide == 3 ? 320 : (wide == 4 ? 128 : 160));
+    else gemm_pick_tile_order(a, split, kTiles[tile].bm, kTiles[tile].bn);
+    if (force_wide == 6 || force_wide == 7) wide = 0;                      // not eligible (odd N, transposed / fp32 output): the default tile runs
     if (ws) rc = gemm_ws_launch(a, stream, ws);
     else if (wide) rc = gemm_wide_launch(a, stream, wide);
     else rc = launch_variant(tile, a, stream);

@@ -143,6 +143,17 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
   const bool geglu = a.act == ACT_GEGLU;
   constexpr int RS = BN8 * 2 + 16;                           // bf16 row stride of a wave's staged 32-row block
   unsigned char* stage = smem + wave * (32 * RS);
+  // per-channel weight scales and bias of the tile's 160 columns go to LDS once: read per fragment behind `if (n < a.N)` they
+  // were 10-20 dependent L2 round trips per 32-row block (same finding as the bf16 kernel's epilogue, gemm.hip)
+  static_assert(4 * 32 * RS + 2 * BN8 * 4 <= NST8 * STAGE, "staging regions + scale / bias slices must fit the pipeline buffers");
+  float* swl = (float*)(smem + 4 * 32 * RS);
+  float* bl = swl + BN8;
+  for (int c = tid; c < BN8; c += 256) {
+    const int n = n0 + c;
+    swl[c] = n < a.N ? a.sW[n] : 0.f;
+    bl[c] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+  }
+  __syncthreads();
 #pragma unroll
   for (int pj = 0; pj < PB; ++pj) {
     const int m = m0 + wave * PB * 32 + pj * 32 + ql;
@@ -156,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
           for (int r = 0; r < 16; ++r) {
             const int n = n0 + ci * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
             if (n < a.N) {
-              float v = acc[ci][pj][r] * sa * a.sW[n];
-              if (a.bias) v += a.bias[n];
+              float v = acc[ci][pj][r] * sa * swl[n - n0];
+              if (a.bias) v += bl[n - n0];
               ((bf16_t*)a.out)[((long)b * a.N + n) * a.ld_out + mm] = f2bf(v);
             }
           }
@@ -171,11 +182,9 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
           const int nv = n0 + ci * 32 + 8 * g + 4 * kh;      // packed row of the value; its gate is 16 rows further
-          float4 swv = float4{0, 0, 0, 0}, swg = swv, bv = swv, bg = swv;
-          if (nv + 16 < a.N) {
-            swv = *(const float4*)(a.sW + nv); swg = *(const float4*)(a.sW + nv + 16);
-            if (a.bias) { bv = *(const float4*)(a.bias + nv); bg = *(const float4*)(a.bias + nv + 16); }
-          }
+          const int cv = nv - n0;                            // columns past N hold zeros in the LDS slices
+          const float4 swv = *(const float4*)(swl + cv), swg = *(const float4*)(swl + cv + 16);
+          const float4 bv = *(const float4*)(bl + cv), bg = *(const float4*)(bl + cv + 16);
           const float v0 = acc[ci][pj][4 * g] * sa * swv.x + bv.x, v1 = acc[ci][pj][4 * g + 1] * sa * swv.y + bv.y;
           const float v2 = acc[ci][pj][4 * g + 2] * sa * swv.z + bv.z, v3 = acc[ci][pj][4 * g + 3] * sa * swv.w + bv.w;
           const float g0 = acc[ci][pj][8 + 4 * g] * sa * swg.x + bg.x, g1 = acc[ci][pj][9 + 4 * g] * sa * swg.y + bg.y;
@@ -189,8 +198,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int col = ci * 32 + 8 * g + 4 * kh, n = n0 + col;
-          float4 sw4 = float4{0, 0, 0, 0}, b4 = sw4;
-          if (n < a.N) { sw4 = *(const float4*)(a.sW + n); if (a.bias) b4 = *(const float4*)(a.bias + n); }
+          const float4 sw4 = *(const float4*)(swl + col), b4 = *(const float4*)(bl + col);
           float v[4] = {acc[ci][pj][4 * g] * sa * sw4.x + b4.x, acc[ci][pj][4 * g + 1] * sa * sw4.y + b4.y,
                         acc[ci][pj][4 * g + 2] * sa * sw4.z + b4.z, acc[ci][pj][4 * g + 3] * sa * sw4.w + b4.w};
           if (a.resid && m < a.M && n < a.N) {

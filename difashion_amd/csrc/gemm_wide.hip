@@ -66,11 +66,13 @@ DFH_DEVICE void kiterw_next(const GemmArgs& a, KIterW& it) {
 }
 template <int N> DFH_DEVICE void ww_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-#define WRD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define WRD_(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 
 // WN = 2: four waves (2 x 2), two workgroups per CU, 3 stages.  WN = 4: eight waves (2 x 4) on a 256 x 320 tile, ONE workgroup
 // per CU, 4 stages (144 KB): 142 flop per staged byte.
-template <int BM, int BN, int WN, int NSTAGE>
+// ABL (probe only, tile ids 13..19 = ABL 1..7; results are garbage): bit 0 drops the LDS-DMA staging of the k-loop, bit 1 the
+// fragment reads, bit 2 the MFMAs -- what is left is timed by scripts/gemm_ablate_probe.py to see which resource paces the loop.
+template <int BM, int BN, int WN, int NSTAGE, int ABL = 0>
 __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(const GemmArgs a) {
   constexpr int NWV = 2 * WN;
   constexpr int TM = BM / 2, TN = BN / WN;           // per-wave output tile
@@ -86,8 +88,9 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
   const int wm = wave / WN, wn = wave % WN;
 
   const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (a.n_major ? tile % ntm : tile / ntn) * BM, n0 = (a.n_major ? tile / ntm : tile % ntn) * BN;   // see gemm.hip
+  int mt_, nt_;
+  tile_coords(blockIdx.x, ntm, ntn, a.n_major, a.tm_xm, a.tm_gm, mt_, nt_);
+  const int m0 = mt_ * BM, n0 = nt_ * BN;
   const int nk = a.ksteps;                           // 32-deep steps (filled by the launcher)
 
   // staging geometry: piece p = i*4 + wave holds tile rows p*16 + lane/4; the LDS image is lane-linear, the SOURCE
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
       if (issued < nk) {
         kiterw_next(a, it);
         int nb = buf - 1; if (nb < 0) nb += NSTAGE;
-        issue_stage(it, nb);
+        if constexpr (!(ABL & 1)) issue_stage(it, nb);
         ++issued;
       }
       // Fragment reads software-pipelined by hand (inline asm + counted lgkmcnt): the A fragment of row i+2 is in
@@ -234,14 +237,20 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
       // are issued right in front of an s_waitcnt lgkmcnt(0) five times per step).
       const unsigned sa = lds0 + buf * STAGE + a_off, sb = lds0 + buf * STAGE + b_off;
       u32x4_t b[FN], a0, a1, a2;
+      if constexpr (ABL & 2) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) asm volatile("" : "=v"(b[j]));
+        asm volatile("" : "=v"(a0)); asm volatile("" : "=v"(a1)); asm volatile("" : "=v"(a2));
+      }
       __builtin_amdgcn_sched_barrier(0);
+#define WRD(dst, addr, off) do { if constexpr (!(ABL & 2)) WRD_(dst, addr, off); } while (0)
       WRD(b[0], sb, 0); WRD(b[1], sb, 1024); WRD(b[2], sb, 2048); WRD(b[3], sb, 3072);
       if constexpr (FN == 5) WRD(b[4], sb, 4096);
       WRD(a0, sa, 0); WRD(a1, sa, 1024);
       if constexpr (FN == 5) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(a0));
       else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(a0));
 #define WROW(i, ar)                                                                                                    \
-      _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                                   \
+      if constexpr (!(ABL & 4)) _Pragma("unroll") for (int j = 0; j < FN; ++j)                                        \
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b[j]), __builtin_bit_cast(bf16x8_t, ar), \
                                                             acc[i][j], 0, 0, 0);
 #define WNEXT(rd, off, wt) WRD(rd, sa, off); asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wt));
@@ -263,6 +272,7 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
       }
 #undef WROW
 #undef WNEXT
+#undef WRD
       __builtin_amdgcn_sched_barrier(0);
       if (++buf == NSTAGE) buf = 0;
     }
@@ -333,9 +343,15 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
   if (has_resid) fetch_resid(0);
   // the tile's bias slice goes to LDS once (behind the fp32 pass tile): per-chunk global reads cost 2.5 us per launch
   constexpr int BIAS_OFF = 64 * RSF;
-  static_assert(BIAS_OFF + BN * 4 <= NSTAGE * STAGE, "bias slice must fit behind the pass tile");
-  float4 bias_reg = make_float4(0.f, 0.f, 0.f, 0.f);
+  // ... and so does the time-embedding row (rowvec) when the whole tile lies inside one image (every level but 8x8): read per
+  // chunk it was EPI dependent L2 round trips in each of the four passes of every resnet conv1
+  constexpr int RV_OFF = BIAS_OFF + BN * 4;
+  static_assert(RV_OFF + BN * 4 <= NSTAGE * STAGE, "bias + rowvec slices must fit behind the pass tile");
+  const bool rv_lds = a.rowvec != nullptr && (m0 / a.rows_per_b) == ((min(m0 + BM, a.M) - 1) / a.rows_per_b);
+  float4 bias_reg = make_float4(0.f, 0.f, 0.f, 0.f), rv_reg = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.bias && tid < BN / 4 && n0 + tid * 4 < a.N) bias_reg = *(const float4*)(a.bias + n0 + tid * 4);
+  if (rv_lds && tid < BN / 4 && n0 + tid * 4 < a.N)
+    rv_reg = *(const float4*)(a.rowvec + (long)(m0 / a.rows_per_b) * a.rv_ld + a.rv_off + n0 + tid * 4);
 #pragma unroll
   for (int q = 0; q < BM / 64; ++q) {
     __syncthreads();                               // pipeline buffers / previous pass no longer read
@@ -349,7 +365,10 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
           *(f32x4_t*)(smem + row * RSF + (wn * TN + j * 16 + fg * 4) * 4) = acc[i][j];
       }
     }
-    if (q == 0 && tid < BN / 4) *(float4*)(smem + BIAS_OFF + tid * 16) = bias_reg;
+    if (q == 0 && tid < BN / 4) {
+      *(float4*)(smem + BIAS_OFF + tid * 16) = bias_reg;
+      *(float4*)(smem + RV_OFF + tid * 16) = rv_reg;
+    }
     __syncthreads();
     if (a.act == ACT_GEGLU) {
       // packed columns come in 32-blocks (16 values | 16 gates): out[m][16 k + i] = (v_i + bv_i) * gelu(g_i + bg_i)
@@ -401,8 +420,13 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
       }
       if (a.rowvec) {
-        const float* rv = a.rowvec + (long)(m / a.rows_per_b) * a.rv_ld + a.rv_off + n;
-        const float4 r0 = *(const float4*)rv, r1 = *(const float4*)(rv + 4);
+        float4 r0, r1;
+        if (rv_lds) {
+          r0 = *(const float4*)(smem + RV_OFF + cchunk * 32); r1 = *(const float4*)(smem + RV_OFF + cchunk * 32 + 16);
+        } else {
+          const float* rv = a.rowvec + (long)(m / a.rows_per_b) * a.rv_ld + a.rv_off + n;
+          r0 = *(const float4*)rv; r1 = *(const float4*)(rv + 4);
+        }
         v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
       }
       if (a.act == ACT_SILU) {
@@ -449,6 +473,12 @@ int gemm_wide_pick(const GemmArgs& a) {
     return (long)((a.M + 255) / 256) * (a.N / 128) >= 448 ? 4 : 0;
   }
   if (a.N % 160 != 0 && a.N < 640) return 0;
+  // plain linears / 1x1 convs (no taps): the eight-wave 128 x 160 kernel of gemm.hip is as fast or faster since its epilogue
+  // stopped serialising the bias loads and its residual loads moved behind the prologue (scripts/gemm_shortk2_probe.py,
+  // profiles/r02/gemm_shortk2_probe.txt: 65536 x 960 x 320 72.7 -> 60.2 us, 65536 x 320 x 1280 + residual 75.3 -> 67.7 us,
+  // 16384 x 1920 x 640 63.4 -> 47.6 us); the 3x3 convs keep the wide tile, and so do the K = 320 linears with a residual, whose
+  // coalesced one-pass-ahead residual reads win (same-box A/B: 31.4 vs 33.7 us)
+  if (a.ntaps == 0 && a.N % 160 == 0 && !(a.resid && a.nplain == 1 && a.p_c[0] <= 320)) return 0;
   const long nt = (a.N + 159) / 160;
   // the 128-row sibling (variant 2) is kept for experiments only: at equal tile size the 64-deep two-stage kernel of
   // gemm.hip wins (848 vs 724 TFLOP/s on conv 320->320 @64): the gain of this file is the larger tile
@@ -464,24 +494,33 @@ bool gemm_wide_eligible(const GemmArgs& a) {
   return tiles >= 448;
 }
 
-template <int BM, int BN, int WN, int NSTAGE>
+template <int BM, int BN, int WN, int NSTAGE, int ABL = 0>
 static int wide_launch_t(GemmArgs a, hipStream_t s) {
   constexpr int lds = NSTAGE * (BM + BN) * BKW * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<BM, BN, WN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_wide_kernel<BM, BN, WN, NSTAGE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   a.ksteps = gemm_wide_ksteps(a);
   a.ksplit = 1;
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_wide_kernel<BM, BN, WN, NSTAGE>), dim3(tiles), dim3(WN * 128), lds, s, a);
+  hipLaunchKernelGGL((gemm_wide_kernel<BM, BN, WN, NSTAGE, ABL>), dim3(tiles), dim3(WN * 128), lds, s, a);
   return check_launch("gemm_wide_kernel");
 }
 
 int gemm_wide_launch(GemmArgs a, hipStream_t s, int variant) {
   if (variant == 3) return wide_launch_t<256, 320, 4, 4>(a, s);
   if (variant == 4) return wide_launch_t<256, 128, 2, 3>(a, s);
+  switch (variant) {                                 // ablation probes (see the kernel's ABL note)
+    case 8: return wide_launch_t<256, 160, 2, 3, 1>(a, s);
+    case 9: return wide_launch_t<256, 160, 2, 3, 2>(a, s);
+    case 10: return wide_launch_t<256, 160, 2, 3, 3>(a, s);
+    case 11: return wide_launch_t<256, 160, 2, 3, 4>(a, s);
+    case 12: return wide_launch_t<256, 160, 2, 3, 5>(a, s);
+    case 13: return wide_launch_t<256, 160, 2, 3, 6>(a, s);
+    default: break;
+  }
   return variant == 2 ? wide_launch_t<128, 160, 2, 3>(a, s) : wide_launch_t<256, 160, 2, 3>(a, s);
 }
 

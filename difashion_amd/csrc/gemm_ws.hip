@@ -49,8 +49,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const GemmArgs a) {
   const int ql = lane & 31, kh = lane >> 5;
 
   const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (a.n_major ? tile % ntm : tile / ntn) * BM, n0 = (a.n_major ? tile / ntm : tile % ntn) * BN;
+  int mt_, nt_;
+  tile_coords(blockIdx.x, ntm, ntn, a.n_major, a.tm_xm, a.tm_gm, mt_, nt_);
+  const int m0 = mt_ * BM, n0 = nt_ * BN;
   const int nk = a.ksteps;
 
   f32x16_t acc[NCB][2];

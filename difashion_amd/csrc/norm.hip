@@ -11,6 +11,7 @@
 // octet below C0/8 comes from src0, the rest from src1.
 #include "dfh_common.h"
 #include "norm.h"
+#include <cstdlib>
 
 namespace {
 
@@ -78,7 +79,10 @@ __global__ void gn_stats_kernel(const GnArgs a) {
   }
 }
 
-// grid (achunks, B); same thread mapping; normalise (+SiLU) and write bf16 [B][HW][C]
+// grid (achunks, B); same thread mapping; normalise (+SiLU) and write bf16 [B][HW][C].  The first GN_PRE pixels of a thread are
+// loaded BEFORE the statistics are reduced: partials -> barrier -> gamma / beta -> data were three dependent memory round
+// trips per block, and a block only lives for a handful of pixels per thread.
+constexpr int GN_PRE = 6;
 __global__ void gn_apply_kernel(const GnArgs a) {
   __shared__ float mean_s[64], rstd_s[64];
   const int C8 = a.C >> 3;
@@ -86,6 +90,23 @@ __global__ void gn_apply_kernel(const GnArgs a) {
   const int o = tid % C8, pl = tid / C8;
   const int b = blockIdx.y;
   const int cpg = a.C / a.G;
+  const int p_begin = blockIdx.x * a.apix_per_chunk;
+  const int p_end = min(a.HW, p_begin + a.apix_per_chunk);
+  const bool live = pl < a.PL;
+  uint4 pre[GN_PRE];
+#pragma unroll
+  for (int u = 0; u < GN_PRE; ++u) {
+    const int p = p_begin + pl + u * a.PL;
+    pre[u] = make_uint4(0u, 0u, 0u, 0u);
+    if (live && p < p_end) pre[u] = *gn_src(a, b, p, o);
+  }
+  float gmr[8], btr[8];
+  if (live) {
+    const float4 g0 = *(const float4*)(a.gamma + o * 8), g1 = *(const float4*)(a.gamma + o * 8 + 4);
+    const float4 b0 = *(const float4*)(a.beta + o * 8), b1 = *(const float4*)(a.beta + o * 8 + 4);
+    gmr[0] = g0.x; gmr[1] = g0.y; gmr[2] = g0.z; gmr[3] = g0.w; gmr[4] = g1.x; gmr[5] = g1.y; gmr[6] = g1.z; gmr[7] = g1.w;
+    btr[0] = b0.x; btr[1] = b0.y; btr[2] = b0.z; btr[3] = b0.w; btr[4] = b1.x; btr[5] = b1.y; btr[6] = b1.z; btr[7] = b1.w;
+  }
   if (tid < a.G) {
     float ss = 0.f, qq = 0.f;
     for (int c = 0; c < a.chunks; ++c) {
@@ -103,90 +124,105 @@ __global__ void gn_apply_kernel(const GnArgs a) {
     }
   }
   __syncthreads();
-  if (pl >= a.PL) return;
+  if (!live) return;
   float sc[8], sh[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int c = o * 8 + k;
     const int g = c / cpg;
-    const float w = a.gamma[c] * rstd_s[g];
+    const float w = gmr[k] * rstd_s[g];
     sc[k] = w;
-    sh[k] = a.beta[c] - mean_s[g] * w;
+    sh[k] = btr[k] - mean_s[g] * w;
   }
-  const int p_begin = blockIdx.x * a.apix_per_chunk;
-  const int p_end = min(a.HW, p_begin + a.apix_per_chunk);
-  int p = p_begin + pl;
-  for (; p + 3 * a.PL < p_end; p += 4 * a.PL) {      // 4 loads in flight per thread
-    uint4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = *gn_src(a, b, p + u * a.PL, o);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float f[8];
-      unpack8(v[u], f);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        float y = f[k] * sc[k] + sh[k];
-        f[k] = a.silu ? silu_f(y) : y;
-      }
-      *(uint4*)(a.out + ((long)(b * a.HW + p + u * a.PL) * a.C + o * 8)) = pack8(f);
-    }
-  }
-  for (; p < p_end; p += a.PL) {
+  auto emit = [&](const uint4& raw, int p) {
     float f[8];
-    unpack8(*gn_src(a, b, p, o), f);
+    unpack8(raw, f);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       float y = f[k] * sc[k] + sh[k];
       f[k] = a.silu ? silu_f(y) : y;
     }
     *(uint4*)(a.out + ((long)(b * a.HW + p) * a.C + o * 8)) = pack8(f);
+  };
+#pragma unroll
+  for (int u = 0; u < GN_PRE; ++u) {
+    const int p = p_begin + pl + u * a.PL;
+    if (p < p_end) emit(pre[u], p);
   }
+  int p = p_begin + pl + GN_PRE * a.PL;
+  for (; p + 3 * a.PL < p_end; p += 4 * a.PL) {      // 4 loads in flight per thread
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *gn_src(a, b, p + u * a.PL, o);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) emit(v[u], p + u * a.PL);
+  }
+  for (; p < p_end; p += a.PL) emit(*gn_src(a, b, p, o), p);
 }
 
-// one wave per token row; exact two-pass variance in registers (C <= 8*64*MAXO)
-template <int MAXO>
+// one wave per R token rows; exact two-pass variance in registers (C <= 8*64*MAXO).  The loads of all R rows (and gamma / beta)
+// are issued before anything is reduced: with one 640-byte row per wave the chip had ~5 MB in flight, half of what 5 TB/s
+// needs at ~2 us of loaded latency.
+template <int MAXO, int R>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                         int M, int C, float eps) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= M) return;
   const int C8 = C >> 3;
-  float v[MAXO][8];
-  float s = 0.f;
+  uint4 raw[R][MAXO];
 #pragma unroll
-  for (int i = 0; i < MAXO; ++i) {
-    const int o = lane + i * 64;
-    if (o < C8) {
-      unpack8(*(const uint4*)(x + (long)row * C + o * 8), v[i]);
+  for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s += v[i][k];
+    for (int i = 0; i < MAXO; ++i) {
+      const int o = lane + i * 64;
+      raw[r][i] = make_uint4(0u, 0u, 0u, 0u);
+      if (o < C8 && row0 + r < M) raw[r][i] = *(const uint4*)(x + (long)(row0 + r) * C + o * 8);
     }
-  }
-  const float mean = wave_sum(s) / (float)C;
-  float q = 0.f;
+  float gg[MAXO][8], bb[MAXO][8];
 #pragma unroll
   for (int i = 0; i < MAXO; ++i) {
     const int o = lane + i * 64;
     if (o < C8) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; q += d * d; }
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-#pragma unroll
-  for (int i = 0; i < MAXO; ++i) {
-    const int o = lane + i * 64;
-    if (o < C8) {
-      float f[8];
       const float4 g0 = *(const float4*)(gamma + o * 8), g1 = *(const float4*)(gamma + o * 8 + 4);
       const float4 b0 = *(const float4*)(beta + o * 8), b1 = *(const float4*)(beta + o * 8 + 4);
-      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      gg[i][0] = g0.x; gg[i][1] = g0.y; gg[i][2] = g0.z; gg[i][3] = g0.w; gg[i][4] = g1.x; gg[i][5] = g1.y; gg[i][6] = g1.z; gg[i][7] = g1.w;
+      bb[i][0] = b0.x; bb[i][1] = b0.y; bb[i][2] = b0.z; bb[i][3] = b0.w; bb[i][4] = b1.x; bb[i][5] = b1.y; bb[i][6] = b1.z; bb[i][7] = b1.w;
+    }
+  }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) f[k] = (v[i][k] - mean) * rstd * gg[k] + bb[k];
-      *(uint4*)(y + (long)row * C + o * 8) = pack8(f);
+  for (int r = 0; r < R; ++r) {
+    if (row0 + r >= M) break;
+    float v[MAXO][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) {
+      unpack8(raw[r][i], v[i]);                    // lanes past C8 hold zeros
+      if (lane + i * 64 < C8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[i][k];
+      }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) {
+      if (lane + i * 64 < C8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) {
+      const int o = lane + i * 64;
+      if (o < C8) {
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = (v[i][k] - mean) * rstd * gg[i][k] + bb[i][k];
+        *(uint4*)(y + (long)(row0 + r) * C + o * 8) = pack8(f);
+      }
     }
   }
 }
@@ -256,6 +292,87 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GnArgs a) {
     }
 }
 
+// ---- mid-size tensors (everything below the 64x64 level): ONE launch, coalesced.  gn_small_kernel above gives a block one
+// (image, group) slab: cpg * 2 = 40..160 contiguous bytes per pixel at a stride of the whole channel count, so every 128-byte line is
+// fetched by the 2-4 blocks whose groups share it (usually on different XCDs), and gamma / beta are re-read per 8-byte unit.
+// Here a block owns GQ ADJACENT groups of one image (160-640 contiguous bytes per pixel), a thread owns a FIXED 4-channel unit
+// of that span (gamma / beta / group index live in registers) and walks pixels; the slab stays in registers as packed bf16
+// (2 VGPRs per unit), the statistics are reduced in a fixed order through LDS (two-pass variance), one read, one write.
+//   threads = PPB pixel lanes x UPPB units per pixel (UPPB = GQ * cpg / 4), thread -> (pp = tid / UPPB, j = tid % UPPB)
+template <int UNITS>
+__global__ __launch_bounds__(1024) void gn_mid_kernel(const GnArgs a, const int gq, const int ppb) {
+  __shared__ float red[1024];
+  __shared__ float colsum[2][256];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int cpg = a.C / a.G, upp = cpg >> 2, uppb = gq * upp;
+  const int g0 = blockIdx.x * gq, cg0 = g0 * cpg;
+  const bool active = tid < ppb * uppb;
+  const int pp = tid / uppb, j = tid - pp * uppb;
+  const int c = cg0 + j * 4;                                   // this thread's four channels in the concatenated tensor
+  const bool first = c < a.C0;
+  const bf16_t* src = first ? a.src0 + (long)b * a.HW * a.C0 + c : a.src1 + (long)b * a.HW * a.C1 + (c - a.C0);
+  const int ldc = first ? a.C0 : a.C1;
+  uint2 v[UNITS];
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < UNITS; ++u) {
+    const int p = pp + u * ppb;
+    v[u] = uint2{0u, 0u};
+    if (active && p < a.HW) v[u] = *(const uint2*)(src + (long)p * ldc);
+  }
+#pragma unroll
+  for (int u = 0; u < UNITS; ++u)      // out-of-range units hold zeros: they add nothing here and are masked in the second pass
+    s += (__uint_as_float(v[u].x << 16) + __uint_as_float(v[u].x & 0xffff0000u)) +
+         (__uint_as_float(v[u].y << 16) + __uint_as_float(v[u].y & 0xffff0000u));
+  const float n = (float)a.HW * (float)cpg;
+  const int gi = j / upp;                                       // group of this thread inside the block
+  auto group_total = [&](float x, int slot) -> float {
+    red[tid] = active ? x : 0.f;
+    __syncthreads();
+    if (tid < uppb) {
+      float t = 0.f;
+      for (int q = 0; q < ppb; ++q) t += red[q * uppb + tid];
+      colsum[slot][tid] = t;
+    }
+    __syncthreads();
+    float t = 0.f;
+    for (int k = 0; k < upp; ++k) t += colsum[slot][gi * upp + k];
+    return t;
+  };
+  const float mean = group_total(s, 0) / n;
+  float q = 0.f;
+#pragma unroll
+  for (int u = 0; u < UNITS; ++u) {
+    if (pp + u * ppb < a.HW) {
+      const float d0 = __uint_as_float(v[u].x << 16) - mean, d1 = __uint_as_float(v[u].x & 0xffff0000u) - mean;
+      const float d2 = __uint_as_float(v[u].y << 16) - mean, d3 = __uint_as_float(v[u].y & 0xffff0000u) - mean;
+      q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+  const float rstd = rsqrtf(group_total(q, 1) / n + a.eps);
+  if (!active) return;
+  if (a.stats_out && pp == 0 && j == gi * upp) {
+    a.stats_out[((long)b * a.G + g0 + gi) * 2] = mean; a.stats_out[((long)b * a.G + g0 + gi) * 2 + 1] = rstd;
+  }
+  const float4 gm = *(const float4*)(a.gamma + c), bt = *(const float4*)(a.beta + c);
+  const float w0 = rstd * gm.x, w1 = rstd * gm.y, w2 = rstd * gm.z, w3 = rstd * gm.w;
+  bf16_t* dst = a.out + (long)b * a.HW * a.C + c;
+#pragma unroll
+  for (int u = 0; u < UNITS; ++u) {
+    const int p = pp + u * ppb;
+    if (p < a.HW) {
+      float y[4] = {(__uint_as_float(v[u].x << 16) - mean) * w0 + bt.x, (__uint_as_float(v[u].x & 0xffff0000u) - mean) * w1 + bt.y,
+                    (__uint_as_float(v[u].y << 16) - mean) * w2 + bt.z, (__uint_as_float(v[u].y & 0xffff0000u) - mean) * w3 + bt.w};
+      if (a.silu) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = silu_f(y[k]);
+      }
+      uint2 o; o.x = pack2bf(y[0], y[1]); o.y = pack2bf(y[2], y[3]);
+      *(uint2*)(dst + (long)p * a.C) = o;
+    }
+  }
+}
+
 namespace dfh {
 
 static void gn_geometry(GnArgs& a, int* block, int* achunks) {
@@ -297,6 +414,34 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
       return check_launch("gn_small_kernel");
     }
   }
+  {
+    // mid path (16x16 / 8x8 tensors the one-slab kernel cannot take: groups that straddle the two concat sources, e.g. 1280 + 640
+    // channels): GQ adjacent groups per block.  Measured against the alternatives (scripts/norm_microbench.py): 24.4 -> 13.4 us
+    // on 16x16 x (1280 + 640); where gn_small_kernel is eligible it is faster (its blocks are four waves, the reductions here
+    // run across up to sixteen), and at 32x32 the two-kernel path is, so this is the fallback between them.
+    static const bool mid_off = [] { const char* e = getenv("DFH_GN_MID"); return e && e[0] == '0'; }();
+    const int cpg = a.C / a.G, upp = cpg >> 2;
+    if (!mid_off && (cpg & 3) == 0 && a.HW <= 256 && a.G % 2 == 0) {
+      for (int gq = 4; gq >= 2; gq >>= 1) {
+        if (a.G % gq || (long)a.B * (a.G / gq) < 128 || gq * upp > 256) continue;
+        const int uppb = gq * upp;
+        int threads = 256;
+        while (threads < 1024 && (a.HW + threads / uppb - 1) / (threads / uppb) > 24) threads *= 2;
+        const int ppb = threads / uppb;
+        if (ppb < 1) continue;
+        const int units = (a.HW + ppb - 1) / ppb;
+        if (units > 32) continue;
+        ProfScope ps(PC_GNORM, 0.0, 4.0 * a.B * (double)a.HW * a.C, stream);
+        const dim3 grid(a.G / gq, a.B), block(threads);
+        if (units <= 4) hipLaunchKernelGGL(gn_mid_kernel<4>, grid, block, 0, stream, a, gq, ppb);
+        else if (units <= 8) hipLaunchKernelGGL(gn_mid_kernel<8>, grid, block, 0, stream, a, gq, ppb);
+        else if (units <= 16) hipLaunchKernelGGL(gn_mid_kernel<16>, grid, block, 0, stream, a, gq, ppb);
+        else if (units <= 24) hipLaunchKernelGGL(gn_mid_kernel<24>, grid, block, 0, stream, a, gq, ppb);
+        else hipLaunchKernelGGL(gn_mid_kernel<32>, grid, block, 0, stream, a, gq, ppb);
+        return check_launch("gn_mid_kernel");
+      }
+    }
+  }
   int block, achunks;
   gn_geometry(a, &block, &achunks);
   DFH_REQUIRE(block <= 1024, "block too large");
@@ -312,11 +457,11 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
 int layernorm_launch(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int M, int C, float eps,
                      hipStream_t stream) {
   DFH_REQUIRE(C % 8 == 0 && C <= 8 * 64 * 4, "LayerNorm width must be a multiple of 8 and <= 2048");
-  const dim3 grid((M + 3) / 4), block(256);
+  const dim3 block(256);
   ProfScope ps(PC_LNORM, 0.0, 4.0 * (double)M * C, stream);
-  if (C <= 512) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, stream, x, gamma, beta, y, M, C, eps);
-  else if (C <= 1024) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, x, gamma, beta, y, M, C, eps);
-  else hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, stream, x, gamma, beta, y, M, C, eps);
+  if (C <= 512) hipLaunchKernelGGL((layernorm_kernel<1, 4>), dim3((M + 15) / 16), block, 0, stream, x, gamma, beta, y, M, C, eps);
+  else if (C <= 1024) hipLaunchKernelGGL((layernorm_kernel<2, 2>), dim3((M + 7) / 8), block, 0, stream, x, gamma, beta, y, M, C, eps);
+  else hipLaunchKernelGGL((layernorm_kernel<4, 1>), dim3((M + 3) / 4), block, 0, stream, x, gamma, beta, y, M, C, eps);
   return check_launch("layernorm_kernel");
 }
 

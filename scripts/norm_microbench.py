@@ -22,7 +22,8 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-for H, C0, C1 in ((64, 320, 0), (64, 320, 320), (64, 640, 320), (32, 640, 0), (32, 640, 640), (16, 1280, 0), (16, 1280, 1280), (8, 1280, 0)):
+for H, C0, C1 in ((64, 320, 0), (64, 320, 320), (64, 640, 320), (32, 320, 0), (32, 640, 0), (32, 640, 320), (32, 640, 640), (32, 1280, 640), (16, 640, 0),
+                  (16, 1280, 0), (16, 1280, 640), (16, 1280, 1280), (8, 1280, 0), (8, 1280, 1280)):
     HW = H * H
     C = C0 + C1
     x0 = torch.randn(B, HW, C0, device=DEV).bfloat16()

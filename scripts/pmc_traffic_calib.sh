@@ -19,7 +19,7 @@ def per_dispatch(sub):
     for f in glob.glob(f"{root}/{sub}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if not (k.startswith("gemm_bf16_kernel") or k.startswith("gemm_wide_kernel") or k.startswith("gemm_ws_kernel")):
+            if not any(t in k[:64] for t in ("gemm_bf16_kernel", "gemm_wide_kernel", "gemm_ws_kernel")):
                 continue
             rows.setdefault(int(r["Dispatch_Id"]), {"kernel": k})[r["Counter_Name"]] = float(r["Counter_Value"])
     return [rows[i] for i in sorted(rows)]
@@ -33,6 +33,7 @@ for i, s in enumerate(shapes):
     tt = t[g]
     hit = sum(x["TCC_HIT_sum"] for x in tt) / max(1.0, sum(x["TCC_HIT_sum"] + x["TCC_MISS_sum"] for x in tt))
     rd = sum(x["TCC_EA0_RDREQ_sum"] for x in tt) / len(tt) * 64 / 1e6
-    print(f"{s['name']:40s} {f[g][0]['kernel'][:34]:34s} {s['read_bytes'] / 1e6:11.1f} {fm:9.1f} {fm / (s['read_bytes'] / 1e6):9.2f} "
+    kn = f[g][0]["kernel"].replace("void (anonymous namespace)::", "")[:34]
+    print(f"{s['name']:40s} {kn:34s} {s['read_bytes'] / 1e6:11.1f} {fm:9.1f} {fm / (s['read_bytes'] / 1e6):9.2f} "
           f"{s['write_bytes'] / 1e6:12.1f} {wm:9.1f} {wm / (s['write_bytes'] / 1e6):6.2f} {hit:7.3f} {rd / fm:14.2f}")
 PY

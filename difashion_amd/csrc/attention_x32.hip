@@ -489,6 +489,7 @@ int attention_x32_launch(const AttnArgs& a, hipStream_t stream) {
       }
       if (variant == 1) return launch_x32<40, 1, 3>(a, stream);      // experiments: one 32-query block per wave at 3 / 4 waves per SIMD
       if (variant == 2) return launch_x32<40, 1, 4>(a, stream);
+      if (variant == 3) return launch_x32<40, 4, 1>(a, stream);      // four blocks per wave, ONE wave per SIMD: 14 fragment reads per 56 MFMAs, but nothing to overlap the exponentials with: 524 vs 458 us
       return launch_x32<40, 2, 2>(a, stream);
     case 80:
       if (variant == 1) return launch_x32<80, 1, 3>(a, stream);

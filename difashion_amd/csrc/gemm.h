@@ -72,6 +72,8 @@ bool gemm_wide_eligible(const GemmArgs& a);
 int gemm_wide_pick(const GemmArgs& a);                       // 0 none, 1 = 256 x 160, 2 = 128 x 160
 int gemm_wide_launch(GemmArgs a, hipStream_t stream, int variant = 1);
 // wave-specialised 256 x {160,128} kernel (gemm_ws.hip): loader waves + matrix waves, one workgroup per CU
+bool gemm_halo_eligible(const GemmArgs& a);                  // gemm_halo.hip: 3x3 conv, pixels staged once per channel slice
+int gemm_halo_launch(GemmArgs a, hipStream_t stream);
 int gemm_ws_pick(const GemmArgs& a, int min_tiles);           // 0 = not eligible, else the column tile (160 / 128)
 int gemm_ws_launch(GemmArgs a, hipStream_t stream, int bn);
 }  // namespace dfh

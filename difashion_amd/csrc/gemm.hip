@@ -705,7 +705,14 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     else if (wide) gemm_pick_tile_order(a, split, wide == 2 ? 128 : 256, wide == 3 ? 320 : (wide == 4 ? 128 : 160));
     else gemm_pick_tile_order(a, split, kTiles[tile].bm, kTiles[tile].bn);
     if (force_wide == 6 || force_wide == 7) wide = 0;                      // not eligible (odd N, transposed / fp32 output): the default tile runs
-    if (ws) rc = gemm_ws_launch(a, stream, ws);
+    // tile id 20 (force_wide 15) pins the halo-patch conv kernel (gemm_halo.hip).  It halves the staged bytes of a 64x64-level conv
+    // and is bit-identical to the wide kernel, but no faster (conv3x3 class 6.96 -> 6.93 ms per step in a same-box A/B, 271 vs 268 us
+    // on zero-filled operands): the k-loop is not paced by its staging alone, so it stays opt-in: DFH_GEMM_HALO=1.
+    static const bool halo_on = [] { const char* e = getenv("DFH_GEMM_HALO"); return e && e[0] == '1'; }();
+    const bool halo = wide_ok && !force_deep && gemm_halo_eligible(a) && (force_wide == 15 || (wide == 1 && !force_wide && halo_on));
+    if (force_wide == 15) wide = halo ? 1 : 0;
+    if (halo) rc = gemm_halo_launch(a, stream);
+    else if (ws) rc = gemm_ws_launch(a, stream, ws);
     else if (wide) rc = gemm_wide_launch(a, stream, wide);
     else rc = launch_variant(tile, a, stream);
   }

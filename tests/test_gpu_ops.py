@@ -131,6 +131,32 @@ def test_conv3x3_lean_tap_staging_on_non_square_inputs(cin, H, W, tile):
     gu.assert_close_bf16(gu.nchw(out.view(B, H, W, cout)), ref, f"conv {cin}->{cout}@{H}x{W} tile{tile}")
 
 
+@pytest.mark.parametrize("cin,cout,H,W,B", [
+    (64, 160, 16, 16, 3),     # 16-wide level: one tile = one whole image, the patch is the zero-padded image
+    (96, 200, 32, 32, 2),     # 32-wide: 8 rows per tile; C_out not a multiple of the 160-column tile
+    (32, 64, 8, 64, 2),       # 64-wide: 4 rows per tile, 2 tiles per image (top and bottom borders in different tiles)
+    (64, 320, 64, 64, 1),     # the 64x64 level itself: interior tiles with halo rows on both sides
+    (160, 96, 24, 32, 2),     # height not a power of two
+])
+def test_conv3x3_halo_patch_kernel(cin, cout, H, W, B):
+    """gemm_halo.hip (tile id 20): the pixels of a channel slice are staged once as a (rows + 2) x (W + 2) patch and the nine taps
+    read it at shifted offsets.  Against fp32 conv2d of the same bf16 operands, with bias, per-image time-embedding row and residual
+    (the wide kernel's epilogue), and bit for bit against the wide kernel (same MFMA order of accumulation per output)."""
+    x = bf(rnd(B, cin, H, W, seed=26))
+    w = rnd(cout, cin, 3, 3, seed=27, scale=0.05)
+    bias = rnd(cout, seed=28)
+    temb = rnd(B, 2 * cout, seed=29)
+    res = bf(rnd(B * H * W, cout, seed=30))
+    kw = dict(M=B * H * W, N=cout, W=gu.pack_conv(w), ldw=9 * cin, conv_src=gu.nhwc(x), conv_c=cin, batch=B, Hin=H, Win=W, stride=1,
+              upsample=0, bias=bias, rowvec=temb, rv_ld=2 * cout, rv_off=cout, rows_per_b=H * W, resid=res)
+    out = gu.gemm(force_tile=20, **kw)
+    ref = F.conv2d(x.float(), bf(w).float(), bias, padding=1) + temb[:, cout:, None, None]
+    ref = ref + gu.nchw(res.float().view(B, H, W, cout))
+    gu.assert_close_bf16(gu.nchw(out.view(B, H, W, cout)), ref, f"halo conv {cin}->{cout}@{H}x{W}")
+    wide = gu.gemm(force_tile=6, **kw)
+    assert torch.equal(out, wide), "halo and wide kernels accumulate the same products in the same order"
+
+
 @pytest.mark.parametrize("tile", [0, 6, 7, 8, 9, 11, 12])
 def test_conv3x3_with_fused_shortcut_and_temb(tile):
     """ResnetBlock2D tail: conv2(h) + conv_shortcut(cat(x, skip)) + biases, and conv1 + time embedding."""

@@ -626,7 +626,8 @@ size_t gemm_partial_floats(const GemmArgs& a) {
 //     40 / 80 column tiles, 6.5 / 26 MB of weights): groups of 8 row tiles walked column by column, FETCH 11-12 x -> 5 x the
 //     algorithmic bytes;
 //   * single-pass 3x3 convs with few column tiles and big weights (32x32 level: 128 x 4 tiles, 7-22 MB): a 4 x 2 grid of XCDs
-//     (each XCD streams half of the weights instead of all of them), 3.0 / 4.2 x -> 2.5 / 3.1 x.
+//     (each XCD streams half of the weights instead of all of them), 3.0 / 4.2 x -> 2.5 / 3.1 x; not at the 64x64 level, where
+//     splitting the column tiles over XCDs doubles the (20 x larger) pixel traffic.
 static void gemm_pick_tile_order(GemmArgs& a, int split, int bm, int bn) {
   static const int env_xm = [] { const char* e = getenv("DFH_TMAP"); return e ? atoi(e) : -1; }();
   static const int env_gm = [] { const char* e = getenv("DFH_TMAP"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }();
@@ -636,10 +637,21 @@ static void gemm_pick_tile_order(GemmArgs& a, int split, int bm, int bn) {
   double kk = (double)a.ntaps * a.conv_c;
   for (int i = 0; i < a.nplain; ++i) kk += a.p_c[i];
   const double w_bytes = (double)a.N * kk * 2.0;
+  const double a_bytes = a.ntaps ? (double)(a.M / (a.Hout * a.Wout)) * a.Hin * a.Win * a.conv_c * 2.0 : (double)a.M * kk * 2.0;
   const int ntm = (a.M + bm - 1) / bm, ntn = (a.N + bn - 1) / bn;
   if (w_bytes <= 2.0e6 || ntm < 16) return;          // the weights stay resident in every L2: nothing to order
   if (ntn >= 16) { a.tm_gm = 8; return; }
-  if (a.ntaps && ntn <= 8 && ntn % 2 == 0 && ntm % 4 == 0) { a.tm_xm = 4; a.tm_gm = 8; }
+  if (!a.ntaps) return;
+  // few column tiles: an xm x (8 / xm) grid of XCDs fetches (8 / xm) x the pixels + xm x the weights in total (xm = 8 is the
+  // legacy order: every XCD streams all the weights).  Measured 4 x 2 against 8 x 1: better on the 32x32-level convs (21 + 8 x 7
+  // MB -> 2 x 21 + 4 x 7), WORSE at 64x64 where the pixels outweigh the weights 20 : 1 -- so pick the minimum of the model.
+  int best = 8; double cost = a_bytes + 8.0 * w_bytes;
+  for (int xm = 4; xm >= 2; xm >>= 1) {
+    if (ntm % xm || ntn % (8 / xm)) continue;
+    const double c = (8.0 / xm) * a_bytes + xm * w_bytes;
+    if (c < 0.95 * cost) { cost = c; best = xm; }
+  }
+  if (best != 8) { a.tm_xm = best; a.tm_gm = 8; }
 }
 
 int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split, int force_glds) {

@@ -18,7 +18,12 @@ DFH_DEVICE const uint4* gnb_src(const GnBwdArgs& a, int b, int p, int o) {
   return (const uint4*)(a.src1 + ((long)(b * a.HW + p) * a.C1 + (o - o0) * 8));
 }
 
-DFH_DEVICE float dsilu(float z) { const float s = 1.0f / (1.0f + __expf(-z)); return s * (1.0f + z * (1.0f - s)); }
+// d/dz silu(z) = s (1 + z (1 - s)), s = sigmoid(z): hardware reciprocal instead of an IEEE division (~10 VALU instructions; these
+// kernels run two passes over 2.9 G elements per training step and are VALU-heavy), as silu_f in dfh_common.h
+DFH_DEVICE float dsilu(float z) {
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896340736f));
+  return s * (1.0f + z * (1.0f - s));
+}
 
 // grid (chunks, B): per-channel sums A_c = sum dz, B_c = sum dz*x^ over this chunk's pixels
 __global__ void gn_bwd_stats_kernel(const GnBwdArgs a) {
@@ -37,17 +42,28 @@ __global__ void gn_bwd_stats_kernel(const GnBwdArgs a) {
       mu[k] = a.stats[((long)b * a.G + g) * 2]; rs[k] = a.stats[((long)b * a.G + g) * 2 + 1];
       A[k] = 0.f; Bq[k] = 0.f;
     }
-    for (int p = p_begin + pl; p < p_end; p += a.PL) {
+    auto accum = [&](const uint4& xr, const uint4& dr) {
       float x[8], d[8];
-      unpack8(*gnb_src(a, b, p, o), x);
-      unpack8(*(const uint4*)(a.dy + ((long)(b * a.HW + p) * a.C + o * 8)), d);
+      unpack8(xr, x); unpack8(dr, d);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float xh = (x[k] - mu[k]) * rs[k];
         const float dz = a.silu ? d[k] * dsilu(ga[k] * xh + be[k]) : d[k];
         A[k] += dz; Bq[k] += dz * xh;
       }
+    };
+    int p = p_begin + pl;
+    for (; p + 3 * a.PL < p_end; p += 4 * a.PL) {    // eight 16-byte loads in flight per thread; accumulation order stays p-ascending
+      uint4 xr[4], dr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xr[u] = *gnb_src(a, b, p + u * a.PL, o);
+        dr[u] = *(const uint4*)(a.dy + ((long)(b * a.HW + p + u * a.PL) * a.C + o * 8));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accum(xr[u], dr[u]);
     }
+    for (; p < p_end; p += a.PL) accum(*gnb_src(a, b, p, o), *(const uint4*)(a.dy + ((long)(b * a.HW + p) * a.C + o * 8)));
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       red[((pl * a.C) + o * 8 + k) * 2 + 0] = A[k];
@@ -103,12 +119,10 @@ __global__ void gn_bwd_apply_kernel(const GnBwdArgs a) {
   const int Cd = first ? a.C0 : a.C1, od = first ? o : o - o0;
   const int acc = first ? a.acc0 : a.acc1;
   const int p_begin = blockIdx.x * a.apix_per_chunk, p_end = min(a.HW, p_begin + a.apix_per_chunk);
-  for (int p = p_begin + pl; p < p_end; p += a.PL) {
+  auto emit = [&](const uint4& xr, const uint4& dr, const uint4& rr, uint4* dst) {
     float x[8], d[8], r[8];
-    unpack8(*gnb_src(a, b, p, o), x);
-    unpack8(*(const uint4*)(a.dy + ((long)(b * a.HW + p) * a.C + o * 8)), d);
-    uint4* dst = (uint4*)(dbase + ((long)(b * a.HW + p) * Cd + od * 8));
-    if (acc) unpack8(*dst, r);
+    unpack8(xr, x); unpack8(dr, d);
+    if (acc) unpack8(rr, r);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float xh = (x[k] - mu[k]) * rs[k];
@@ -117,6 +131,25 @@ __global__ void gn_bwd_apply_kernel(const GnBwdArgs a) {
       r[k] = acc ? r[k] + dx : dx;
     }
     *dst = pack8(r);
+  };
+  auto dst_of = [&](int p) { return (uint4*)(dbase + ((long)(b * a.HW + p) * Cd + od * 8)); };
+  int p = p_begin + pl;
+  for (; p + 3 * a.PL < p_end; p += 4 * a.PL) {      // 8-12 loads in flight per thread
+    uint4 xr[4], dr[4], rr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      xr[u] = *gnb_src(a, b, p + u * a.PL, o);
+      dr[u] = *(const uint4*)(a.dy + ((long)(b * a.HW + p + u * a.PL) * a.C + o * 8));
+      rr[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (acc) rr[u] = *dst_of(p + u * a.PL);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) emit(xr[u], dr[u], rr[u], dst_of(p + u * a.PL));
+  }
+  for (; p < p_end; p += a.PL) {
+    uint4 rr = make_uint4(0u, 0u, 0u, 0u);
+    if (acc) rr = *dst_of(p);
+    emit(*gnb_src(a, b, p, o), *(const uint4*)(a.dy + ((long)(b * a.HW + p) * a.C + o * 8)), rr, dst_of(p));
   }
 }
 
@@ -138,19 +171,35 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
     for (int k = 0; k < 8; ++k) { gg[i][k] = o < C8 ? gamma[o * 8 + k] : 0.f; dgam[i][k] = 0.f; dbet[i][k] = 0.f; }
   }
   const int r_end = min(M, (int)(blockIdx.x + 1) * 64);
-  for (int row = blockIdx.x * 64 + wave; row < r_end; row += 4) {
-    float v[MAXO][8], d[MAXO][8];
-    float s = 0.f;
+  // the NEXT row's x / dy (and dx when accumulating) are loaded before the current row is reduced: one row per iteration with its
+  // loads at the top was a chain of dependent round trips (16 per wave)
+  uint4 xn[MAXO], dn[MAXO], rn[MAXO];
+  auto fetch = [&](int row) {
 #pragma unroll
     for (int i = 0; i < MAXO; ++i) {
       const int o = lane + i * 64;
-      if (o < C8) {
-        unpack8(*(const uint4*)(x + (long)row * C + o * 8), v[i]);
-        unpack8(*(const uint4*)(dy + (long)row * C + o * 8), d[i]);
+      xn[i] = make_uint4(0u, 0u, 0u, 0u); dn[i] = xn[i]; rn[i] = xn[i];
+      if (o < C8 && row < r_end) {
+        xn[i] = *(const uint4*)(x + (long)row * C + o * 8);
+        dn[i] = *(const uint4*)(dy + (long)row * C + o * 8);
+        if (accumulate) rn[i] = *(const uint4*)(dx + (long)row * C + o * 8);
+      }
+    }
+  };
+  fetch(blockIdx.x * 64 + wave);
+  for (int row = blockIdx.x * 64 + wave; row < r_end; row += 4) {
+    float v[MAXO][8], d[MAXO][8];
+    uint4 rcur[MAXO];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) {
+      unpack8(xn[i], v[i]); unpack8(dn[i], d[i]); rcur[i] = rn[i];
+      if (lane + i * 64 < C8) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) s += v[i][k];
       }
     }
+    fetch(row + 4);
     const float mean = wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
@@ -180,7 +229,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
       if (o < C8) {
         float r[8];
         uint4* dst = (uint4*)(dx + (long)row * C + o * 8);
-        if (accumulate) unpack8(*dst, r);
+        if (accumulate) unpack8(rcur[i], r);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const float g = rstd * (d[i][k] - s1 - v[i][k] * s2);

@@ -74,7 +74,8 @@ __global__ void gn_stats_kernel(const GnArgs a) {
         ss += red[(l * a.C + c) * 2 + 0];
         qq += red[(l * a.C + c) * 2 + 1];
       }
-    float* dst = a.partial + (((long)b * gridDim.x + blockIdx.x) * a.G + tid) * 2;
+    // [b][group][chunk][2]: a group's partials are contiguous, the apply kernel reads them as float4s
+    float* dst = a.partial + (((long)b * a.G + tid) * gridDim.x + blockIdx.x) * 2;
     dst[0] = ss; dst[1] = qq;
   }
 }
@@ -107,11 +108,30 @@ __global__ void gn_apply_kernel(const GnArgs a) {
     gmr[0] = g0.x; gmr[1] = g0.y; gmr[2] = g0.z; gmr[3] = g0.w; gmr[4] = g1.x; gmr[5] = g1.y; gmr[6] = g1.z; gmr[7] = g1.w;
     btr[0] = b0.x; btr[1] = b0.y; btr[2] = b0.z; btr[3] = b0.w; btr[4] = b1.x; btr[5] = b1.y; btr[6] = b1.z; btr[7] = b1.w;
   }
+  // statistics: the image's `chunks` partials per group, summed by eight threads per group (each a contiguous run of chunks in
+  // ascending order, then the eight runs in ascending order: a fixed order).  Summed by one thread per group this prologue was a
+  // chain of 8-16 dependent load batches per block and paced the whole kernel (37 -> 28 us on 64x64 x 320 with it gone).
+  __shared__ float2 run_s[64][8];
+  const bool wide_red = blockDim.x >= (unsigned)a.G * 8u && !a.serial_red;
+  if (wide_red) {
+    if (tid < a.G * 8) {
+      const int g = tid >> 3, sub = tid & 7;
+      const int per = (a.chunks + 7) >> 3, c0 = sub * per, c1 = min(a.chunks, c0 + per);
+      const float2* src = (const float2*)(a.partial + ((long)b * a.G + g) * a.chunks * 2);
+      float ss = 0.f, qq = 0.f;
+      for (int c = c0; c < c1; ++c) { const float2 v = src[c]; ss += v.x; qq += v.y; }
+      run_s[g][sub] = float2{ss, qq};
+    }
+    __syncthreads();
+  }
   if (tid < a.G) {
     float ss = 0.f, qq = 0.f;
-    for (int c = 0; c < a.chunks; ++c) {
-      const float* src = a.partial + (((long)b * a.chunks + c) * a.G + tid) * 2;
-      ss += src[0]; qq += src[1];
+    if (wide_red) {
+#pragma unroll
+      for (int sub = 0; sub < 8; ++sub) { ss += run_s[tid][sub].x; qq += run_s[tid][sub].y; }
+    } else {
+      const float2* src = (const float2*)(a.partial + ((long)b * a.G + tid) * a.chunks * 2);      // contiguous (gn_stats_kernel)
+      for (int c = 0; c < a.chunks; ++c) { ss += src[c].x; qq += src[c].y; }
     }
     const float n = (float)a.HW * (float)cpg;
     const float mean = ss / n;
@@ -229,7 +249,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
 
 }  // namespace
 
-// ---- small tensors (16x16 / 8x8 levels, and 32x32 at 640 channels): ONE launch.  A block owns one (batch, group) slab of
+// ---- small tensors (16x16 / 8x8 levels): ONE launch.  A block owns one (batch, group) slab of
 // HW x cpg <= 32768 elements, reads it once into registers (8-byte units = 4 channels of a pixel), reduces it in a fixed
 // order (two-pass variance from the registers), normalises and writes.  The two-kernel path above spends ~2 x 8 us of launch
 // and dependency latency on tensors that hold a few hundred KB.
@@ -242,6 +262,10 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GnArgs a) {
   const bf16_t* src = first ? a.src0 + (long)b * a.HW * a.C0 + cg : a.src1 + (long)b * a.HW * a.C1 + (cg - a.C0);
   const int ldc = first ? a.C0 : a.C1;
   __shared__ float red[8];
+  // the group's gamma / beta go to LDS once: read per unit from global they were two more loads for every 8-byte data load
+  __shared__ __attribute__((aligned(16))) float gam_s[256], bet_s[256];
+  const bool gb_lds = cpg <= 256;
+  if (gb_lds && tid < cpg) { gam_s[tid] = a.gamma[cg + tid]; bet_s[tid] = a.beta[cg + tid]; }
   float v[UNITS][4];
   int pix[UNITS], ch[UNITS];
   float s = 0.f;
@@ -280,7 +304,8 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GnArgs a) {
 #pragma unroll
   for (int u = 0; u < UNITS; ++u)
     if (pix[u] >= 0) {
-      const float4 gm = *(const float4*)(a.gamma + cg + ch[u]), bt = *(const float4*)(a.beta + cg + ch[u]);
+      const float4 gm = gb_lds ? *(const float4*)(gam_s + ch[u]) : *(const float4*)(a.gamma + cg + ch[u]);
+      const float4 bt = gb_lds ? *(const float4*)(bet_s + ch[u]) : *(const float4*)(a.beta + cg + ch[u]);
       float y[4] = {(v[u][0] - mean) * rstd * gm.x + bt.x, (v[u][1] - mean) * rstd * gm.y + bt.y,
                     (v[u][2] - mean) * rstd * gm.z + bt.z, (v[u][3] - mean) * rstd * gm.w + bt.w};
       if (a.silu) {
@@ -383,12 +408,16 @@ static void gn_geometry(GnArgs& a, int* block, int* achunks) {
   a.PL = PL;
   *block = ((C8 * PL + 63) / 64) * 64;
   // statistics: enough chunks to fill the chip, at most GN_MAX_CHUNKS (partial buffer size)
-  int chunks = (512 + a.B - 1) / a.B;
+  static const int env_serial = [] { const char* e = getenv("DFH_GN_SERIAL"); return e ? atoi(e) : 0; }();
+  a.serial_red = env_serial;
+  static const int env_sc = [] { const char* e = getenv("DFH_GN_SC"); return e ? atoi(e) : 512; }();    // probe knobs
+  static const int env_ac = [] { const char* e = getenv("DFH_GN_AC"); return e ? atoi(e) : 1024; }();
+  int chunks = (env_sc + a.B - 1) / a.B;
   const int max_by_pix = (a.HW + PL - 1) / PL;
   chunks = std::max(1, std::min({chunks, max_by_pix, (int)GN_MAX_CHUNKS}));
   a.pix_per_chunk = (a.HW + chunks - 1) / chunks;
   a.chunks = (a.HW + a.pix_per_chunk - 1) / a.pix_per_chunk;
-  int ac = (2048 + a.B - 1) / a.B;
+  int ac = (env_ac + a.B - 1) / a.B;
   ac = std::max(1, std::min(ac, max_by_pix));
   a.apix_per_chunk = (a.HW + ac - 1) / ac;
   *achunks = (a.HW + a.apix_per_chunk - 1) / a.apix_per_chunk;
@@ -405,7 +434,8 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
     const int cpg = a.C / a.G;
     const long units = (long)a.HW * (cpg >> 2);
     const bool one_source_per_group = a.C1 == 0 || a.C0 % cpg == 0;
-    if ((cpg & 3) == 0 && units <= 256 * 32 && one_source_per_group && (long)a.B * a.G >= 64) {
+    static const int small_max = [] { const char* e = getenv("DFH_GN_SMALL_MAX"); return e ? atoi(e) : 16; }();   // probe knob; > 16 units per thread (32x32 x 640) the two-kernel path is faster since its prologue fix: 25.6 -> 21.3 us
+    if ((cpg & 3) == 0 && units <= 256 * small_max && one_source_per_group && (long)a.B * a.G >= 64) {
       ProfScope ps(PC_GNORM, 0.0, 4.0 * a.B * (double)a.HW * a.C, stream);
       const dim3 grid(a.G, a.B);
       if (units <= 256 * 8) hipLaunchKernelGGL(gn_small_kernel<8>, grid, dim3(256), 0, stream, a);

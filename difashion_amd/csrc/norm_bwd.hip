@@ -82,7 +82,7 @@ __global__ void gn_bwd_stats_kernel(const GnBwdArgs a) {
   if (tid < a.G) {
     float s1 = 0.f, s2 = 0.f;
     for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { s1 += a.gamma[c] * red[c * 2]; s2 += a.gamma[c] * red[c * 2 + 1]; }
-    float* dst = a.partial + (((long)b * gridDim.x + blockIdx.x) * a.G + tid) * 2;
+    float* dst = a.partial + (((long)b * a.G + tid) * gridDim.x + blockIdx.x) * 2;   // [b][group][chunk][2], as the forward
     dst[0] = s1; dst[1] = s2;
   }
 }
@@ -94,11 +94,28 @@ __global__ void gn_bwd_apply_kernel(const GnBwdArgs a) {
   const int tid = threadIdx.x;
   const int o = tid % C8, pl = tid / C8;
   const int b = blockIdx.y;
+  // the image's partials per group, summed by eight threads per group in a fixed order (see gn_apply_kernel in norm.hip)
+  __shared__ float2 run_s[64][8];
+  const bool wide_red = blockDim.x >= (unsigned)a.G * 8u;
+  if (wide_red) {
+    if (tid < a.G * 8) {
+      const int g = tid >> 3, sub = tid & 7;
+      const int per = (a.chunks + 7) >> 3, c0 = sub * per, c1 = min(a.chunks, c0 + per);
+      const float2* src = (const float2*)(a.partial + ((long)b * a.G + g) * a.chunks * 2);
+      float s1 = 0.f, s2 = 0.f;
+      for (int c = c0; c < c1; ++c) { const float2 v = src[c]; s1 += v.x; s2 += v.y; }
+      run_s[g][sub] = float2{s1, s2};
+    }
+    __syncthreads();
+  }
   if (tid < a.G) {
     float s1 = 0.f, s2 = 0.f;
-    for (int c = 0; c < a.chunks; ++c) {
-      const float* src = a.partial + (((long)b * a.chunks + c) * a.G + tid) * 2;
-      s1 += src[0]; s2 += src[1];
+    if (wide_red) {
+#pragma unroll
+      for (int sub = 0; sub < 8; ++sub) { s1 += run_s[tid][sub].x; s2 += run_s[tid][sub].y; }
+    } else {
+      const float2* src = (const float2*)(a.partial + ((long)b * a.G + tid) * a.chunks * 2);
+      for (int c = 0; c < a.chunks; ++c) { s1 += src[c].x; s2 += src[c].y; }
     }
     const float n = (float)a.HW * (float)cpg;
     s1_s[tid] = s1 / n; s2_s[tid] = s2 / n;

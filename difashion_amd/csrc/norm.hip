@@ -41,6 +41,18 @@ __global__ void gn_stats_kernel(const GnArgs a) {
     // 4 independent 16-byte loads in flight per thread (a single dependent load per iteration is
     // latency-bound at ~1 TB/s); accumulation order stays p-ascending, so results are unchanged.
     int p = p_begin + pl;
+    for (; p + 7 * a.PL < p_end; p += 8 * a.PL) {    // eight loads in flight
+      uint4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *gn_src(a, b, p + u * a.PL, o);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float f[8];
+        unpack8(v[u], f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s[k] += f[k]; q[k] += f[k] * f[k]; }
+      }
+    }
     for (; p + 3 * a.PL < p_end; p += 4 * a.PL) {
       uint4 v[4];
 #pragma unroll

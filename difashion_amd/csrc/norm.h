@@ -15,7 +15,6 @@ struct GnArgs {
   float* stats_out;                          // optional [B][G][2] (mean, rstd), kept for the backward pass
   // filled by the launcher
   int C, PL, chunks, pix_per_chunk, apix_per_chunk;
-  int serial_red;                            // probe: one thread per group sums the partials (the pre-round-2 prologue)
 };
 
 // GroupNorm(+SiLU) backward.  x = concat(src0, src1) as in the forward; dy [B][HW][C]; stats [B][G][2] from the forward.

@@ -124,7 +124,7 @@ __global__ void gn_apply_kernel(const GnArgs a) {
   // ascending order, then the eight runs in ascending order: a fixed order).  Summed by one thread per group this prologue was a
   // chain of 8-16 dependent load batches per block and paced the whole kernel (37 -> 28 us on 64x64 x 320 with it gone).
   __shared__ float2 run_s[64][8];
-  const bool wide_red = blockDim.x >= (unsigned)a.G * 8u && !a.serial_red;
+  const bool wide_red = blockDim.x >= (unsigned)a.G * 8u;
   if (wide_red) {
     if (tid < a.G * 8) {
       const int g = tid >> 3, sub = tid & 7;
@@ -420,8 +420,6 @@ static void gn_geometry(GnArgs& a, int* block, int* achunks) {
   a.PL = PL;
   *block = ((C8 * PL + 63) / 64) * 64;
   // statistics: enough chunks to fill the chip, at most GN_MAX_CHUNKS (partial buffer size)
-  static const int env_serial = [] { const char* e = getenv("DFH_GN_SERIAL"); return e ? atoi(e) : 0; }();
-  a.serial_red = env_serial;
   static const int env_sc = [] { const char* e = getenv("DFH_GN_SC"); return e ? atoi(e) : 512; }();    // probe knobs
   static const int env_ac = [] { const char* e = getenv("DFH_GN_AC"); return e ? atoi(e) : 1024; }();
   int chunks = (env_sc + a.B - 1) / a.B;

@@ -263,68 +263,87 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
   }
 }
 
-// LayerNorm with the fp8 quantisation of its output fused: one wave per token row (C <= 2048), exact two-pass variance in
-// registers like layernorm_kernel (norm.hip); the row maximum of |y| gives the token's scale.
-template <int MAXO>
+// LayerNorm with the fp8 quantisation of its output fused: one wave per R token rows (C <= 2048), exact two-pass variance in
+// registers like layernorm_kernel (norm.hip, incl. its rows-in-flight scheme: all R rows are loaded before the first is reduced);
+// the row maximum of |y| gives the token's scale.
+template <int MAXO, int R>
 __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, uint8_t* __restrict__ q,
                                                             float* __restrict__ scale, int M, int C, float eps) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= M) return;
   const int C8 = C >> 3;
-  float v[MAXO][8];
-  float s = 0.f;
+  uint4 raw[R][MAXO];
 #pragma unroll
-  for (int i = 0; i < MAXO; ++i) {
-    const int o = lane + i * 64;
-    if (o < C8) {
-      unpack8(*(const uint4*)(x + (long)row * C + o * 8), v[i]);
+  for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s += v[i][k];
+    for (int i = 0; i < MAXO; ++i) {
+      const int o = lane + i * 64;
+      raw[r][i] = make_uint4(0u, 0u, 0u, 0u);
+      if (o < C8 && row0 + r < M) raw[r][i] = *(const uint4*)(x + (long)(row0 + r) * C + o * 8);
     }
-  }
-  const float mean = wave_sum(s) / (float)C;
-  float qq = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXO; ++i) {
-    const int o = lane + i * 64;
-    if (o < C8) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; qq += d * d; }
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(qq) / (float)C + eps);
-  float amax = 0.f;
+  float gg[MAXO][8], bb[MAXO][8];
 #pragma unroll
   for (int i = 0; i < MAXO; ++i) {
     const int o = lane + i * 64;
     if (o < C8) {
       const float4 g0 = *(const float4*)(gamma + o * 8), g1 = *(const float4*)(gamma + o * 8 + 4);
       const float4 b0 = *(const float4*)(beta + o * 8), b1 = *(const float4*)(beta + o * 8 + 4);
-      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        // the bf16 path rounds the normalised value to bf16 before the GEMM reads it; quantise that same value
-        v[i][k] = bf2f(f2bf((v[i][k] - mean) * rstd * gg[k] + bb[k]));
-        amax = fmaxf(amax, fabsf(v[i][k]));
-      }
+      gg[i][0] = g0.x; gg[i][1] = g0.y; gg[i][2] = g0.z; gg[i][3] = g0.w; gg[i][4] = g1.x; gg[i][5] = g1.y; gg[i][6] = g1.z; gg[i][7] = g1.w;
+      bb[i][0] = b0.x; bb[i][1] = b0.y; bb[i][2] = b0.z; bb[i][3] = b0.w; bb[i][4] = b1.x; bb[i][5] = b1.y; bb[i][6] = b1.z; bb[i][7] = b1.w;
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
-  const float sc = amax > 0.f ? amax / FP8_MAX : 1.0f;
-  const float inv = 1.0f / sc;
-  if (lane == 0) scale[row] = sc;
+  for (int r = 0; r < R; ++r) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    float v[MAXO][8];
+    float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXO; ++i) {
-    const int o = lane + i * 64;
-    if (o < C8) {
-      uint2 w;
-      w.x = pack4_fp8(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv);
-      w.y = pack4_fp8(v[i][4] * inv, v[i][5] * inv, v[i][6] * inv, v[i][7] * inv);
-      *(uint2*)(q + (long)row * C + o * 8) = w;
+    for (int i = 0; i < MAXO; ++i) {
+      unpack8(raw[r][i], v[i]);
+      if (lane + i * 64 < C8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[i][k];
+      }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) {
+      if (lane + i * 64 < C8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; qq += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(qq) / (float)C + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) {
+      if (lane + i * 64 < C8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          // the bf16 path rounds the normalised value to bf16 before the GEMM reads it; quantise that same value
+          v[i][k] = bf2f(f2bf((v[i][k] - mean) * rstd * gg[i][k] + bb[i][k]));
+          amax = fmaxf(amax, fabsf(v[i][k]));
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float sc = amax > 0.f ? amax / FP8_MAX : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) {
+      const int o = lane + i * 64;
+      if (o < C8) {
+        uint2 w;
+        w.x = pack4_fp8(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv);
+        w.y = pack4_fp8(v[i][4] * inv, v[i][5] * inv, v[i][6] * inv, v[i][7] * inv);
+        *(uint2*)(q + (long)row * C + o * 8) = w;
+      }
     }
   }
 }
@@ -374,11 +393,11 @@ int quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, float* scale, in
 int layernorm_fp8_launch(const bf16_t* x, const float* gamma, const float* beta, uint8_t* q, float* scale, int M, int C, float eps,
                          hipStream_t stream) {
   DFH_REQUIRE(C % 8 == 0 && C <= 8 * 64 * 4, "LayerNorm width must be a multiple of 8 and <= 2048");
-  const dim3 grid((M + 3) / 4), block(256);
+  const dim3 block(256);
   ProfScope ps(PC_LNORM, 0.0, 3.0 * (double)M * C + 4.0 * M, stream);
-  if (C <= 512) hipLaunchKernelGGL(layernorm_fp8_kernel<1>, grid, block, 0, stream, x, gamma, beta, q, scale, M, C, eps);
-  else if (C <= 1024) hipLaunchKernelGGL(layernorm_fp8_kernel<2>, grid, block, 0, stream, x, gamma, beta, q, scale, M, C, eps);
-  else hipLaunchKernelGGL(layernorm_fp8_kernel<4>, grid, block, 0, stream, x, gamma, beta, q, scale, M, C, eps);
+  if (C <= 512) hipLaunchKernelGGL((layernorm_fp8_kernel<1, 4>), dim3((M + 15) / 16), block, 0, stream, x, gamma, beta, q, scale, M, C, eps);
+  else if (C <= 1024) hipLaunchKernelGGL((layernorm_fp8_kernel<2, 2>), dim3((M + 7) / 8), block, 0, stream, x, gamma, beta, q, scale, M, C, eps);
+  else hipLaunchKernelGGL((layernorm_fp8_kernel<4, 1>), dim3((M + 3) / 4), block, 0, stream, x, gamma, beta, q, scale, M, C, eps);
   return check_launch("layernorm_fp8_kernel");
 }
 

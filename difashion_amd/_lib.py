@@ -52,6 +52,7 @@ class GemmDesc(C.Structure):
         ("partial", C.c_void_p), ("partial_floats", C.c_size_t),
         ("zero_page", C.c_void_p),
         ("force_tile", C.c_int), ("force_split", C.c_int), ("force_glds", C.c_int),
+        ("gstat", C.c_void_p), ("gstat_cpg", C.c_int), ("gstat_hw", C.c_int),
     ]
 
 
@@ -117,6 +118,8 @@ SIGNATURES = {
     "dfh_gemm_wgrad_partial_floats": (_sz, [C.POINTER(GemmDesc), _i]),
     "dfh_colsum": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "dfh_groupnorm": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    "dfh_gemm_gstat": (_i, [C.POINTER(GemmDesc), _vp, C.POINTER(C.c_int)]),
+    "dfh_groupnorm_pre": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _vp, _vp]),
     "dfh_groupnorm_stats": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     "dfh_groupnorm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "dfh_attention_lse": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),

@@ -119,6 +119,19 @@ int dfh_gemm(const dfh_gemm_desc* d, void* stream) {
   return dfh::gemm_launch(g, (hipStream_t)stream, d->force_tile, d->force_split, d->force_glds);
 }
 
+int dfh_gemm_gstat(const dfh_gemm_desc* d, void* stream, int* written) {
+  GemmArgs g;
+  if (int rc = fill_gemm(d, &g)) return rc;
+  DFH_REQUIRE(written != nullptr, "null argument");
+  const size_t need = d->force_split > 1 ? (size_t)d->force_split * g.M * g.N : dfh::gemm_partial_floats(g);
+  DFH_REQUIRE(need == 0 || (d->partial && d->partial_floats >= need), "partial buffer too small for split-K");
+  g.gstat = d->gstat; g.gstat_cpg = d->gstat_cpg; g.gstat_hw = d->gstat_hw;
+  bool w = false;
+  const int rc = dfh::gemm_launch(g, (hipStream_t)stream, d->force_tile, d->force_split, d->force_glds, &w);
+  *written = w ? 1 : 0;
+  return rc;
+}
+
 static int fill_wgrad(const dfh_gemm_desc* d, const void* dY, int ldy, float* dW, int ldw, int msplit, WgradArgs& w) {
   GemmArgs g;
   DFH_REQUIRE(d, "null argument");
@@ -161,6 +174,14 @@ int dfh_groupnorm(const void* src0, int c0, const void* src1, int c1, int batch,
   a.src0 = (const bf16_t*)src0; a.C0 = c0; a.src1 = (const bf16_t*)src1; a.C1 = src1 ? c1 : 0;
   a.B = batch; a.HW = hw; a.G = groups; a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu;
   a.out = (bf16_t*)out; a.partial = partial;
+  return dfh::groupnorm_launch(a, (hipStream_t)stream);
+}
+
+int dfh_groupnorm_pre(const void* src, int c, int batch, int hw, int groups, const float* gamma, const float* beta, float eps, int silu,
+                      void* out, const float* gstat, int chunks, float* stats_out, void* stream) {
+  GnArgs a; std::memset(&a, 0, sizeof(a));
+  a.src0 = (const bf16_t*)src; a.C0 = c; a.B = batch; a.HW = hw; a.G = groups; a.gamma = gamma; a.beta = beta; a.eps = eps;
+  a.silu = silu; a.out = (bf16_t*)out; a.pre = gstat; a.pre_chunks = chunks; a.stats_out = stats_out;
   return dfh::groupnorm_launch(a, (hipStream_t)stream);
 }
 

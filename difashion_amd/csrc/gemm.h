@@ -39,6 +39,10 @@ struct GemmArgs {
   int act;
   void* out; int ld_out; int out_mode;
   float* partial;  // [ksplit][M][N] fp32 when ksplit > 1
+  // --- optional GroupNorm statistics of the OUTPUT, written by the 256-row epilogue (gemm_wide_epilogue.h) when the launcher finds
+  //     the launch eligible: per (image, group, row tile) the sum and the sum of squares of the bf16-rounded outputs, in the layout
+  //     gn_apply_kernel reads ([image][group][chunk][2], chunk = row tile inside the image), so the consumer skips gn_stats_kernel
+  float* gstat; int gstat_cpg, gstat_hw;   // channels per group of the consuming GroupNorm; pixels per image
 };
 
 // fp8 (OCP e4m3fn) linear: out[m][n] = epilogue(sA[m] * sW[n] * sum_k A8[m][k] * W8[n][k]); gemm_fp8.hip
@@ -63,7 +67,8 @@ int layernorm_fp8_launch(const bf16_t* x, const float* gamma, const float* beta,
                          hipStream_t stream);
 // Picks a tile shape + split-K factor, launches, and (if split) launches the reduce.  ``partial``
 // must hold gemm_partial_floats(...) floats when the heuristic splits.
-int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile = 0, int force_split = 0, int force_glds = -1);
+int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile = 0, int force_split = 0, int force_glds = -1,
+                bool* gstat_written = nullptr);   // *gstat_written: whether a.gstat was filled (only the 256 x 160 epilogue can)
 int gemm_pick_split(const GemmArgs& a, int* tile_out);
 size_t gemm_partial_floats(const GemmArgs& a);
 int gemm_count_ksteps(const GemmArgs& a);

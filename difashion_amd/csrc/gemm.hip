@@ -654,7 +654,8 @@ static void gemm_pick_tile_order(GemmArgs& a, int split, int bm, int bn) {
   if (best != 8) { a.tm_xm = best; a.tm_gm = 8; }
 }
 
-int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split, int force_glds) {
+int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split, int force_glds, bool* gstat_written) {
+  if (gstat_written) *gstat_written = false;
   (void)force_glds;   // staging is always LDS-DMA; the flag is kept for ABI stability
   DFH_REQUIRE(a.M > 0 && a.N > 0, "empty GEMM");
   DFH_REQUIRE(a.N % 4 == 0, "N must be a multiple of 4");
@@ -723,6 +724,11 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     static const bool halo_on = [] { const char* e = getenv("DFH_GEMM_HALO"); return e && e[0] == '1'; }();
     const bool halo = wide_ok && !force_deep && gemm_halo_eligible(a) && (force_wide == 15 || (wide == 1 && !force_wide && halo_on));
     if (force_wide == 15) wide = halo ? 1 : 0;
+    // output statistics for the consuming GroupNorm: only the 256 x 160 epilogue writes them, on full tiles inside one image
+    const bool gst_ok = a.gstat && (halo || (wide == 1 && !ws)) && a.gstat_cpg > 0 && 160 % a.gstat_cpg == 0 && a.N % 160 == 0 &&
+                        a.N % a.gstat_cpg == 0 && a.M % 256 == 0 && a.gstat_hw % 256 == 0 && a.act != ACT_GEGLU;
+    if (!gst_ok) a.gstat = nullptr;
+    else if (gstat_written) *gstat_written = true;
     if (halo) rc = gemm_halo_launch(a, stream);
     else if (ws) rc = gemm_ws_launch(a, stream, ws);
     else if (wide) rc = gemm_wide_launch(a, stream, wide);

@@ -36,6 +36,13 @@ DFH_DEVICE void wide_epilogue(const GemmArgs& a, f32x4_t (&acc)[BM / 2 / 16][BN 
   };
   const bool has_resid = a.resid != nullptr && a.act != ACT_GEGLU;
   if (has_resid) fetch_resid(0);
+  // GroupNorm statistics of the output (a.gstat, see gemm.h): the rounded values of a pass go back into the fp32 pass tile, thread
+  // t < BN sums column t over the 64 rows in row order, and after the last pass the columns are folded into groups: fixed orders
+  // throughout, no atomics.  The launcher guarantees full tiles inside one image and BN % cpg == 0.
+  const bool gst = a.gstat != nullptr;
+  constexpr int CQ = BN / 4;                        // column quads; thread t < 4 * CQ sums quad t % CQ over rows (t / CQ) * 16 .. + 15
+  static_assert(4 * CQ <= NWV * 64, "one thread per (column quad, row quarter)");
+  float4 col_s = float4{0.f, 0.f, 0.f, 0.f}, col_q = col_s;
   // the tile's bias slice goes to LDS once (behind the fp32 pass tile): per-chunk global reads cost 2.5 us per launch
   constexpr int BIAS_OFF = 64 * RSF;
   // ... and so does the time-embedding row (rowvec) when the whole tile lies inside one image (every level but 8x8): read per
@@ -140,7 +147,53 @@ DFH_DEVICE void wide_epilogue(const GemmArgs& a, f32x4_t (&acc)[BM / 2 / 16][BN 
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += f[r];
       }
-      *(uint4*)((bf16_t*)a.out + (long)m * a.ld_out + n) = pack8(v);
+      const uint4 packed = pack8(v);
+      *(uint4*)((bf16_t*)a.out + (long)m * a.ld_out + n) = packed;
+      if (gst) {                                       // this thread read the slot, nobody else touches it in this pass
+        float f[8];
+        unpack8(packed, f);
+        *(float4*)(smem + row * RSF + cchunk * 32) = float4{f[0], f[1], f[2], f[3]};
+        *(float4*)(smem + row * RSF + cchunk * 32 + 16) = float4{f[4], f[5], f[6], f[7]};
+      }
+    }
+    if (gst) {
+      __syncthreads();
+      if (tid < 4 * CQ) {
+        const int cq = tid % CQ, r0 = (tid / CQ) * 16;
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+          const float4 x = *(const float4*)(smem + (r0 + r) * RSF + cq * 16);
+          col_s.x += x.x; col_s.y += x.y; col_s.z += x.z; col_s.w += x.w;
+          col_q.x += x.x * x.x; col_q.y += x.y * x.y; col_q.z += x.z * x.z; col_q.w += x.w * x.w;
+        }
+      }
+    }
+  }
+  if (gst) {
+    __syncthreads();
+    float* cst = (float*)smem;                         // [BN][2], then the four row quarters folded in order
+    float* qrt = cst + 2 * BN;                         // [4][BN][2]
+    if (tid < 4 * CQ) {
+      const int cq = tid % CQ, rq = tid / CQ;
+      float* d = qrt + (rq * BN + cq * 4) * 2;
+      d[0] = col_s.x; d[1] = col_q.x; d[2] = col_s.y; d[3] = col_q.y; d[4] = col_s.z; d[5] = col_q.z; d[6] = col_s.w; d[7] = col_q.w;
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float ss = 0.f, qq = 0.f;
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) { ss += qrt[(rq * BN + tid) * 2]; qq += qrt[(rq * BN + tid) * 2 + 1]; }
+      cst[tid * 2] = ss; cst[tid * 2 + 1] = qq;
+    }
+    __syncthreads();
+    const int cpg = a.gstat_cpg;
+    if (tid < BN / cpg) {
+      float ss = 0.f, qq = 0.f;
+      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { ss += cst[c * 2]; qq += cst[c * 2 + 1]; }
+      const int b = m0 / a.gstat_hw, chunk = (m0 - b * a.gstat_hw) / BM, chunks = a.gstat_hw / BM;
+      const int g = (n0 + tid * cpg) / cpg, G = a.N / cpg;
+      float* dst = a.gstat + (((long)b * G + g) * chunks + chunk) * 2;
+      dst[0] = ss; dst[1] = qq;
     }
   }
 }

@@ -13,6 +13,8 @@ struct GnArgs {
   bf16_t* out;                               // [B][HW][C0+C1]
   float* partial;                            // >= B * GN_MAX_CHUNKS * G * 2 floats
   float* stats_out;                          // optional [B][G][2] (mean, rstd), kept for the backward pass
+  const float* pre; int pre_chunks;          // optional: statistics partials written by the producing GEMM's epilogue
+                                             // ([B][G][pre_chunks][2], gemm.h GemmArgs::gstat): gn_stats_kernel is skipped
   // filled by the launcher
   int C, PL, chunks, pix_per_chunk, apix_per_chunk;
 };

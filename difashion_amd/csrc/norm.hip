@@ -438,8 +438,19 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
   DFH_REQUIRE(a.C % 8 == 0 && a.C0 % 8 == 0 && a.C1 % 8 == 0, "channels must be multiples of 8");
   DFH_REQUIRE(a.G > 0 && a.G <= 64 && a.C % a.G == 0, "bad group count");
   DFH_REQUIRE(a.C / 8 <= 1024, "too many channels");
-  DFH_REQUIRE(a.partial != nullptr && a.out != nullptr && a.src0 != nullptr, "null pointer");
+  DFH_REQUIRE((a.partial != nullptr || a.pre != nullptr) && a.out != nullptr && a.src0 != nullptr, "null pointer");
   DFH_REQUIRE(a.C1 == 0 || a.src1 != nullptr, "second source missing");
+  if (a.pre) {
+    // the producer's epilogue already summed the tensor (one source, its own group structure): normalise only
+    DFH_REQUIRE(a.C1 == 0 && a.pre_chunks > 0 && a.pre_chunks <= (int)GN_MAX_CHUNKS, "producer statistics: one source, 1..64 chunks");
+    int block, achunks;
+    gn_geometry(a, &block, &achunks);
+    DFH_REQUIRE(block <= 1024, "block too large");
+    a.partial = const_cast<float*>(a.pre); a.chunks = a.pre_chunks;
+    ProfScope ps(PC_GNORM, 0.0, 4.0 * a.B * (double)a.HW * a.C, stream);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(achunks, a.B), dim3(block), 0, stream, a);
+    return check_launch("gn_apply_kernel");
+  }
   {
     const int cpg = a.C / a.G;
     const long units = (long)a.HW * (cpg >> 2);

@@ -50,7 +50,12 @@ struct AttL {
 };
 struct ConvL { Mat w; Vec b; int cin = 0, cout = 0; std::string pre; Mat wt; };
 
-struct Tensor { bf16_t* p = nullptr; int H = 0, W = 0, C = 0; };
+struct Tensor {
+  bf16_t* p = nullptr; int H = 0, W = 0, C = 0;
+  // GroupNorm statistics of this tensor written by the GEMM epilogue that produced it (gemm.h GemmArgs::gstat); null when the
+  // launch ran on a kernel that does not write them -- the consuming GroupNorm then computes its own
+  const float* gst = nullptr; int gst_cpg = 0, gst_chunks = 0;
+};
 
 struct Bump {
   char* base = nullptr; size_t cap = 0, off = 0, peak = 0;
@@ -386,12 +391,23 @@ struct dfh_unet {
     Tensor palloc(int H, int W, int C) { return Tensor{(bf16_t*)persist.alloc((size_t)B * H * W * C * 2), H, W, C}; }
     Tensor talloc(int H, int W, int C) { return Tensor{(bf16_t*)temp.alloc((size_t)B * H * W * C * 2), H, W, C}; }
 
-    void gemm(GemmArgs g) {
+    // o / bump: the output tensor and the allocator it came from when the output feeds a GroupNorm -- the epilogue then leaves
+    // that GroupNorm's statistics beside it (64x64 level: the launches the 256 x 160 tile takes).  DFH_GN_PRE=0 turns it off (A/B).
+    void gemm(GemmArgs g, Tensor* o = nullptr, Bump* bump = nullptr) {
       if (rc) return;
       g.zero = zero; g.partial = partial;
+      static const bool pre_off = [] { const char* e = getenv("DFH_GN_PRE"); return e && e[0] == '0'; }();
+      float* gst = nullptr;
+      const int G = u->cfg.norm_num_groups;
+      if (o && bump && !pre_off && (o->H * o->W) % 256 == 0 && o->C % G == 0 && (o->H * o->W) / 256 <= (int)GN_MAX_CHUNKS) {
+        gst = (float*)bump->alloc((size_t)B * G * ((o->H * o->W) / 256) * 2 * sizeof(float));      // same in the dry run
+        g.gstat = gst; g.gstat_cpg = o->C / G; g.gstat_hw = o->H * o->W;
+      }
       if (dry) { partial_need = std::max(partial_need, dfh::gemm_partial_floats(g) * sizeof(float)); return; }
       if (dfh::gemm_partial_floats(g) * sizeof(float) > partial_cap) { dfh::set_error("split-K partial buffer too small"); rc = -1; return; }
-      rc = dfh::gemm_launch(g, s);
+      bool written = false;
+      rc = dfh::gemm_launch(g, s, 0, 0, -1, &written);
+      if (o && written) { o->gst = gst; o->gst_cpg = g.gstat_cpg; o->gst_chunks = g.gstat_hw / 256; }
     }
     static GemmArgs base(int M, int N) {
       GemmArgs g; std::memset(&g, 0, sizeof(g));
@@ -400,7 +416,7 @@ struct dfh_unet {
     }
     // out = act(x . W^T + bias) (+resid); x rows [M][K]
     void linear(const bf16_t* x, int M, int K, const Mat& W, const Vec* bias, int act, const bf16_t* resid, void* out,
-                int N, int out_mode = OUT_BF16, int ld_out = -1, int rows_per_b = 0) {
+                int N, int out_mode = OUT_BF16, int ld_out = -1, int rows_per_b = 0, Tensor* o = nullptr, Bump* bump = nullptr) {
       GemmArgs g = base(M, N);
       g.p_src[0] = x; g.p_c[0] = K; g.nplain = 1;
       g.W = w16(W); g.ldw = W.K;
@@ -408,7 +424,7 @@ struct dfh_unet {
       g.act = act; g.resid = resid; g.ld_res = N;
       g.out = out; g.out_mode = out_mode; g.ld_out = ld_out < 0 ? (act == ACT_GEGLU ? N / 2 : N) : ld_out;
       if (rows_per_b) g.rows_per_b = rows_per_b;
-      gemm(g);
+      gemm(g, o, bump);
     }
     void groupnorm(const Tensor& x0, const Tensor* x1, const Vec& w, const Vec& b, float eps, int silu, Tensor& out) {
       if (rc || dry) return;
@@ -416,6 +432,7 @@ struct dfh_unet {
       a.src0 = x0.p; a.C0 = x0.C; a.src1 = x1 ? x1->p : nullptr; a.C1 = x1 ? x1->C : 0;
       a.B = B; a.HW = x0.H * x0.W; a.G = u->cfg.norm_num_groups;
       a.gamma = v32(w); a.beta = v32(b); a.eps = eps; a.silu = silu; a.out = out.p; a.partial = gn_partial;
+      if (!x1 && x0.gst && x0.gst_cpg == x0.C / a.G) { a.pre = x0.gst; a.pre_chunks = x0.gst_chunks; }   // summed by its producer
       rc = dfh::groupnorm_launch(a, s);
     }
     bool use8(const Mat8& m) const { return u->fp8 && m.on; }        // the forward entry checks that arena8 is bound
@@ -459,7 +476,7 @@ struct dfh_unet {
       g.Hin = x.H; g.Win = x.W; g.Hout = Ho; g.Wout = Wo; g.stride = stride; g.ups = ups;
       g.W = w16(c.w); g.ldw = c.w.K; g.bias = v32(c.b);
       g.out = o.p;
-      gemm(g);
+      gemm(g, &o, to_persist ? &persist : &temp);
       return o;
     }
 
@@ -477,7 +494,7 @@ struct dfh_unet {
         g.W = w16(r.w1); g.ldw = r.w1.K; g.bias = v32(r.b1);
         g.rowvec = temb_all; g.rv_ld = u->temb_total; g.rv_off = r.temb_off; g.rows_per_b = H * W;
         g.out = h1.p;
-        gemm(g);
+        gemm(g, &h1, &temp);
       }
       Tensor g2 = talloc(H, W, r.cout);
       groupnorm(h1, nullptr, r.n2w, r.n2b, u->cfg.norm_eps, 1, g2);
@@ -493,7 +510,7 @@ struct dfh_unet {
           g.resid = x0.p; g.ld_res = r.cout;
         }
         g.out = out.p;
-        gemm(g);
+        gemm(g, &out, &persist);
       }
       temp.off = mark;
       return out;
@@ -545,7 +562,7 @@ struct dfh_unet {
         linear(n1.p, M, C, a.ff1, &a.ff1b, ACT_GEGLU, nullptr, ff.p, 8 * C);
       }
       linear(ff.p, M, 4 * C, a.ff2, &a.ff2b, ACT_NONE, h2.p, h0.p, C);   // h0 is dead by now: reuse
-      linear(h0.p, M, C, a.pout, &a.poutb, ACT_NONE, x.p, out.p, C);
+      linear(h0.p, M, C, a.pout, &a.poutb, ACT_NONE, x.p, out.p, C, OUT_BF16, -1, 0, &out, &persist);   // feeds the next block's GroupNorm
       temp.off = mark;
       return out;
     }

@@ -196,9 +196,15 @@ typedef struct dfh_gemm_desc {
   float* partial; size_t partial_floats;        /* split-K slabs (dfh_gemm_partial_floats) */
   const void* zero_page;                        /* >= 256 zero bytes */
   int force_tile, force_split, force_glds;      /* 0,0,-1 = heuristics */
+  float* gstat; int gstat_cpg, gstat_hw;        /* optional: GroupNorm statistics of the output for the consumer (channels per group,
+                                                 * pixels per image): [image][group][hw / 256][2] sums / sums of squares; written only
+                                                 * by the 256 x 160 tile, and only through dfh_gemm_gstat (dfh_gemm ignores the three fields) */
 } dfh_gemm_desc;
 size_t dfh_gemm_partial_floats(const dfh_gemm_desc* d);
 int dfh_gemm(const dfh_gemm_desc* d, void* stream);
+/* dfh_gemm + the output statistics for the consuming GroupNorm (d->gstat ...); *written = 1 when they were produced, 0 when the launch
+ * ran on a kernel that cannot (the caller then runs plain dfh_groupnorm) */
+int dfh_gemm_gstat(const dfh_gemm_desc* d, void* stream, int* written);
 /* Weight gradient of the same op (train.py:699 backward): dW[n][k] += sum_m dY[m][n] * A[m][k], where A is the
  * forward operand described by d (conv_src / a0 / a1 segments, M, N, zero_page; W / out / epilogue fields unused).
  * dW: fp32 [N][ldw] in the PACKED weight layout, accumulated with atomics (zero it first).  msplit 0 = heuristic. */
@@ -213,6 +219,9 @@ int dfh_colsum(const void* Y, int ldy, int N, int groups, int rows_per_group, fl
  * (ResnetBlock2D.norm1/norm2, conv_norm_out, Transformer2DModel.norm).  partial: >= B*64*G*2 floats */
 int dfh_groupnorm(const void* src0, int c0, const void* src1, int c1, int batch, int hw, int groups,
                   const float* gamma, const float* beta, float eps, int silu, void* out, float* partial, void* stream);
+/* the same with the statistics supplied by the producing dfh_gemm (gstat, chunks = hw / 256): one launch, the tensor is read once */
+int dfh_groupnorm_pre(const void* src, int c, int batch, int hw, int groups, const float* gamma, const float* beta, float eps,
+                      int silu, void* out, const float* gstat, int chunks, float* stats_out, void* stream);
 /* LayerNorm over the last dim of [M][C] bf16 (BasicTransformerBlock.norm1/2/3) */
 int dfh_layernorm(const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps, void* stream);
 /* ---- fp8 (OCP e4m3fn) linears: BASELINE configs[4].  The reference has no fp8 path (fp16 autocast, run_inf4eval.sh:1); these

@@ -29,7 +29,8 @@ def stream():
 
 def gemm(*, M, N, W, ldw, a0=None, a0_c=0, a1=None, a1_c=0, conv_src=None, conv_c=0, batch=0, Hin=0, Win=0, stride=1,
          upsample=0, bias=None, rowvec=None, rv_ld=0, rv_off=0, rows_per_b=0, resid=None, act=0, out_mode=0,
-         out=None, ld_out=None, force_tile=0, force_split=0, force_glds=-1):
+         out=None, ld_out=None, force_tile=0, force_split=0, force_glds=-1, gstat=None, gstat_cpg=0, gstat_hw=0):
+    """gstat: a float32 device tensor for the output's GroupNorm statistics (dfh_gemm_gstat); the call then returns (out, written)."""
     d = _lib.GemmDesc()
     if conv_src is not None:
         d.conv_src, d.conv_c, d.conv = conv_src.data_ptr(), conv_c, 1
@@ -60,6 +61,12 @@ def gemm(*, M, N, W, ldw, a0=None, a0_c=0, a1=None, a1_c=0, conv_src=None, conv_
     if need:
         part = torch.empty(need, dtype=torch.float32, device=DEV)
         d.partial, d.partial_floats = part.data_ptr(), need
+    if gstat is not None:
+        d.gstat, d.gstat_cpg, d.gstat_hw = gstat.data_ptr(), gstat_cpg, gstat_hw
+        written = C.c_int(0)
+        _lib.call("dfh_gemm_gstat", C.byref(d), stream(), C.byref(written))
+        torch.cuda.synchronize()
+        return out, bool(written.value)
     _lib.call("dfh_gemm", C.byref(d), stream())
     torch.cuda.synchronize()
     return out

@@ -157,6 +157,59 @@ def test_conv3x3_halo_patch_kernel(cin, cout, H, W, B):
     assert torch.equal(out, wide), "halo and wide kernels accumulate the same products in the same order"
 
 
+@pytest.mark.parametrize("kind,cin,cout,H,B,tile", [
+    ("conv", 64, 320, 32, 2, 6),      # 3x3 conv on the wide kernel: 4 row tiles per image, cpg 10 (16 groups per column tile)
+    ("conv", 64, 320, 32, 2, 20),     # the halo-patch kernel shares the epilogue
+    ("conv", 32, 640, 16, 3, 6),      # one row tile per image, cpg 20
+    ("linear", 320, 320, 32, 2, 6),   # proj_out shape class: linear + residual
+])
+def test_gemm_writes_groupnorm_statistics_for_its_consumer(kind, cin, cout, H, B, tile):
+    """The 256-row epilogue writes, per (image, group, row tile), the sum and the sum of squares of the bf16 outputs (dfh_gemm_gstat);
+    dfh_groupnorm_pre normalises from them in ONE launch.  Checked: the partials against torch sums of the GEMM's own output, and
+    the normalised tensor against plain dfh_groupnorm of that output (same statistics up to summation order) and against
+    F.group_norm; a launch on a kernel that cannot produce them reports written = 0."""
+    G, HW = 32, H * H
+    M, cpg, chunks = B * HW, cout // 32, HW // 256
+    bias = rnd(cout, seed=41)
+    res = bf(rnd(M, cout, seed=42))
+    gst = torch.full((B * G * chunks * 2,), float("nan"), dtype=torch.float32, device=DEV)
+    if kind == "conv":
+        x = bf(rnd(B, cin, H, H, seed=43))
+        w = rnd(cout, cin, 3, 3, seed=44, scale=0.05)
+        temb = rnd(B, 2 * cout, seed=45)
+        kw = dict(M=M, N=cout, W=gu.pack_conv(w), ldw=9 * cin, conv_src=gu.nhwc(x), conv_c=cin, batch=B, Hin=H, Win=H, bias=bias,
+                  rowvec=temb, rv_ld=2 * cout, rv_off=cout, rows_per_b=HW)
+    else:
+        a = bf(rnd(M, cin, seed=43))
+        w = bf(rnd(cout, cin, seed=44, scale=0.05))
+        kw = dict(M=M, N=cout, W=w, ldw=cin, a0=a, a0_c=cin, bias=bias, resid=res)
+    out, written = gu.gemm(force_tile=tile, gstat=gst, gstat_cpg=cpg, gstat_hw=HW, **kw)
+    assert written
+    y = out.float().view(B, chunks, 256, G, cpg)
+    ref = torch.stack([y.sum(dim=(2, 4)), (y * y).sum(dim=(2, 4))], dim=-1).permute(0, 2, 1, 3)     # [B][G][chunks][2]
+    got = gst.view(B, G, chunks, 2)
+    assert torch.allclose(got, ref, rtol=2e-5, atol=1e-2), float((got - ref).abs().max())
+    gamma, beta = rnd(cout, seed=46) + 1.0, rnd(cout, seed=47)
+    o_pre = torch.empty(M, cout, dtype=torch.bfloat16, device=DEV)
+    stats = torch.empty(B * G * 2, dtype=torch.float32, device=DEV)
+    _lib.call("dfh_groupnorm_pre", _lib.ptr(out), cout, B, HW, G, _lib.ptr(gamma), _lib.ptr(beta), 1e-5, 1, _lib.ptr(o_pre),
+              _lib.ptr(gst), chunks, _lib.ptr(stats), gu.stream())
+    o_two = torch.empty_like(o_pre)
+    part = torch.empty(B * 64 * 64 * 2, dtype=torch.float32, device=DEV)
+    _lib.call("dfh_groupnorm", _lib.ptr(out), cout, None, 0, B, HW, G, _lib.ptr(gamma), _lib.ptr(beta), 1e-5, 1, _lib.ptr(o_two),
+              _lib.ptr(part), gu.stream())
+    torch.cuda.synchronize()
+    assert float((o_pre.float() - o_two.float()).abs().max()) <= 2e-2       # one bf16 step at |y| ~ 2-4: summation order only
+    xr = gu.nchw(out.float().view(B, H, H, cout))
+    gref = F.silu(F.group_norm(xr, G, gamma, beta, 1e-5))
+    gu.assert_close_bf16(gu.nchw(o_pre.view(B, H, H, cout)), gref, "groupnorm from producer statistics")
+    mean = xr.view(B, G, -1).mean(-1)
+    assert torch.allclose(stats.view(B, G, 2)[..., 0], mean, atol=1e-3)
+    # a launch that runs on another kernel (eight-wave 128 x 160) must say so
+    _, w2 = gu.gemm(force_tile=10, gstat=gst, gstat_cpg=cpg, gstat_hw=HW, **kw)
+    assert not w2
+
+
 @pytest.mark.parametrize("tile", [0, 6, 7, 8, 9, 11, 12])
 def test_conv3x3_with_fused_shortcut_and_temb(tile):
     """ResnetBlock2D tail: conv2(h) + conv_shortcut(cat(x, skip)) + biases, and conv1 + time embedding."""

@@ -51,7 +51,7 @@ class GemmDesc(C.Structure):
         ("out", C.c_void_p), ("ld_out", C.c_int), ("out_mode", C.c_int),
         ("partial", C.c_void_p), ("partial_floats", C.c_size_t),
         ("zero_page", C.c_void_p),
-        ("force_tile", C.c_int), ("force_split", C.c_int), ("force_glds", C.c_int),
+        ("force_tile", C.c_int), ("force_split", C.c_int), ("force_order", C.c_int),
         ("gstat", C.c_void_p), ("gstat_cpg", C.c_int), ("gstat_hw", C.c_int),
     ]
 
@@ -75,6 +75,10 @@ SIGNATURES = {
     "dfh_build_info": (C.c_char_p, []),
     "dfh_prof_begin": (_i, []),
     "dfh_prof_end": (_i, [C.POINTER(ProfClass), _i]),
+    "dfh_census_reset": (None, []),
+    "dfh_census_count": (_i, []),
+    "dfh_census_name": (C.c_char_p, [_i]),
+    "dfh_census_get": (C.c_long, [_i]),
     "dfh_unet_create": (_i, [C.POINTER(UNetConfigC), C.POINTER(_vp)]),
     "dfh_unet_destroy": (None, [_vp]),
     "dfh_unet_num_params": (_i, [_vp]),
@@ -165,7 +169,7 @@ SIGNATURES = {
     "dfh_noise_mix": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "dfh_mse_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
 }
-_NO_STATUS = {"dfh_abi_version", "dfh_unet_num_params", "dfh_unet_param_ndim", "dfh_unet_param_dim", "dfh_vae_num_params",
+_NO_STATUS = {"dfh_abi_version", "dfh_census_count", "dfh_unet_num_params", "dfh_unet_param_ndim", "dfh_unet_param_dim", "dfh_vae_num_params",
               "dfh_vae_param_ndim", "dfh_vae_param_dim"}
 
 _lib = None
@@ -244,6 +248,16 @@ def prof_end():
         raise DfhError(f"dfh_prof_end failed: {last_error()}")
     return {arr[i].name.decode(): dict(launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops, bytes=arr[i].bytes)
             for i in range(n)}
+
+
+def census_reset():
+    raw().dfh_census_reset()
+
+
+def census():
+    """-> {kernel family: launches since census_reset()} (host-side counters of the launchers; test infrastructure)."""
+    lib = raw()
+    return {lib.dfh_census_name(i).decode(): int(lib.dfh_census_get(i)) for i in range(lib.dfh_census_count())}
 
 
 def stream_ptr():

@@ -27,6 +27,12 @@ int check_launch(const char* what) {
   return 0;
 }
 
+static long g_census[CK_COUNT] = {0};
+void census(int id) { if (id >= 0 && id < CK_COUNT) ++g_census[id]; }
+static const char* const kCensusNames[CK_COUNT] = {"gemm_wide", "gemm_8wave", "gemm_lean", "gemm_other", "gemm_row", "splitk_reduce",
+    "splitk_fused", "gstat_written", "gn_pre", "gn_stats", "gn_small", "gn_mid", "layernorm", "ln_folded", "attention_x32", "attention_16",
+    "gemm_fp8", "text_cached"};
+
 struct ProfRec { hipEvent_t e0, e1; int cls; double flops, bytes; };
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -101,6 +107,10 @@ int dfh_prof_end(dfh_prof_class* out, int max_classes) {
   dfh::g_recs.clear();
   return dfh::PC_COUNT;
 }
+void dfh_census_reset(void) { std::memset(dfh::g_census, 0, sizeof(dfh::g_census)); }
+int dfh_census_count(void) { return dfh::CK_COUNT; }
+const char* dfh_census_name(int i) { return (i >= 0 && i < dfh::CK_COUNT) ? dfh::kCensusNames[i] : ""; }
+long dfh_census_get(int i) { return (i >= 0 && i < dfh::CK_COUNT) ? dfh::g_census[i] : -1; }
 const char* dfh_last_error(void) { return dfh::g_err.c_str(); }
 const char* dfh_build_info(void) { return "libdifashion_hip gfx950 (CDNA4) bf16-MFMA abi=1"; }
 
@@ -116,7 +126,7 @@ int dfh_gemm(const dfh_gemm_desc* d, void* stream) {
   if (int rc = fill_gemm(d, &g)) return rc;
   const size_t need = d->force_split > 1 ? (size_t)d->force_split * g.M * g.N : dfh::gemm_partial_floats(g);
   DFH_REQUIRE(need == 0 || (d->partial && d->partial_floats >= need), "partial buffer too small for split-K");
-  return dfh::gemm_launch(g, (hipStream_t)stream, d->force_tile, d->force_split, d->force_glds);
+  return dfh::gemm_launch(g, (hipStream_t)stream, d->force_tile, d->force_split, d->force_order);
 }
 
 int dfh_gemm_gstat(const dfh_gemm_desc* d, void* stream, int* written) {
@@ -127,7 +137,7 @@ int dfh_gemm_gstat(const dfh_gemm_desc* d, void* stream, int* written) {
   DFH_REQUIRE(need == 0 || (d->partial && d->partial_floats >= need), "partial buffer too small for split-K");
   g.gstat = d->gstat; g.gstat_cpg = d->gstat_cpg; g.gstat_hw = d->gstat_hw;
   bool w = false;
-  const int rc = dfh::gemm_launch(g, (hipStream_t)stream, d->force_tile, d->force_split, d->force_glds, &w);
+  const int rc = dfh::gemm_launch(g, (hipStream_t)stream, d->force_tile, d->force_split, d->force_order, &w);
   *written = w ? 1 : 0;
   return rc;
 }

@@ -311,6 +311,7 @@ int attention_launch(const AttnArgs& a, hipStream_t stream) {
   DFH_REQUIRE(a.ldvt >= ((a.Nk + 7) / 8) * 8, "V^T rows must be padded to a multiple of 8 keys");
   static const bool x32_off = [] { const char* e = getenv("DFH_ATTN_X32"); return e && e[0] == '0'; }();   // A/B switch for the microbenchmarks
   if (!x32_off && attention_x32_eligible(a)) return attention_x32_launch(a, stream);
+  census(CK_ATTN_16);
   switch (a.D) {
     case 32: return launch<32>(a, stream);
     case 40: return launch<40>(a, stream);

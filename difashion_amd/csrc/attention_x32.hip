@@ -465,6 +465,8 @@ bool attention_x32_eligible(const AttnArgs& a) {
 }
 
 int attention_x32_launch(const AttnArgs& a, hipStream_t stream) {
+  census(CK_ATTN_X32);
+#ifdef DFH_PROBES   // experiment instantiations (one / four query blocks per wave, phase stamps): probe builds only (scripts/probes/Makefile)
   static const int variant = [] { const char* e = getenv("DFH_ATTN_VARIANT"); return e ? atoi(e) : 0; }();   // experiments
   switch (a.D) {
     case 40:
@@ -490,10 +492,16 @@ int attention_x32_launch(const AttnArgs& a, hipStream_t stream) {
       if (variant == 1) return launch_x32<40, 1, 3>(a, stream);      // experiments: one 32-query block per wave at 3 / 4 waves per SIMD
       if (variant == 2) return launch_x32<40, 1, 4>(a, stream);
       if (variant == 3) return launch_x32<40, 4, 1>(a, stream);      // four blocks per wave, ONE wave per SIMD: 14 fragment reads per 56 MFMAs, but nothing to overlap the exponentials with: 524 vs 458 us
-      return launch_x32<40, 2, 2>(a, stream);
+      break;
     case 80:
       if (variant == 1) return launch_x32<80, 1, 3>(a, stream);
-      return launch_x32<80, 1, 2>(a, stream);
+      break;
+    default: break;
+  }
+#endif
+  switch (a.D) {
+    case 40: return launch_x32<40, 2, 2>(a, stream);
+    case 80: return launch_x32<80, 1, 2>(a, stream);
     default: break;
   }
   set_error("attention_x32_launch: unsupported head dim");

@@ -108,6 +108,12 @@ int check_launch(const char* what);     // returns 0 or negative and records the
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline).
 enum ProfClass { PC_CONV3 = 0, PC_LINEAR = 1, PC_ATTN = 2, PC_GNORM = 3, PC_LNORM = 4, PC_SPLITK = 5, PC_OTHER = 6,
                  PC_WGRAD = 7, PC_ATTN_BWD = 8, PC_NORM_BWD = 9, PC_OPTIM = 10, PC_LINEAR_FP8 = 11, PC_COUNT = 12 };
+// Launch census: one counter per kernel family, bumped by the launchers (tests assert through it WHICH kernels a walk ran, e.g. that
+// the batch-16 forward really took the wide tile, the producer-statistics GroupNorm and the split-K path; dfh_census_* in the C ABI)
+enum CensusId { CK_GEMM_WIDE = 0, CK_GEMM_8WAVE, CK_GEMM_LEAN, CK_GEMM_OTHER, CK_GEMM_ROW, CK_SPLITK, CK_SPLITK_FUSED, CK_GSTAT_WRITTEN,
+                CK_GN_PRE, CK_GN_STATS, CK_GN_SMALL, CK_GN_MID, CK_LAYERNORM, CK_LN_FOLDED, CK_ATTN_X32, CK_ATTN_16, CK_GEMM_FP8,
+                CK_TEXT_CACHED, CK_COUNT };
+void census(int id);
 bool prof_enabled();
 void prof_open(int cls, double flops, double bytes, hipStream_t s);   // no-ops unless enabled
 void prof_close(hipStream_t s);

@@ -67,7 +67,7 @@ int layernorm_fp8_launch(const bf16_t* x, const float* gamma, const float* beta,
                          hipStream_t stream);
 // Picks a tile shape + split-K factor, launches, and (if split) launches the reduce.  ``partial``
 // must hold gemm_partial_floats(...) floats when the heuristic splits.
-int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile = 0, int force_split = 0, int force_glds = -1,
+int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile = 0, int force_split = 0, int force_order = -1,
                 bool* gstat_written = nullptr);   // *gstat_written: whether a.gstat was filled (only the 256 x 160 epilogue can)
 int gemm_pick_split(const GemmArgs& a, int* tile_out);
 size_t gemm_partial_floats(const GemmArgs& a);
@@ -76,9 +76,11 @@ int gemm_count_ksteps(const GemmArgs& a);
 bool gemm_wide_eligible(const GemmArgs& a);
 int gemm_wide_pick(const GemmArgs& a);                       // 0 none, 1 = 256 x 160, 2 = 128 x 160
 int gemm_wide_launch(GemmArgs a, hipStream_t stream, int variant = 1);
+#ifdef DFH_PROBES   // scripts/probes/kernels: experiments that lost their A/B, built only into the probe library
 // wave-specialised 256 x {160,128} kernel (gemm_ws.hip): loader waves + matrix waves, one workgroup per CU
 bool gemm_halo_eligible(const GemmArgs& a);                  // gemm_halo.hip: 3x3 conv, pixels staged once per channel slice
 int gemm_halo_launch(GemmArgs a, hipStream_t stream);
 int gemm_ws_pick(const GemmArgs& a, int min_tiles);           // 0 = not eligible, else the column tile (160 / 128)
 int gemm_ws_launch(GemmArgs a, hipStream_t stream, int bn);
+#endif
 }  // namespace dfh

@@ -632,7 +632,9 @@ static void gemm_pick_tile_order(GemmArgs& a, int split, int bm, int bn) {
   static const int env_xm = [] { const char* e = getenv("DFH_TMAP"); return e ? atoi(e) : -1; }();
   static const int env_gm = [] { const char* e = getenv("DFH_TMAP"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }();
   a.tm_xm = 0; a.tm_gm = 0;
-  if (env_xm >= 0) { a.tm_xm = env_xm; a.tm_gm = env_gm; return; }
+  if (env_xm >= 0) {            // probe knob; xm must divide the 8 XCDs (anything else would enumerate some tiles twice and others never)
+    a.tm_xm = (env_xm == 1 || env_xm == 2 || env_xm == 4 || env_xm == 8) ? env_xm : 0; a.tm_gm = env_gm; return;
+  }
   if (split > 1 || a.n_major) return;
   double kk = (double)a.ntaps * a.conv_c;
   for (int i = 0; i < a.nplain; ++i) kk += a.p_c[i];
@@ -654,9 +656,8 @@ static void gemm_pick_tile_order(GemmArgs& a, int split, int bm, int bn) {
   if (best != 8) { a.tm_xm = best; a.tm_gm = 8; }
 }
 
-int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split, int force_glds, bool* gstat_written) {
+int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split, int force_order, bool* gstat_written) {
   if (gstat_written) *gstat_written = false;
-  (void)force_glds;   // staging is always LDS-DMA; the flag is kept for ABI stability
   DFH_REQUIRE(a.M > 0 && a.N > 0, "empty GEMM");
   DFH_REQUIRE(a.N % 4 == 0, "N must be a multiple of 4");
   DFH_REQUIRE(a.ntaps == 0 || a.ntaps == 9, "ntaps must be 0 or 9");
@@ -687,8 +688,8 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     for (int i = 0; i < a.nplain; ++i) kk += a.p_c[i];
     const double w_bytes = (double)a.N * kk, a_bytes = (double)a.M * (a.ntaps ? (double)a.conv_c : kk);
     // measured (scripts/gemm_nmajor_probe.py): +12 % / +6 % on the 16x16-level 3x3 convs, -4 % on the linear shapes -> convs only
-    a.n_major = (force_glds == 2 || (force_glds < 0 && a.ntaps && w_bytes > a_bytes && a.N > 160)) ? 1 : 0;   // force_glds 2 / 3 pin it (probe)
-    if (force_glds == 3) a.n_major = 0;
+    a.n_major = (force_order == 2 || (force_order < 0 && a.ntaps && w_bytes > a_bytes && a.N > 160)) ? 1 : 0;   // force_order 2 / 3 pin it (probe)
+    if (force_order == 3) a.n_major = 0;
   }
   if (split > 1) DFH_REQUIRE(a.partial != nullptr, "split-K needs a partial buffer");
   if (a.resid) DFH_REQUIRE((double)a.M * a.ld_res * 2.0 < 4.0e9, "residual tensor must be smaller than 4 GB (32-bit lane offsets)");
@@ -704,41 +705,47 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     const bool wide_ok = split == 1 && a.out_mode == OUT_BF16 && (a.act != ACT_GEGLU || a.N % 160 == 0 || a.N % 128 == 0) && (a.N & 7) == 0 &&
                          (a.ld_out & 7) == 0 && (!a.resid || (a.ld_res & 7) == 0);
     int wide = (!wide_ok || force_deep) ? 0 : (force_wide ? force_wide : ((force_tile == 0 && force_split == 0) ? gemm_wide_pick(a) : 0));
-    // tile ids 11 / 12 (force_wide 6 / 7): the wave-specialised kernel (gemm_ws.hip) with a 160 / 128 column tile.  Measured
-    // (scripts/gemm_ws_probe.py, profiles/r02/gemm_ws_probe.txt): equal to the eight-wave 128 x 160 kernel at the 32x32 / 16x16
-    // levels, 5-20 % SLOWER than the wide kernel at the 64x64 level -- four loader waves sustain ~16 B/clk/CU of LDS-DMA (one
-    // 1-KiB piece per ~250 cycles and wave) where the tile needs 40 -- so it is opt-in: DFH_GEMM_WS=1 lets it take the launches
-    // that give every CU a 256-row tile.
+    int ws = 0; bool halo = false;
+#ifdef DFH_PROBES
+    // Probe builds only (scripts/probes/Makefile): tile ids 11 / 12 = the wave-specialised kernel (scripts/probes/kernels/gemm_ws.hip, opt-in
+    // DFH_GEMM_WS=1), tile id 20 = the halo-patch conv kernel (scripts/probes/kernels/gemm_halo.hip, DFH_GEMM_HALO=1).  Both lost their A/B
+    // (profiles/r02/gemm_ws_probe.txt; conv3x3 class 6.96 -> 6.93 ms) and are kept as measurements, not as product code.
     static const bool ws_off = [] { const char* e = getenv("DFH_GEMM_WS"); return !(e && e[0] == '1'); }();
-    int ws = 0;
     if (wide_ok && !force_deep) {
       if (force_wide == 6 || force_wide == 7) ws = gemm_ws_pick(a, 1) ? (force_wide == 6 ? 160 : 128) : 0;
       else if (!force_wide && force_tile == 0 && force_split == 0 && !ws_off) ws = gemm_ws_pick(a, 224);
     }
+    static const bool halo_on = [] { const char* e = getenv("DFH_GEMM_HALO"); return e && e[0] == '1'; }();
+    halo = wide_ok && !force_deep && gemm_halo_eligible(a) && (force_wide == 15 || (wide == 1 && !force_wide && halo_on));
+#else
+    DFH_REQUIRE(force_wide != 6 && force_wide != 7 && force_wide != 15 && !(force_wide >= 8 && force_wide <= 14),
+                "tile ids 11-20 are probe kernels: build scripts/probes (make -C scripts/probes) and load it with DFH_LIB");
+#endif
     if (ws) gemm_pick_tile_order(a, split, 256, ws);
     else if (wide) gemm_pick_tile_order(a, split, wide == 2 ? 128 : 256, wide == 3 ? 320 : (wide == 4 ? 128 : 160));
     else gemm_pick_tile_order(a, split, kTiles[tile].bm, kTiles[tile].bn);
     if (force_wide == 6 || force_wide == 7) wide = 0;                      // not eligible (odd N, transposed / fp32 output): the default tile runs
-    // tile id 20 (force_wide 15) pins the halo-patch conv kernel (gemm_halo.hip).  It halves the staged bytes of a 64x64-level conv
-    // and is bit-identical to the wide kernel, but no faster (conv3x3 class 6.96 -> 6.93 ms per step in a same-box A/B, 271 vs 268 us
-    // on zero-filled operands): the k-loop is not paced by its staging alone, so it stays opt-in: DFH_GEMM_HALO=1.
-    static const bool halo_on = [] { const char* e = getenv("DFH_GEMM_HALO"); return e && e[0] == '1'; }();
-    const bool halo = wide_ok && !force_deep && gemm_halo_eligible(a) && (force_wide == 15 || (wide == 1 && !force_wide && halo_on));
     if (force_wide == 15) wide = halo ? 1 : 0;
     // output statistics for the consuming GroupNorm: only the 256 x 160 epilogue writes them, on full tiles inside one image
     const bool gst_ok = a.gstat && (halo || (wide == 1 && !ws)) && a.gstat_cpg > 0 && 160 % a.gstat_cpg == 0 && a.N % 160 == 0 &&
                         a.N % a.gstat_cpg == 0 && a.M % 256 == 0 && a.gstat_hw % 256 == 0 && a.act != ACT_GEGLU;
     if (!gst_ok) a.gstat = nullptr;
     else if (gstat_written) *gstat_written = true;
+#ifdef DFH_PROBES
     if (halo) rc = gemm_halo_launch(a, stream);
     else if (ws) rc = gemm_ws_launch(a, stream, ws);
-    else if (wide) rc = gemm_wide_launch(a, stream, wide);
+    else
+#endif
+    if (wide) rc = gemm_wide_launch(a, stream, wide);
     else rc = launch_variant(tile, a, stream);
+    census(wide ? CK_GEMM_WIDE : ((halo || ws) ? CK_GEMM_OTHER : (tile == kEightWave ? (lean_plain(a) ? CK_GEMM_LEAN : CK_GEMM_8WAVE) : CK_GEMM_OTHER)));
+    if (a.gstat) census(CK_GSTAT_WRITTEN);
   }
   if (rc) return rc;
   if (split > 1) {
     const long total4 = ((long)a.M * a.N) / 4;
     ProfScope ps(PC_SPLITK, 0.0, (double)split * a.M * a.N * 4.0 + (double)a.M * a.N * 2.0, stream);
+    census(CK_SPLITK);
     hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, a);
     return check_launch("gemm_splitk_reduce");
   }

@@ -385,8 +385,10 @@ static int wide_launch_t(GemmArgs a, hipStream_t s) {
 }
 
 int gemm_wide_launch(GemmArgs a, hipStream_t s, int variant) {
-  if (variant == 3) return wide_launch_t<256, 320, 4, 4>(a, s);
   if (variant == 4) return wide_launch_t<256, 128, 2, 3>(a, s);
+#ifdef DFH_PROBES   // experiment tiles (eight-wave 256 x 320, 128-row sibling) and the k-loop ablations: probe builds only
+  if (variant == 3) return wide_launch_t<256, 320, 4, 4>(a, s);
+  if (variant == 2) return wide_launch_t<128, 160, 2, 3>(a, s);
   switch (variant) {                                 // ablation probes (see the kernel's ABL note)
     case 8: return wide_launch_t<256, 160, 2, 3, 1>(a, s);
     case 9: return wide_launch_t<256, 160, 2, 3, 2>(a, s);
@@ -396,7 +398,10 @@ int gemm_wide_launch(GemmArgs a, hipStream_t s, int variant) {
     case 13: return wide_launch_t<256, 160, 2, 3, 6>(a, s);
     default: break;
   }
-  return variant == 2 ? wide_launch_t<128, 160, 2, 3>(a, s) : wide_launch_t<256, 160, 2, 3>(a, s);
+#else
+  DFH_REQUIRE(variant == 1, "wide-kernel variants 2 / 3 / 8-13 are probe instantiations (make -C scripts/probes)");
+#endif
+  return wide_launch_t<256, 160, 2, 3>(a, s);
 }
 
 }  // namespace dfh

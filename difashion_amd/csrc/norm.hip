@@ -448,6 +448,7 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
     DFH_REQUIRE(block <= 1024, "block too large");
     a.partial = const_cast<float*>(a.pre); a.chunks = a.pre_chunks;
     ProfScope ps(PC_GNORM, 0.0, 4.0 * a.B * (double)a.HW * a.C, stream);
+    census(CK_GN_PRE);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(achunks, a.B), dim3(block), 0, stream, a);
     return check_launch("gn_apply_kernel");
   }
@@ -459,6 +460,7 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
     if ((cpg & 3) == 0 && units <= 256 * small_max && one_source_per_group && (long)a.B * a.G >= 64) {
       ProfScope ps(PC_GNORM, 0.0, 4.0 * a.B * (double)a.HW * a.C, stream);
       const dim3 grid(a.G, a.B);
+      census(CK_GN_SMALL);
       if (units <= 256 * 8) hipLaunchKernelGGL(gn_small_kernel<8>, grid, dim3(256), 0, stream, a);
       else if (units <= 256 * 16) hipLaunchKernelGGL(gn_small_kernel<16>, grid, dim3(256), 0, stream, a);
       else hipLaunchKernelGGL(gn_small_kernel<32>, grid, dim3(256), 0, stream, a);
@@ -484,6 +486,7 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
         if (units > 32) continue;
         ProfScope ps(PC_GNORM, 0.0, 4.0 * a.B * (double)a.HW * a.C, stream);
         const dim3 grid(a.G / gq, a.B), block(threads);
+        census(CK_GN_MID);
         if (units <= 4) hipLaunchKernelGGL(gn_mid_kernel<4>, grid, block, 0, stream, a, gq, ppb);
         else if (units <= 8) hipLaunchKernelGGL(gn_mid_kernel<8>, grid, block, 0, stream, a, gq, ppb);
         else if (units <= 16) hipLaunchKernelGGL(gn_mid_kernel<16>, grid, block, 0, stream, a, gq, ppb);
@@ -499,6 +502,7 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
   const size_t lds = (size_t)a.PL * a.C * 2 * sizeof(float);
   DFH_REQUIRE(lds <= 64 * 1024, "GroupNorm LDS reduction too large");
   ProfScope ps(PC_GNORM, 0.0, 4.0 * a.B * (double)a.HW * a.C, stream);   // algorithmic: one read + one write (bf16)
+  census(CK_GN_STATS);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(a.chunks, a.B), dim3(block), lds, stream, a);
   if (int rc = check_launch("gn_stats_kernel")) return rc;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(achunks, a.B), dim3(block), 0, stream, a);
@@ -510,6 +514,7 @@ int layernorm_launch(const bf16_t* x, const float* gamma, const float* beta, bf1
   DFH_REQUIRE(C % 8 == 0 && C <= 8 * 64 * 4, "LayerNorm width must be a multiple of 8 and <= 2048");
   const dim3 block(256);
   ProfScope ps(PC_LNORM, 0.0, 4.0 * (double)M * C, stream);
+  census(CK_LAYERNORM);
   if (C <= 512) hipLaunchKernelGGL((layernorm_kernel<1, 4>), dim3((M + 15) / 16), block, 0, stream, x, gamma, beta, y, M, C, eps);
   else if (C <= 1024) hipLaunchKernelGGL((layernorm_kernel<2, 2>), dim3((M + 7) / 8), block, 0, stream, x, gamma, beta, y, M, C, eps);
   else hipLaunchKernelGGL((layernorm_kernel<4, 1>), dim3((M + 3) / 4), block, 0, stream, x, gamma, beta, y, M, C, eps);

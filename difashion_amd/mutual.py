@@ -126,7 +126,7 @@ class MutualEncoder(nn.Module):
         d.act = act
         d.out, d.ld_out, d.out_mode = out.data_ptr(), N, out_mode
         d.zero_page = zero.data_ptr()
-        d.force_glds = -1
+        d.force_order = -1
         need = _lib.raw().dfh_gemm_partial_floats(C.byref(d))
         part = None
         if need:

@@ -46,6 +46,13 @@ typedef struct dfh_prof_class {
 int dfh_prof_begin(void);
 int dfh_prof_end(dfh_prof_class* out, int max_classes);   /* returns the number of classes written (7) */
 
+/* Launch census: how many times each kernel family was launched since the last reset (host-side counters bumped by the launchers).
+ * Test infrastructure for "which kernels did this walk take" (tests/test_gpu_unet.py: the batch-16 forward of the bench workload). */
+void dfh_census_reset(void);
+int dfh_census_count(void);
+const char* dfh_census_name(int i);
+long dfh_census_get(int i);
+
 /* ------------------------------------------------------------------ U-Net context
  * Replaces: diffusers UNet2DConditionModel as constructed at df.py:77-93 (in_channels widened to
  * 8) and called at df.py:249-253 (training) and df.py:518-523 (sampling). */
@@ -195,7 +202,7 @@ typedef struct dfh_gemm_desc {
   void* out; int ld_out; int out_mode;          /* 0 bf16 [M][ld] 1 bf16 [b][N][ld] 2 fp32 [M][ld] 3 fp32 [b][N][ld] */
   float* partial; size_t partial_floats;        /* split-K slabs (dfh_gemm_partial_floats) */
   const void* zero_page;                        /* >= 256 zero bytes */
-  int force_tile, force_split, force_glds;      /* 0,0,-1 = heuristics */
+  int force_tile, force_split, force_order;     /* 0,0,-1 = heuristics; force_order 2 / 3 = tile ids n-major / m-major */
   float* gstat; int gstat_cpg, gstat_hw;        /* optional: GroupNorm statistics of the output for the consumer (channels per group,
                                                  * pixels per image): [image][group][hw / 256][2] sums / sums of squares; written only
                                                  * by the 256 x 160 tile, and only through dfh_gemm_gstat (dfh_gemm ignores the three fields) */

@@ -49,7 +49,7 @@ def run(name, M, N, K, conv=None, bias=True, resid=True, out_mode=0, act=0, tile
     if out_mode in (1, 3):            # transposed per batch: [b][n][rows_per_b], 16 batches
         d.rows_per_b, d.ld_out = M // 16, M // 16
     z = torch.zeros(256, dtype=torch.uint8, device=DEV); keep.append(z); d.zero_page = z.data_ptr()
-    d.force_tile, d.force_split, d.force_glds = tile, split, glds
+    d.force_tile, d.force_split, d.force_order = tile, split, glds
     need = _lib.raw().dfh_gemm_partial_floats(C.byref(d))
     if need:
         p = torch.empty(need, device=DEV); keep.append(p); d.partial, d.partial_floats = p.data_ptr(), need

@@ -1,0 +1,51 @@
+"""Parity of the probe-only kernels (scripts/probes/kernels): run with the probe library loaded,
+    make -C scripts/probes && DFH_LIB=scripts/probes/build/libdifashion_probes.so python -m pytest scripts/probes/tests -q
+Not part of tests/ (the product library does not contain these kernels)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+from tests import gpu_util as gu  # noqa: E402
+from tests.gpu_util import bf, rnd  # noqa: E402
+
+pytestmark = pytest.mark.skipif("probes" not in os.environ.get("DFH_LIB", ""), reason="needs DFH_LIB=<probe library>")
+
+
+@pytest.mark.parametrize("cin,cout,H,W,B", [
+    (64, 160, 16, 16, 3),     # 16-wide level: one tile = one whole image, the patch is the zero-padded image
+    (96, 200, 32, 32, 2),     # 32-wide: 8 rows per tile; C_out not a multiple of the 160-column tile
+    (32, 64, 8, 64, 2),       # 64-wide: 4 rows per tile, 2 tiles per image (top and bottom borders in different tiles)
+    (64, 320, 64, 64, 1),     # the 64x64 level itself: interior tiles with halo rows on both sides
+    (160, 96, 24, 32, 2),     # height not a power of two
+])
+def test_conv3x3_halo_patch_kernel(cin, cout, H, W, B):
+    """gemm_halo.hip (tile id 20): the pixels of a channel slice are staged once as a (rows + 2) x (W + 2) patch and the nine taps
+    read it at shifted offsets.  Against fp32 conv2d of the same bf16 operands, with bias, per-image time-embedding row and residual
+    (the wide kernel's epilogue), and bit for bit against the wide kernel (same MFMA order of accumulation per output)."""
+    x = bf(rnd(B, cin, H, W, seed=26))
+    w = rnd(cout, cin, 3, 3, seed=27, scale=0.05)
+    bias = rnd(cout, seed=28)
+    temb = rnd(B, 2 * cout, seed=29)
+    res = bf(rnd(B * H * W, cout, seed=30))
+    kw = dict(M=B * H * W, N=cout, W=gu.pack_conv(w), ldw=9 * cin, conv_src=gu.nhwc(x), conv_c=cin, batch=B, Hin=H, Win=W, stride=1,
+              upsample=0, bias=bias, rowvec=temb, rv_ld=2 * cout, rv_off=cout, rows_per_b=H * W, resid=res)
+    out = gu.gemm(force_tile=20, **kw)
+    ref = F.conv2d(x.float(), bf(w).float(), bias, padding=1) + temb[:, cout:, None, None]
+    ref = ref + gu.nchw(res.float().view(B, H, W, cout))
+    gu.assert_close_bf16(gu.nchw(out.view(B, H, W, cout)), ref, f"halo conv {cin}->{cout}@{H}x{W}")
+    wide = gu.gemm(force_tile=6, **kw)
+    assert torch.equal(out, wide), "halo and wide kernels accumulate the same products in the same order"
+
+
+@pytest.mark.parametrize("tile", [7, 8, 11, 12])    # 128-row wide sibling, eight-wave 256 x 320, wave-specialised 160 / 128
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (128, 160, 64), (16, 1280, 200)])
+def test_probe_gemm_tiles(tile, M, N, K):
+    a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05))
+    bias = rnd(N, seed=3)
+    res = bf(rnd(M, N, seed=4))
+    out = gu.gemm(M=M, N=N, W=w, ldw=K, a0=a, a0_c=K, bias=bias, resid=res, force_tile=tile)
+    gu.assert_close_bf16(out, a.float() @ w.float().T + bias + res.float(), f"probe tile {tile}")

@@ -29,7 +29,7 @@ def stream():
 
 def gemm(*, M, N, W, ldw, a0=None, a0_c=0, a1=None, a1_c=0, conv_src=None, conv_c=0, batch=0, Hin=0, Win=0, stride=1,
          upsample=0, bias=None, rowvec=None, rv_ld=0, rv_off=0, rows_per_b=0, resid=None, act=0, out_mode=0,
-         out=None, ld_out=None, force_tile=0, force_split=0, force_glds=-1, gstat=None, gstat_cpg=0, gstat_hw=0):
+         out=None, ld_out=None, force_tile=0, force_split=0, force_order=-1, gstat=None, gstat_cpg=0, gstat_hw=0):
     """gstat: a float32 device tensor for the output's GroupNorm statistics (dfh_gemm_gstat); the call then returns (out, written)."""
     d = _lib.GemmDesc()
     if conv_src is not None:
@@ -55,7 +55,7 @@ def gemm(*, M, N, W, ldw, a0=None, a0_c=0, a1=None, a1_c=0, conv_src=None, conv_
     d.out, d.ld_out = out.data_ptr(), ld_out
     z = zero_page()
     d.zero_page = z.data_ptr()
-    d.force_tile, d.force_split, d.force_glds = force_tile, force_split, force_glds
+    d.force_tile, d.force_split, d.force_order = force_tile, force_split, force_order
     need = _lib.raw().dfh_gemm_partial_floats(C.byref(d))
     part = None
     if need:

@@ -16,16 +16,16 @@ pytestmark = pytest.mark.gpu
 
 
 # ----------------------------------------------------------------------------- GEMM (linear / 1x1 conv)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])  # every tile / pipeline-depth variant of gemm.hip; 6-9 = gemm_wide.hip; 10 = eight-wave 128x160; 11 / 12 = gemm_ws.hip
-@pytest.mark.parametrize("glds", [1])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 9, 10])  # every tile / pipeline-depth variant of gemm.hip; 6 / 9 = gemm_wide.hip (256x160 / 256x128); 10 = eight-wave 128x160
+@pytest.mark.parametrize("order", [-1, 2, 3])     # tile enumeration: heuristic / n-major / m-major (placement never changes results)
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (128, 160, 64), (77 * 3, 64, 768), (16, 1280, 200), (4, 256, 2048)])
-def test_gemm_plain(tile, glds, M, N, K):
+def test_gemm_plain(tile, order, M, N, K):
     a, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=0.05))
     bias = rnd(N, seed=3)
     res = bf(rnd(M, N, seed=4))
-    out = gu.gemm(M=M, N=N, W=w, ldw=K, a0=a, a0_c=K, bias=bias, resid=res, force_tile=tile, force_glds=glds)
+    out = gu.gemm(M=M, N=N, W=w, ldw=K, a0=a, a0_c=K, bias=bias, resid=res, force_tile=tile, force_order=order)
     ref = a.float() @ w.float().T + bias + res.float()
-    gu.assert_close_bf16(out, ref, f"gemm {M}x{N}x{K} tile{tile} glds{glds}")
+    gu.assert_close_bf16(out, ref, f"gemm {M}x{N}x{K} tile{tile} order{order}")
 
 
 @pytest.mark.parametrize("split", [2, 5])
@@ -50,7 +50,7 @@ def test_gemm_two_sources_is_channel_concat():
     gu.assert_close_bf16(out, ref, "concat")
 
 
-@pytest.mark.parametrize("tile", [0, 6, 7, 8, 9, 11, 12])
+@pytest.mark.parametrize("tile", [0, 6, 9])
 @pytest.mark.parametrize("act,fn", [(1, F.silu), (2, lambda x: F.leaky_relu(x, 0.01)), (3, torch.tanh)])
 def test_gemm_activations_and_rowvec(act, fn, tile):
     B, rows, N, K = 3, 40, 128, 96
@@ -63,8 +63,7 @@ def test_gemm_activations_and_rowvec(act, fn, tile):
     gu.assert_close_bf16(out, ref, f"act{act}")
 
 
-@pytest.mark.parametrize("M,C,tile", [(200, 64, 0), (300, 40, 0), (300, 40, 6), (520, 80, 6), (300, 40, 7), (300, 40, 8), (700, 80, 8),
-                                         (300, 64, 9), (700, 80, 9), (256, 16, 9), (300, 40, 11), (700, 80, 11), (300, 64, 12), (520, 80, 12)])
+@pytest.mark.parametrize("M,C,tile", [(200, 64, 0), (300, 40, 0), (300, 40, 6), (520, 80, 6), (300, 64, 9), (700, 80, 9), (256, 16, 9)])
 def test_gemm_geglu_epilogue(M, C, tile):
     """FeedForward GEGLU: proj -> chunk(2) -> a * gelu(gate); weights/bias interleaved by dfh_pack_*."""
     x = bf(rnd(M, C, seed=15))
@@ -101,7 +100,7 @@ def test_gemm_transposed_outputs():
     (64, 4, 16, 1, 0),      # conv_out shape class
     (128, 128, 2, 1, 0),    # 2x2 level of the tiny configs: every tap hits padding somewhere
 ])
-@pytest.mark.parametrize("glds", [0, 1, 4, 6, 7, 8, 9, 10, 11, 12])   # here: forced tile variant (0 = heuristic, 1 = 256x160 ring, 4 = 128x160 2-stage, 6 = wide)
+@pytest.mark.parametrize("glds", [0, 1, 4, 6, 9, 10])   # here: forced tile variant (0 = heuristic, 1 = 256x160 ring, 4 = 128x160 2-stage, 6 = wide)
 def test_conv3x3(cin, cout, H, stride, ups, glds):
     B = 2
     x = bf(rnd(B, cin, H, H, seed=20))
@@ -115,7 +114,7 @@ def test_conv3x3(cin, cout, H, stride, ups, glds):
     gu.assert_close_bf16(gu.nchw(out.view(B, Ho, Ho, cout)), ref, f"conv {cin}->{cout}@{H} s{stride} u{ups}")
 
 
-@pytest.mark.parametrize("tile", [0, 1, 6, 10, 11])
+@pytest.mark.parametrize("tile", [0, 1, 6, 10])
 @pytest.mark.parametrize("cin,H,W", [(64, 12, 20), (128, 5, 3), (192, 16, 1)])
 def test_conv3x3_lean_tap_staging_on_non_square_inputs(cin, H, W, tile):
     """The lean tap staging (centre-pixel offset + 9-bit validity mask per staging piece) on inputs whose height and
@@ -131,35 +130,8 @@ def test_conv3x3_lean_tap_staging_on_non_square_inputs(cin, H, W, tile):
     gu.assert_close_bf16(gu.nchw(out.view(B, H, W, cout)), ref, f"conv {cin}->{cout}@{H}x{W} tile{tile}")
 
 
-@pytest.mark.parametrize("cin,cout,H,W,B", [
-    (64, 160, 16, 16, 3),     # 16-wide level: one tile = one whole image, the patch is the zero-padded image
-    (96, 200, 32, 32, 2),     # 32-wide: 8 rows per tile; C_out not a multiple of the 160-column tile
-    (32, 64, 8, 64, 2),       # 64-wide: 4 rows per tile, 2 tiles per image (top and bottom borders in different tiles)
-    (64, 320, 64, 64, 1),     # the 64x64 level itself: interior tiles with halo rows on both sides
-    (160, 96, 24, 32, 2),     # height not a power of two
-])
-def test_conv3x3_halo_patch_kernel(cin, cout, H, W, B):
-    """gemm_halo.hip (tile id 20): the pixels of a channel slice are staged once as a (rows + 2) x (W + 2) patch and the nine taps
-    read it at shifted offsets.  Against fp32 conv2d of the same bf16 operands, with bias, per-image time-embedding row and residual
-    (the wide kernel's epilogue), and bit for bit against the wide kernel (same MFMA order of accumulation per output)."""
-    x = bf(rnd(B, cin, H, W, seed=26))
-    w = rnd(cout, cin, 3, 3, seed=27, scale=0.05)
-    bias = rnd(cout, seed=28)
-    temb = rnd(B, 2 * cout, seed=29)
-    res = bf(rnd(B * H * W, cout, seed=30))
-    kw = dict(M=B * H * W, N=cout, W=gu.pack_conv(w), ldw=9 * cin, conv_src=gu.nhwc(x), conv_c=cin, batch=B, Hin=H, Win=W, stride=1,
-              upsample=0, bias=bias, rowvec=temb, rv_ld=2 * cout, rv_off=cout, rows_per_b=H * W, resid=res)
-    out = gu.gemm(force_tile=20, **kw)
-    ref = F.conv2d(x.float(), bf(w).float(), bias, padding=1) + temb[:, cout:, None, None]
-    ref = ref + gu.nchw(res.float().view(B, H, W, cout))
-    gu.assert_close_bf16(gu.nchw(out.view(B, H, W, cout)), ref, f"halo conv {cin}->{cout}@{H}x{W}")
-    wide = gu.gemm(force_tile=6, **kw)
-    assert torch.equal(out, wide), "halo and wide kernels accumulate the same products in the same order"
-
-
 @pytest.mark.parametrize("kind,cin,cout,H,B,tile", [
     ("conv", 64, 320, 32, 2, 6),      # 3x3 conv on the wide kernel: 4 row tiles per image, cpg 10 (16 groups per column tile)
-    ("conv", 64, 320, 32, 2, 20),     # the halo-patch kernel shares the epilogue
     ("conv", 32, 640, 16, 3, 6),      # one row tile per image, cpg 20
     ("linear", 320, 320, 32, 2, 6),   # proj_out shape class: linear + residual
 ])
@@ -210,7 +182,7 @@ def test_gemm_writes_groupnorm_statistics_for_its_consumer(kind, cin, cout, H, B
     assert not w2
 
 
-@pytest.mark.parametrize("tile", [0, 6, 7, 8, 9, 11, 12])
+@pytest.mark.parametrize("tile", [0, 6, 9])
 def test_conv3x3_with_fused_shortcut_and_temb(tile):
     """ResnetBlock2D tail: conv2(h) + conv_shortcut(cat(x, skip)) + biases, and conv1 + time embedding."""
     B, H, c0, c1, cout = 2, 8, 64, 32, 96

@@ -4,8 +4,10 @@ real reference glue and (b) the oracle run on identical inputs.
 Tolerances: step-0 U-Net input differs from the reference only through the bf16 MutualEncoder GEMMs
 scaled by eta=0.1 -> atol 2e-3.  Later quantities pass through the bf16 U-Net and guidance scales up
 to 12, so they are compared in relative L2: raw U-Net output <= 3e-2 at EVERY step under teacher forcing (the oracle's
-trajectory feeds both U-Nets), final latents of the free-running sampler <= 8e-2 after 6-10 steps and <= 0.15 after 50
-(observed values are printed: ~1.6e-2 and ~0.01-0.06)."""
+trajectory feeds both U-Nets), final latents of the free-running sampler <= 8e-2 after 6-10 steps AND after 50
+(observed values are printed: ~1.6e-2 and ~0.01-0.06); the product sampler's combined guided epsilon is checked at step 0,
+where the trajectories have not yet diverged (the guidance mix u + 4(a-cm) + 5(cm-c) + 12(c-u) amplifies the per-branch
+error by its coefficients: bound 0.25, see test_sampler_vs_reference_golden)."""
 import glob
 import os
 
@@ -81,7 +83,14 @@ def test_sampler_vs_reference_golden(case, unet):
     ef = rel_err(final.cpu(), rec["final"])
     print(case, f"unet_out_0 {e0:.2e} unet_out_last {el:.2e} final {ef:.2e}")
     assert e0 <= 3e-2
-    assert ef <= (8e-2 if int(rec["steps"]) <= 10 else 0.15)
+    assert ef <= 8e-2
+    # the COMBINED guided epsilon of the product sampler at step 0 (same latents on both sides: no trajectory divergence yet), against
+    # the oracle's combination of the golden per-branch predictions -- guards the guidance mix / scale plumbing inside sample_outfits
+    mode, _ = glue_ref.cfg_plan(sc, sh, sm, bool(rec["use_history"]), bool(rec["use_mutual"]))
+    eps_ref = glue_ref.cfg_combine(mode, rec["unet_out_0"], sc, sh, sm)
+    eps_err = rel_err(taps["eps_0"].cpu(), eps_ref)
+    print(case, f"eps_0 {eps_err:.2e}")
+    assert eps_err <= 0.25
 
 
 @pytest.mark.parametrize("case", ["gor_full_ddim10", "mix_full_pndm10", "gor_full_ddim50"])
@@ -120,7 +129,7 @@ def test_sampler_teacher_forced_every_step(case, unet):
                             num_inference_steps=steps, cate_scale=sc, hist_scale=sh, mutual_scale=sm)
     lat_err = rel_err(got.cpu(), ref)
     print(case, "free-running final latents", f"{lat_err:.2e}")
-    assert lat_err <= (8e-2 if steps <= 10 else 0.15)
+    assert lat_err <= 8e-2
 
 
 @pytest.mark.parametrize("case", TRAIN)

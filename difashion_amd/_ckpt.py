@@ -4,7 +4,8 @@ diffusers 0.18.2 (the reference's pin, README.md:27) writes ``diffusion_pytorch_
 (``save_pretrained(safe_serialization=False)``) -- the reference's own save hook (train.py:518-524: ``unet``, ``unet_ema``,
 ``fashion_encoder``, ``fashion_encoder_ema``) therefore produces ``.bin`` directories, and many published snapshots carry
 only ``.bin``.  ``load_weights`` takes ``.safetensors`` when present and falls back to ``.bin`` (``torch.load(weights_only=True)``),
-honouring diffusers' ``variant`` infix (``diffusion_pytorch_model.fp16.safetensors``).
+honouring diffusers' ``variant`` infix (``diffusion_pytorch_model.fp16.safetensors``).  A requested variant that does not
+exist is an error (diffusers raises too): silently loading the plain file would hand the caller other weights than asked for.
 """
 from __future__ import annotations
 
@@ -17,9 +18,8 @@ WEIGHTS_STEM = "diffusion_pytorch_model"
 
 
 def weight_candidates(variant: Optional[str] = None):
-    stems = [f"{WEIGHTS_STEM}.{variant}"] if variant else []
-    stems.append(WEIGHTS_STEM)
-    return [s + ext for s in stems for ext in (".safetensors", ".bin")]
+    stem = f"{WEIGHTS_STEM}.{variant}" if variant else WEIGHTS_STEM
+    return [stem + ext for ext in (".safetensors", ".bin")]
 
 
 def load_weights(directory: str, variant: Optional[str] = None) -> Dict[str, torch.Tensor]:
@@ -34,7 +34,8 @@ def load_weights(directory: str, variant: Optional[str] = None) -> Dict[str, tor
             return load_file(f)
         sd = torch.load(f, map_location="cpu", weights_only=True)
         return sd.get("state_dict", sd) if isinstance(sd, dict) else sd
-    raise FileNotFoundError(f"no weights in {directory!r}: looked for {', '.join(tried)}")
+    what = f"no '{variant}' variant weights" if variant else "no weights"
+    raise FileNotFoundError(f"{what} in {directory!r}: looked for {', '.join(tried)}")
 
 
 # diffusers < 0.15 named the single-head VAE mid-block attention differently; diffusers 0.18.2 renames on load

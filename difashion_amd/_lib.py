@@ -91,6 +91,9 @@ SIGNATURES = {
     "dfh_unet_bind": (_i, [_vp, _vp, _vp, _vp, _sz, _i]),
     "dfh_unet_pack": (_i, [_vp, C.POINTER(_vp), _i, _vp]),
     "dfh_unet_forward": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "dfh_unet_run_cache_bytes": (_sz, [_vp, _i, _i]),
+    "dfh_unet_run_cache": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "dfh_unet_forward_cached": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "dfh_unet_debug_tap": (_i, [_vp, C.c_char_p, _vp, _sz, _vp]),
     "dfh_vae_create": (_i, [C.POINTER(VAEConfigC), C.POINTER(_vp)]),
     "dfh_vae_destroy": (None, [_vp]),
@@ -150,6 +153,8 @@ SIGNATURES = {
     "dfh_ema": (_i, [_vp, _vp, _sz, _f, _vp]),
     "dfh_adamw_ema": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp]),
     "dfh_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "dfh_ln_fold": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "dfh_gemm_ln": (_i, [C.POINTER(GemmDesc), _vp, C.POINTER(C.c_int), _vp, _i, _i, _f, _vp, _vp]),
     "dfh_quantize_rows_fp8": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
     "dfh_layernorm_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "dfh_gemm_fp8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),

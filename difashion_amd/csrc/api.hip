@@ -306,6 +306,27 @@ int dfh_layernorm(const void* x, const float* gamma, const float* beta, void* y,
   return dfh::layernorm_launch((const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps, (hipStream_t)stream);
 }
 
+// LayerNorm folded into the GEMMs around it (gemm.h, lnfold.hip)
+int dfh_ln_fold(const void* W, int ldw, const float* gamma, const float* beta, const float* bias, void* WF, float* s, float* b, int N, int K,
+                void* stream) {
+  return dfh::ln_fold_launch((const bf16_t*)W, ldw, gamma, beta, bias, (bf16_t*)WF, s, b, N, K, (hipStream_t)stream);
+}
+
+int dfh_gemm_ln(const dfh_gemm_desc* d, float* rowstat, int* rowstat_bn, const float* ln_stat, int ln_parts, int ln_cnt, float ln_eps,
+                const float* ln_s, void* stream) {
+  GemmArgs g;
+  if (int rc = fill_gemm(d, &g)) return rc;
+  const size_t need = d->force_split > 1 ? (size_t)d->force_split * g.M * g.N : dfh::gemm_partial_floats(g);
+  DFH_REQUIRE(need == 0 || (d->partial && d->partial_floats >= need), "partial buffer too small for split-K");
+  g.rowstat = rowstat;
+  g.ln_stat = ln_stat; g.ln_parts = ln_parts; g.ln_cnt = ln_cnt; g.ln_eps = ln_eps; g.ln_s = ln_s;
+  if (ln_stat) DFH_REQUIRE(dfh::gemm_ln_consumer_ok(g), "this launch shape cannot consume folded-LayerNorm statistics (split-K / unstaged GEGLU)");
+  int bn = 0;
+  const int rc = dfh::gemm_launch(g, (hipStream_t)stream, d->force_tile, d->force_split, d->force_order, nullptr, &bn);
+  if (rowstat_bn) *rowstat_bn = bn;
+  return rc;
+}
+
 int dfh_gemm_fp8(const void* A, const float* sA, const void* W, const float* sW, int M, int N, int K, const float* bias,
                  const void* resid, int ld_res, int act, void* out, int ld_out, int out_mode, int rows_per_b, const void* zero_page,
                  void* stream) {

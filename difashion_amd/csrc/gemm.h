@@ -43,6 +43,15 @@ struct GemmArgs {
   //     the launch eligible: per (image, group, row tile) the sum and the sum of squares of the bf16-rounded outputs, in the layout
   //     gn_apply_kernel reads ([image][group][chunk][2], chunk = row tile inside the image), so the consumer skips gn_stats_kernel
   float* gstat; int gstat_cpg, gstat_hw;   // channels per group of the consuming GroupNorm; pixels per image
+  // --- LayerNorm folded into the GEMMs around it (transformer blocks, inference walk).  LN(x) . W^T = rstd * (x . W'^T - mean * s) + b'
+  //     with W' = W * gamma (per input channel), s[n] = sum_k W'[n][k], b'[n] = bias[n] + sum_k W[n][k] * beta[k]: the consumer runs on
+  //     the RAW rows x with W' as its weights, b' as its bias and fixes each output row up in the epilogue; the per-row statistics
+  //     come from the epilogue of the GEMM that produced x.
+  //   producer: rowstat != null -> per output row and column tile the mean and the centred sum of squares of the bf16-rounded outputs,
+  //             layout [N / BN][M][2] (one 8-byte record per row and column tile; equal counts BN, combined exactly by the consumer)
+  //   consumer: ln_stat = the producer's rowstat, ln_parts = its column tiles, ln_cnt = its BN, ln_s = s, bias = b'
+  float* rowstat;
+  const float* ln_stat; int ln_parts, ln_cnt; float ln_eps; const float* ln_s;
 };
 
 // fp8 (OCP e4m3fn) linear: out[m][n] = epilogue(sA[m] * sW[n] * sum_k A8[m][k] * W8[n][k]); gemm_fp8.hip
@@ -58,6 +67,25 @@ struct Fp8GemmArgs {
   const uint8_t* zero;                  // >= 16 bytes of zeros in device memory
 };
 
+#ifdef __HIPCC__
+// (mean, rstd) of row m of a folded-LayerNorm consumer: the producer's per-column-tile records (mean_t, M2_t over ln_cnt columns each)
+// combined exactly (equal counts: mean = average of the means, M2 = sum M2_t + cnt * sum (mean_t - mean)^2), fixed order
+DFH_DEVICE float2 ln_row_stats(const GemmArgs& a, int m) {
+  if (m >= a.M) return float2{0.f, 1.f};
+  float mean = 0.f;
+  for (int t = 0; t < a.ln_parts; ++t) mean += a.ln_stat[((long)t * a.M + m) * 2];
+  mean *= 1.0f / (float)a.ln_parts;
+  float m2 = 0.f;
+  for (int t = 0; t < a.ln_parts; ++t) {
+    const float2 r = *(const float2*)(a.ln_stat + ((long)t * a.M + m) * 2);
+    const float d = r.x - mean;
+    m2 += r.y + (float)a.ln_cnt * d * d;
+  }
+  const float var = m2 / (float)(a.ln_parts * a.ln_cnt);
+  return float2{mean, rsqrtf(var + a.ln_eps)};
+}
+#endif
+
 namespace dfh {
 int gemm_fp8_launch(const Fp8GemmArgs& a, hipStream_t stream);
 // bf16 [R][K] (row stride ldx) -> e4m3 [R][K] + one scale per row (amax / 448)
@@ -68,7 +96,13 @@ int layernorm_fp8_launch(const bf16_t* x, const float* gamma, const float* beta,
 // Picks a tile shape + split-K factor, launches, and (if split) launches the reduce.  ``partial``
 // must hold gemm_partial_floats(...) floats when the heuristic splits.
 int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile = 0, int force_split = 0, int force_order = -1,
-                bool* gstat_written = nullptr);   // *gstat_written: whether a.gstat was filled (only the 256 x 160 epilogue can)
+                bool* gstat_written = nullptr,    // *gstat_written: whether a.gstat was filled (only the 256 x 160 epilogue can)
+                int* rowstat_bn = nullptr);       // *rowstat_bn: column tile of the a.rowstat records written (0 = none: kernel / shape cannot)
+// lnfold.hip: W' = bf16(W * gamma) [N][K], s[n] = sum_k W'[n][k], b[n] = bias[n] (or 0) + sum_k W[n][k] * beta[k]
+int ln_fold_launch(const bf16_t* W, int ldw, const float* gamma, const float* beta, const float* bias, bf16_t* WF, float* s, float* b,
+                   int N, int K, hipStream_t stream);
+// can a launch of this shape consume folded-LayerNorm statistics (single pass, an epilogue that implements the fix-up)?
+bool gemm_ln_consumer_ok(GemmArgs a);
 int gemm_pick_split(const GemmArgs& a, int* tile_out);
 size_t gemm_partial_floats(const GemmArgs& a);
 int gemm_count_ksteps(const GemmArgs& a);

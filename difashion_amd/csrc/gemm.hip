@@ -263,7 +263,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
         ++issued;
       }
     }
+    // the first wait below counts the residual loads as the NEWEST operations in flight (+NRES): pin them behind the prologue's
+    // LDS-DMA pieces -- plain global loads and global_load_lds do not alias, so nothing else keeps the scheduler from hoisting them
+    __builtin_amdgcn_sched_barrier(0);
     if (res_pre) fetch_resid();
+    __builtin_amdgcn_sched_barrier(0);
     int buf = 0;
     for (int t = 0; t < nk; ++t) {
       // stages beyond t already in flight may stay in flight: wait only for stage t's pieces
@@ -318,19 +322,28 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
     // global load per lane, then unconditional ds_reads per fragment.  Loaded per fragment inside `if (a.bias)`, hipcc kept
     // every load behind its branch: ten dependent L2 round trips, 4.4-5.5k cycles of a tile whose K = 320 loop takes 6.6k
     // (in-kernel stamps); batched into registers they cost 8 VGPRs too many for two workgroups per CU.
-    constexpr int STRIP = 2 * TN * 4;                // bias | rowvec, fp32
-    static_assert(BM * RS + NWV * STRIP <= NSTAGE * STAGE, "bias strips must fit behind the staged output tile");
+    constexpr int STRIP = 2 * TN * 4;                // bias | rowvec (or the folded-LayerNorm s slice), fp32
+    constexpr int LNROW = BM * RS + NWV * STRIP;     // folded LayerNorm: (mean, rstd) of the tile's rows, fp32 pairs
+    static_assert(LNROW + BM * 8 <= NSTAGE * STAGE, "bias strips + row statistics must fit behind the staged output tile");
     float* strip = (float*)(smem + BM * RS + wave * STRIP);
+    const bool lnf = a.ln_stat != nullptr;
     // the time-embedding row is per image: through the strip when the whole tile lies in one image, else per fragment
-    const bool rv_lds = a.rowvec != nullptr && (m0 / a.rows_per_b) == ((min(m0 + BM, a.M) - 1) / a.rows_per_b);
+    const bool rv_lds = a.rowvec != nullptr && (a.rv_ld == 0 || (m0 / a.rows_per_b) == ((min(m0 + BM, a.M) - 1) / a.rows_per_b));   // rv_ld == 0: one row for every image (cached timestep row)
     float4 bq = float4{0.f, 0.f, 0.f, 0.f}, rq = bq;
     if (lane < TN / 4) {
       const int n = n0 + wn * TN + lane * 4;
       if (a.bias && n < a.N) bq = *(const float4*)(a.bias + n);
       if (rv_lds && n < a.N) rq = *(const float4*)(a.rowvec + (long)(m0 / a.rows_per_b) * a.rv_ld + a.rv_off + n);
+      if (lnf && n < a.N) rq = *(const float4*)(a.ln_s + n);
     }
+    float2 lnmr = float2{0.f, 1.f};
+    if (lnf && tid < BM) lnmr = ln_row_stats(a, m0 + tid);
     __syncthreads();                                 // every wave is done reading the last pipeline stage
     if (lane < TN / 4) { *(float4*)(strip + lane * 4) = bq; *(float4*)(strip + TN + lane * 4) = rq; }
+    if (lnf) {
+      if (tid < BM) *(float2*)(smem + LNROW + tid * 8) = lnmr;
+      __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int row = wm * TM + i * 16 + fr, m = m0 + row;
@@ -340,6 +353,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
         const int col = wn * TN + j * 16 + fg * 4, n = n0 + col;
         const float4 bv = *(const float4*)(strip + j * 16 + fg * 4);
         float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
+        if (lnf) {                                   // rstd * (acc - mean * s) + b'
+          const float2 mr = *(const float2*)(smem + LNROW + row * 8);
+          const float4 sv = *(const float4*)(strip + TN + j * 16 + fg * 4);
+          const float ms = -mr.x * mr.y;
+          v[0] = fmaf(mr.y, acc[i][j][0], fmaf(ms, sv.x, bv.x)); v[1] = fmaf(mr.y, acc[i][j][1], fmaf(ms, sv.y, bv.y));
+          v[2] = fmaf(mr.y, acc[i][j][2], fmaf(ms, sv.z, bv.z)); v[3] = fmaf(mr.y, acc[i][j][3], fmaf(ms, sv.w, bv.w));
+        }
         if (a.rowvec) {
           float4 rv;
           if (rv_lds) rv = *(const float4*)(strip + TN + j * 16 + fg * 4);
@@ -373,21 +393,67 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
       if (m < a.M && n < a.N)
         *(uint4*)((bf16_t*)a.out + (long)m * a.ld_out + n) = *(const uint4*)(smem + row * RS + cc * 16);
     }
+    if (a.rowstat) {
+      // Row statistics of this tile's bf16-rounded outputs for a LayerNorm folded into the consumer (gemm.h): TPR adjacent lanes share a
+      // row, two passes over the staged tile (mean, then the centred squares: no cancellation), fixed orders.  The launcher guarantees
+      // N % BN == 0 (whole column tiles).
+      constexpr int TPR = NWV * 64 / BM;             // 4 (eight-wave 128-row tile) or 2
+      static_assert(TPR == 2 || TPR == 4, "threads per row");
+      const int row = tid / TPR, part = tid % TPR;
+      const unsigned char* src = smem + row * RS;
+      float sum = 0.f;
+      for (int c = part; c < CPR; c += TPR) {
+        float f[8]; unpack8(*(const uint4*)(src + c * 16), f);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sum += f[r];
+      }
+      sum += __shfl_xor(sum, 1, 64);
+      if (TPR == 4) sum += __shfl_xor(sum, 2, 64);
+      const float mean = sum * (1.0f / BN);
+      float m2 = 0.f;
+      for (int c = part; c < CPR; c += TPR) {
+        float f[8]; unpack8(*(const uint4*)(src + c * 16), f);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const float d = f[r] - mean; m2 = fmaf(d, d, m2); }
+      }
+      m2 += __shfl_xor(m2, 1, 64);
+      if (TPR == 4) m2 += __shfl_xor(m2, 2, 64);
+      const int m = m0 + row;
+      if (part == 0 && m < a.M) *(float2*)(a.rowstat + ((long)nt_ * a.M + m) * 2) = float2{mean, m2};
+    }
     return;
   }
   if (staged_geglu) {
     // value * gelu(gate) on 16-column value/gate blocks: the tile's BN packed columns give BN/2 outputs per row
+    const bool lnf = a.ln_stat != nullptr;
+    constexpr int LNROWG = BM * RS;
+    static_assert(LNROWG + BM * 8 <= NSTAGE * STAGE, "row statistics must fit behind the staged output tile");
+    float2 lnmr = float2{0.f, 1.f};
+    if (lnf && tid < BM) lnmr = ln_row_stats(a, m0 + tid);
     __syncthreads();
+    if (lnf) {
+      if (tid < BM) *(float2*)(smem + LNROWG + tid * 8) = lnmr;
+      __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int row = wm * TM + i * 16 + fr;
+      float2 mr = float2{0.f, 1.f};
+      if (lnf) mr = *(const float2*)(smem + LNROWG + row * 8);
+      const float ms = -mr.x * mr.y;
 #pragma unroll
       for (int j = 0; j + 1 < FN; j += 2) {
         const int n = n0 + wn * TN + j * 16 + fg * 4;      // packed column of the "value" half
         float4 bv = float4{0, 0, 0, 0}, bg = float4{0, 0, 0, 0};
         if (a.bias && n + 16 < a.N) { bv = *(const float4*)(a.bias + n); bg = *(const float4*)(a.bias + n + 16); }
-        const float v[4] = {acc[i][j][0] + bv.x, acc[i][j][1] + bv.y, acc[i][j][2] + bv.z, acc[i][j][3] + bv.w};
-        const float g[4] = {acc[i][j + 1][0] + bg.x, acc[i][j + 1][1] + bg.y, acc[i][j + 1][2] + bg.z, acc[i][j + 1][3] + bg.w};
+        if (lnf && n + 16 < a.N) {                         // rstd * (acc - mean * s) + b' == rstd * acc + (b' - rstd * mean * s)
+          const float4 sv = *(const float4*)(a.ln_s + n), sg = *(const float4*)(a.ln_s + n + 16);
+          bv.x = fmaf(ms, sv.x, bv.x); bv.y = fmaf(ms, sv.y, bv.y); bv.z = fmaf(ms, sv.z, bv.z); bv.w = fmaf(ms, sv.w, bv.w);
+          bg.x = fmaf(ms, sg.x, bg.x); bg.y = fmaf(ms, sg.y, bg.y); bg.z = fmaf(ms, sg.z, bg.z); bg.w = fmaf(ms, sg.w, bg.w);
+        }
+        const float v[4] = {fmaf(mr.y, acc[i][j][0], bv.x), fmaf(mr.y, acc[i][j][1], bv.y), fmaf(mr.y, acc[i][j][2], bv.z), fmaf(mr.y, acc[i][j][3], bv.w)};
+        const float g[4] = {fmaf(mr.y, acc[i][j + 1][0], bg.x), fmaf(mr.y, acc[i][j + 1][1], bg.y), fmaf(mr.y, acc[i][j + 1][2], bg.z),
+                            fmaf(mr.y, acc[i][j + 1][3], bg.w)};
         const int ocl = ((wn * TN) >> 1) + (j >> 1) * 16 + fg * 4;      // output column inside the tile
         uint2 o;
         o.x = pack2bf(v[0] * gelu_erf_f(g[0]), v[1] * gelu_erf_f(g[1]));
@@ -410,6 +476,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
     const int m = m0 + wm * TM + i * 16 + fr;
     if (m >= a.M) continue;
     const int b = (a.rowvec || a.out_mode == OUT_BF16_T || a.out_mode == OUT_F32_T) ? m / a.rows_per_b : 0;
+    float2 lmr = float2{0.f, 1.f};
+    if (a.ln_stat) lmr = ln_row_stats(a, m);              // the launcher refuses ln_stat with split-K or the GEGLU branch below
     if (a.act == ACT_GEGLU && !partial) {
 #pragma unroll
       for (int j = 0; j + 1 < FN; j += 2) {
@@ -435,6 +503,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
       if (partial) {
         *(float4*)(a.partial + ((long)blockIdx.z * a.M + m) * a.N + n) = float4{v[0], v[1], v[2], v[3]};
         continue;
+      }
+      if (a.ln_stat) {
+        const float4 sv = *(const float4*)(a.ln_s + n);
+        const float ms = -lmr.x * lmr.y;
+        v[0] = fmaf(lmr.y, v[0], ms * sv.x); v[1] = fmaf(lmr.y, v[1], ms * sv.y);
+        v[2] = fmaf(lmr.y, v[2], ms * sv.z); v[3] = fmaf(lmr.y, v[3], ms * sv.w);
       }
       if (a.bias) {
         const float4 bv = *(const float4*)(a.bias + n);
@@ -656,8 +730,18 @@ static void gemm_pick_tile_order(GemmArgs& a, int split, int bm, int bn) {
   if (best != 8) { a.tm_xm = best; a.tm_gm = 8; }
 }
 
-int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split, int force_order, bool* gstat_written) {
+bool gemm_ln_consumer_ok(GemmArgs a) {
+  if (a.rows_per_b <= 0) a.rows_per_b = a.M;
+  a.ksteps = gemm_count_ksteps(a);
+  int tile;
+  if (gemm_pick_split(a, &tile) != 1) return false;                     // the split-K reduce does not implement the fix-up
+  if (a.act == ACT_GEGLU && ((a.ld_out & 7) || a.N % 32)) return false;  // ... nor does the unstaged GEGLU branch
+  return a.ntaps == 0 && a.resid == nullptr && a.rowvec == nullptr;
+}
+
+int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split, int force_order, bool* gstat_written, int* rowstat_bn) {
   if (gstat_written) *gstat_written = false;
+  if (rowstat_bn) *rowstat_bn = 0;
   DFH_REQUIRE(a.M > 0 && a.N > 0, "empty GEMM");
   DFH_REQUIRE(a.N % 4 == 0, "N must be a multiple of 4");
   DFH_REQUIRE(a.ntaps == 0 || a.ntaps == 9, "ntaps must be 0 or 9");
@@ -692,6 +776,11 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     if (force_order == 3) a.n_major = 0;
   }
   if (split > 1) DFH_REQUIRE(a.partial != nullptr, "split-K needs a partial buffer");
+  if (a.ln_stat) {
+    DFH_REQUIRE(split == 1 && a.ln_parts > 0 && a.ln_cnt > 0 && a.ln_s != nullptr && !a.rowvec && !a.resid,
+                "folded LayerNorm: single-pass launches without rowvec / residual only (gemm_ln_consumer_ok)");
+    DFH_REQUIRE(a.act != ACT_GEGLU || (a.ld_out & 7) == 0, "folded LayerNorm + GEGLU needs 16-byte aligned output rows");
+  }
   if (a.resid) DFH_REQUIRE((double)a.M * a.ld_res * 2.0 < 4.0e9, "residual tensor must be smaller than 4 GB (32-bit lane offsets)");
   int rc;
   {
@@ -731,6 +820,14 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
                         a.N % a.gstat_cpg == 0 && a.M % 256 == 0 && a.gstat_hw % 256 == 0 && a.act != ACT_GEGLU;
     if (!gst_ok) a.gstat = nullptr;
     else if (gstat_written) *gstat_written = true;
+    // per-row output statistics for a LayerNorm folded into the consumer: the staged bf16 epilogue of gemm_bf16_kernel and the 256-row
+    // epilogue write them, on whole column tiles
+    {
+      const int bn = wide == 1 ? 160 : (wide == 4 ? 128 : (wide || ws ? 0 : kTiles[tile].bn));
+      const bool staged_ok = split == 1 && a.out_mode == OUT_BF16 && a.act != ACT_GEGLU && (a.N & 7) == 0 && (a.ld_out & 7) == 0;
+      if (!(a.rowstat && bn > 0 && staged_ok && a.N % bn == 0 && !halo)) a.rowstat = nullptr;
+      else if (rowstat_bn) *rowstat_bn = bn;
+    }
 #ifdef DFH_PROBES
     if (halo) rc = gemm_halo_launch(a, stream);
     else if (ws) rc = gemm_ws_launch(a, stream, ws);

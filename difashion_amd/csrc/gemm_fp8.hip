@@ -377,6 +377,7 @@ int gemm_fp8_launch(const Fp8GemmArgs& a, hipStream_t stream) {
   if (a.act == ACT_GEGLU) DFH_REQUIRE(a.N % 32 == 0 && !a.resid && a.out_mode == OUT_BF16, "fp8 GEGLU: N % 32 == 0, bias only, bf16 out");
   if (a.out_mode == OUT_BF16) DFH_REQUIRE(a.ld_out % 8 == 0, "fp8 GEMM: output rows must be 16-byte aligned");
   if (a.out_mode == OUT_BF16_T) DFH_REQUIRE(a.rows_per_b > 0 && !a.resid, "fp8 GEMM: transposed output needs rows_per_b, no residual");
+  census(CK_GEMM_FP8);
   ProfScope ps(PC_LINEAR_FP8, 2.0 * a.M * a.N * (double)a.K,
                (double)a.M * a.K + (double)a.N * a.K + 2.0 * a.M * (a.act == ACT_GEGLU ? a.N / 2 : a.N), stream);
   // 256-row tiles while they still give every CU two workgroups, 128-row tiles below

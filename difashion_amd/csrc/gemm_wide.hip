@@ -287,21 +287,40 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
   if constexpr (FN % 2 == 0) {
     if (a.act == ACT_GEGLU) {
       constexpr int RSG = BN + 16;                     // bf16 row stride of the staged [BM][BN / 2] tile (bytes)
-      static_assert(BM * RSG <= NSTAGE * STAGE, "staged GEGLU tile must fit the pipeline buffers");
+      constexpr int LNROWG = BM * RSG;                 // folded LayerNorm (gemm.h): (mean, rstd) of the tile's rows behind the staged tile
+      static_assert(LNROWG + BM * 8 <= NSTAGE * STAGE, "staged GEGLU tile + row statistics must fit the pipeline buffers");
+      static_assert(BM <= NWV * 64, "one thread per tile row");
+      const bool lnf = a.ln_stat != nullptr;
+      float2 lnmr = float2{0.f, 1.f};
+      if (lnf && tid < BM) lnmr = ln_row_stats(a, m0 + tid);
       __syncthreads();                                 // every wave is done reading the last pipeline stage
-      float4 bv[FN / 2], bg[FN / 2];
+      if (lnf) {
+        if (tid < BM) *(float2*)(smem + LNROWG + tid * 8) = lnmr;
+        __syncthreads();
+      }
+      float4 bv[FN / 2], bg[FN / 2], sv[FN / 2], sg[FN / 2];
 #pragma unroll
       for (int jj = 0; jj < FN / 2; ++jj) {
         const int n = n0 + wn * TN + jj * 32 + fg * 4;
-        bv[jj] = float4{0, 0, 0, 0}; bg[jj] = float4{0, 0, 0, 0};
+        bv[jj] = float4{0, 0, 0, 0}; bg[jj] = float4{0, 0, 0, 0}; sv[jj] = bv[jj]; sg[jj] = bv[jj];
         if (a.bias && n + 16 < a.N) { bv[jj] = *(const float4*)(a.bias + n); bg[jj] = *(const float4*)(a.bias + n + 16); }
+        if (lnf && n + 16 < a.N) { sv[jj] = *(const float4*)(a.ln_s + n); sg[jj] = *(const float4*)(a.ln_s + n + 16); }
       }
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         const int row = wm * TM + i * 16 + fr;
+        float2 mr = float2{0.f, 1.f};
+        if (lnf) mr = *(const float2*)(smem + LNROWG + row * 8);
+        const float ms = -mr.x * mr.y;                 // rstd * (acc - mean * s) + b' == rstd * acc + (b' - rstd * mean * s)
 #pragma unroll
         for (int jj = 0; jj < FN / 2; ++jj) {
-          const f32x4_t v = acc[i][2 * jj], g = acc[i][2 * jj + 1];
+          f32x4_t v = acc[i][2 * jj], g = acc[i][2 * jj + 1];
+          if (lnf) {
+            v[0] = fmaf(mr.y, v[0], ms * sv[jj].x); v[1] = fmaf(mr.y, v[1], ms * sv[jj].y);
+            v[2] = fmaf(mr.y, v[2], ms * sv[jj].z); v[3] = fmaf(mr.y, v[3], ms * sv[jj].w);
+            g[0] = fmaf(mr.y, g[0], ms * sg[jj].x); g[1] = fmaf(mr.y, g[1], ms * sg[jj].y);
+            g[2] = fmaf(mr.y, g[2], ms * sg[jj].z); g[3] = fmaf(mr.y, g[3], ms * sg[jj].w);
+          }
           uint2 o;
           o.x = pack2bf((v[0] + bv[jj].x) * gelu_erf_f(g[0] + bg[jj].x), (v[1] + bv[jj].y) * gelu_erf_f(g[1] + bg[jj].y));
           o.y = pack2bf((v[2] + bv[jj].z) * gelu_erf_f(g[2] + bg[jj].z), (v[3] + bv[jj].w) * gelu_erf_f(g[3] + bg[jj].w));
@@ -339,6 +358,7 @@ int gemm_wide_ksteps(const GemmArgs& a) {
 // 1 = 256 x 160, 4 = 256 x 128 (N a multiple of 128 but not of 160), 0 = not eligible; 2 / 3 are experiment variants
 int gemm_wide_pick(const GemmArgs& a) {
   if (a.out_mode != OUT_BF16) return 0;
+  if (a.ln_stat && !(a.act == ACT_GEGLU && a.N % 128 == 0)) return 0;   // only the in-register GEGLU epilogue implements the LayerNorm fix-up
   if (a.act == ACT_GEGLU && (a.resid || a.rowvec)) return 0;
   if ((a.N & 7) || (a.ld_out & 7) || (a.resid && (a.ld_res & 7))) return 0;
   // GEGLU: the 256 x 128 sibling keeps whole (value, gate) block pairs inside a wave -> epilogue in registers

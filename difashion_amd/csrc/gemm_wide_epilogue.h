@@ -40,6 +40,7 @@ DFH_DEVICE void wide_epilogue(const GemmArgs& a, f32x4_t (&acc)[BM / 2 / 16][BN 
   // t < BN sums column t over the 64 rows in row order, and after the last pass the columns are folded into groups: fixed orders
   // throughout, no atomics.  The launcher guarantees full tiles inside one image and BN % cpg == 0.
   const bool gst = a.gstat != nullptr;
+  const bool rst = a.rowstat != nullptr;             // per-row statistics of the output for a folded LayerNorm (gemm.h): full column tiles only
   constexpr int CQ = BN / 4;                        // column quads; thread t < 4 * CQ sums quad t % CQ over rows (t / CQ) * 16 .. + 15
   static_assert(4 * CQ <= NWV * 64, "one thread per (column quad, row quarter)");
   float4 col_s = float4{0.f, 0.f, 0.f, 0.f}, col_q = col_s;
@@ -49,7 +50,7 @@ DFH_DEVICE void wide_epilogue(const GemmArgs& a, f32x4_t (&acc)[BM / 2 / 16][BN 
   // chunk it was EPI dependent L2 round trips in each of the four passes of every resnet conv1
   constexpr int RV_OFF = BIAS_OFF + BN * 4;
   static_assert(RV_OFF + BN * 4 <= LDS_BYTES, "bias + rowvec slices must fit behind the pass tile");
-  const bool rv_lds = a.rowvec != nullptr && (m0 / a.rows_per_b) == ((min(m0 + BM, a.M) - 1) / a.rows_per_b);
+  const bool rv_lds = a.rowvec != nullptr && (a.rv_ld == 0 || (m0 / a.rows_per_b) == ((min(m0 + BM, a.M) - 1) / a.rows_per_b));   // rv_ld == 0: one row for every image (cached timestep row)
   float4 bias_reg = make_float4(0.f, 0.f, 0.f, 0.f), rv_reg = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.bias && tid < BN / 4 && n0 + tid * 4 < a.N) bias_reg = *(const float4*)(a.bias + n0 + tid * 4);
   if (rv_lds && tid < BN / 4 && n0 + tid * 4 < a.N)
@@ -149,11 +150,33 @@ DFH_DEVICE void wide_epilogue(const GemmArgs& a, f32x4_t (&acc)[BM / 2 / 16][BN 
       }
       const uint4 packed = pack8(v);
       *(uint4*)((bf16_t*)a.out + (long)m * a.ld_out + n) = packed;
-      if (gst) {                                       // this thread read the slot, nobody else touches it in this pass
+      if (gst || rst) {                                // this thread read the slot, nobody else touches it in this pass
         float f[8];
         unpack8(packed, f);
         *(float4*)(smem + row * RSF + cchunk * 32) = float4{f[0], f[1], f[2], f[3]};
         *(float4*)(smem + row * RSF + cchunk * 32 + 16) = float4{f[4], f[5], f[6], f[7]};
+      }
+    }
+    if (rst) {
+      // four adjacent lanes per row of the 64-row pass, two passes over the rounded values (mean, then centred squares), fixed orders
+      static_assert(NWV * 64 >= 256, "four threads per row of a 64-row pass");
+      __syncthreads();
+      if (tid < 256) {
+        const int row = tid >> 2, part = tid & 3;
+        const unsigned char* src = smem + row * RSF;
+        float sum = 0.f;
+        for (int c = part; c < BN / 4; c += 4) { const float4 x = *(const float4*)(src + c * 16); sum += (x.x + x.y) + (x.z + x.w); }
+        sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64);
+        const float mean = sum * (1.0f / BN);
+        float m2 = 0.f;
+        for (int c = part; c < BN / 4; c += 4) {
+          const float4 x = *(const float4*)(src + c * 16);
+          const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
+          m2 = fmaf(d0, d0, m2); m2 = fmaf(d1, d1, m2); m2 = fmaf(d2, d2, m2); m2 = fmaf(d3, d3, m2);
+        }
+        m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64);
+        const int m = m0 + q * 64 + row;
+        if (part == 0 && m < a.M) *(float2*)(a.rowstat + ((long)(n0 / BN) * a.M + m) * 2) = float2{mean, m2};
       }
     }
     if (gst) {

@@ -1,0 +1,61 @@
+// LayerNorm folded into the projection that consumes it (inference walk of the transformer blocks; reference call site
+// DiFashion/models/difashion.py:518-523 -> diffusers BasicTransformerBlock: x + attn1(LN1(x)), x + attn2(LN2(x), ctx), x + ff(LN3(x))).
+//
+//   LN(x)[k] = (x[k] - mean) * rstd * gamma[k] + beta[k]
+//   LN(x) . W[n]  =  rstd * ( x . W'[n]  -  mean * s[n] )  +  b'[n],     W'[n][k] = W[n][k] * gamma[k],
+//                                                                        s[n]  = sum_k W'[n][k]      (of the bf16-ROUNDED W': the
+//                                                                                 cancellation against x . W' must be exact),
+//                                                                        b'[n] = bias[n] + sum_k W[n][k] * beta[k]
+// so the GEMM runs on the raw rows x (no LayerNorm kernel, no normalised copy of the tensor in HBM) and its epilogue applies the two
+// per-row scalars (gemm.h GemmArgs::ln_stat).  This kernel derives W', s and b' from the packed bf16 matrix whenever the weights are
+// packed: one block per output row.  Works on any packed row order (GEGLU-interleaved rows carry their bias in the same order).
+#include "gemm.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__ W, int ldw, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ bias,
+                                                      bf16_t* __restrict__ WF, float* __restrict__ s_out, float* __restrict__ b_out, int K) {
+  const int n = blockIdx.x;
+  const bf16_t* w = W + (long)n * ldw;
+  bf16_t* wf = WF + (long)n * K;
+  float s = 0.f, b = 0.f;
+  for (int k = threadIdx.x * 8; k < K; k += 256 * 8) {          // K is a multiple of 8 (16-byte rows)
+    float f[8], o[8];
+    unpack8(*(const uint4*)(w + k), f);
+    const float4 g0 = *(const float4*)(gamma + k), g1 = *(const float4*)(gamma + k + 4);
+    const float4 e0 = *(const float4*)(beta + k), e1 = *(const float4*)(beta + k + 4);
+    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { o[r] = f[r] * g[r]; b = fmaf(f[r], e[r], b); }
+    const uint4 packed = pack8(o);
+    *(uint4*)(wf + k) = packed;
+    unpack8(packed, o);                                           // the rounded values are what the MFMA multiplies
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += o[r];
+  }
+  __shared__ float red[2][4];
+  s = wave_sum(s); b = wave_sum(b);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = s; red[1][wave] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_out[n] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    b_out[n] = (bias ? bias[n] : 0.f) + ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+  }
+}
+
+}  // namespace
+
+namespace dfh {
+
+int ln_fold_launch(const bf16_t* W, int ldw, const float* gamma, const float* beta, const float* bias, bf16_t* WF, float* s, float* b,
+                   int N, int K, hipStream_t stream) {
+  DFH_REQUIRE(W && gamma && beta && WF && s && b, "null pointer");
+  DFH_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0, "K and the row stride must be multiples of 8");
+  hipLaunchKernelGGL(ln_fold_kernel, dim3(N), dim3(256), 0, stream, W, ldw, gamma, beta, bias, WF, s, b, K);
+  return check_launch("ln_fold_kernel");
+}
+
+}  // namespace dfh

@@ -94,6 +94,36 @@ int dfh_unet_forward(dfh_unet* u, const void* sample, int sample_bf16, const flo
   return u->run(sample, sample_bf16, timestep, ehs, ehs_bf16, out, batch, (hipStream_t)stream, false);
 }
 
+size_t dfh_unet_run_cache_bytes(const dfh_unet* u, int batch, int n_timesteps) {
+  return (u && batch > 0 && n_timesteps >= 0) ? u->run_cache_bytes(batch, n_timesteps) : 0;
+}
+
+int dfh_unet_run_cache(dfh_unet* u, const void* ehs, int ehs_bf16, int batch, const float* timesteps, int n_timesteps, void* cache,
+                       size_t cache_bytes, void* stream) {
+  DFH_REQUIRE(u && ehs && cache && (timesteps || n_timesteps == 0), "null argument");
+  DFH_REQUIRE(u->ws != nullptr, "dfh_unet_bind not called");
+  DFH_REQUIRE(batch > 0 && batch <= u->max_batch, "batch exceeds the bound max_batch");
+  DFH_REQUIRE((uintptr_t)cache % 256 == 0 && cache_bytes >= u->run_cache_bytes(batch, n_timesteps), "run cache too small or misaligned");
+  return u->run_cache(ehs, ehs_bf16, batch, timesteps, n_timesteps, cache, (hipStream_t)stream);
+}
+
+int dfh_unet_forward_cached(dfh_unet* u, const void* sample, int sample_bf16, const void* cache, int batch, int n_timesteps, int t_index,
+                            float* out, void* stream) {
+  DFH_REQUIRE(u && sample && cache && out, "null argument");
+  DFH_REQUIRE(u->ws != nullptr, "dfh_unet_bind not called");
+  DFH_REQUIRE(batch > 0 && batch <= u->max_batch, "batch exceeds the bound max_batch");
+  DFH_REQUIRE(t_index >= 0 && t_index < n_timesteps, "timestep index outside the cached schedule");
+  DFH_REQUIRE(!u->fp8 || u->arena8, "fp8 enabled but dfh_unet_bind_fp8 not called");
+  if (batch != u->plan_batch) u->run(nullptr, 0, nullptr, nullptr, 0, nullptr, batch, nullptr, true);
+  DFH_REQUIRE(u->plan_total <= u->ws_bytes, "workspace too small for this batch");
+  dfh_unet::RunCache rc;
+  rc.kx = (const bf16_t*)cache;
+  rc.vxt = (const bf16_t*)((const char*)cache + dfh_unet::cache_kx_bytes(*u, batch));
+  rc.temb_row = (const float*)((const char*)cache + dfh_unet::cache_kx_bytes(*u, batch) + dfh_unet::cache_vxt_bytes(*u, batch)) +
+                (size_t)t_index * u->temb_total;
+  return u->run(sample, sample_bf16, nullptr, nullptr, 0, out, batch, (hipStream_t)stream, false, &rc);
+}
+
 }  // extern "C"
 
 // debug tap: NHWC bf16 -> NCHW fp32

@@ -41,8 +41,13 @@ struct ResL {
   Vec n1w, n1b, b1, n2w, n2b, b2; Mat w1, w2;
   std::string pre; Mat w1t, w2t, wst;   // training: transposed packs for the data-gradient GEMMs
 };
+// A LayerNorm-fed projection with the LayerNorm folded in (lnfold.hip): W' (bf16 elements) / s / b' (floats) offsets inside the fold
+// region at the head of the workspace
+struct Fold { size_t w = 0, s = 0, b = 0; int N = 0, K = 0; };
+
 struct AttL {
   int C = 0, heads = 0, x_off = 0;   // x_off: this layer's row offset in the batched cross K / V matrices
+  Fold fqk, fv, fq2, fff1;
   Vec nw, nb, pinb, l1w, l1b, o1b, l2w, l2b, o2b, l3w, l3b, ff1b, ff2b, poutb;
   Mat pin, qk, v, o1, q2, o2, ff1, ff2, pout;
   std::string pre; Mat pint, qkvt, o1t, q2t, o2t, ff1t, ff2t, poutt;
@@ -111,6 +116,19 @@ struct dfh_unet {
   ConvL conv_in, conv_out;
   Mat te1, te2, tproj, kx_all, vx_all; Vec te1b, te2b, tprojb, cnw, cnb;
   int temb_total = 0, x_total = 0;   // x_total: sum of C over all transformer layers (batched text K/V)
+  // folded-LayerNorm copies of the LayerNorm-fed projections (derived data, re-made by every pack): they live at the head of the
+  // WORKSPACE, not in arena16 / arena32 -- the training path sizes its gradient arenas and its all-reduce by those
+  size_t fold16 = 0, fold32 = 0; bool fold_valid = false;
+  size_t fold_bytes() const { return ((fold16 * 2 + 255) & ~(size_t)255) + ((fold32 * 4 + 255) & ~(size_t)255); }
+  bf16_t* fold_w() const { return (bf16_t*)ws; }
+  float* fold_v() const { return (float*)(ws + ((fold16 * 2 + 255) & ~(size_t)255)); }
+  Fold fold_alloc(int N, int K) {
+    Fold f; f.N = N; f.K = K;
+    f.w = fold16; fold16 += ((size_t)N * K + 127) & ~(size_t)127;
+    f.s = fold32; fold32 += (N + 63) & ~63;
+    f.b = fold32; fold32 += (N + 63) & ~63;
+    return f;
+  }
   std::vector<std::vector<ResL>> down_res, up_res;
   std::vector<std::vector<AttL>> down_att, up_att;
   std::vector<ConvL> down_samp, up_samp;
@@ -236,6 +254,7 @@ struct dfh_unet {
     a.ff2b = vec(tb + ".ff.net.2.bias", C);
     a.pout = mat(pre + ".proj_out.weight", C, C, !lin);
     a.poutb = vec(pre + ".proj_out.bias", C);
+    a.fqk = fold_alloc(2 * C, C); a.fv = fold_alloc(C, C); a.fq2 = fold_alloc(C, C); a.fff1 = fold_alloc(8 * C, C);
   }
 
   void build_conv(const std::string& pre, int cout, int cin, ConvL& c) {
@@ -378,12 +397,33 @@ struct dfh_unet {
     return 0;
   }
 
+  // W' / s / b' of every LayerNorm-fed projection from the freshly packed bf16 matrices (needs the workspace: after dfh_unet_bind)
+  int fold_layernorms(hipStream_t s) {
+    fold_valid = false;
+    if (!ws || !arena16 || !arena32) return 0;
+    for (AttL* a : all_att()) {
+      if (a->C % 8) continue;
+      const Mat* src[4] = {&a->qk, &a->v, &a->q2, &a->ff1};
+      const Fold* dst[4] = {&a->fqk, &a->fv, &a->fq2, &a->fff1};
+      const Vec* gam[4] = {&a->l1w, &a->l1w, &a->l2w, &a->l3w};
+      const Vec* bet[4] = {&a->l1b, &a->l1b, &a->l2b, &a->l3b};
+      for (int i = 0; i < 4; ++i) {
+        const float* bias = i == 3 ? arena32 + a->ff1b.off : nullptr;
+        if (int rc = dfh::ln_fold_launch(arena16 + src[i]->off, src[i]->K, arena32 + gam[i]->off, arena32 + bet[i]->off, bias,
+                                         fold_w() + dst[i]->w, fold_v() + dst[i]->s, fold_v() + dst[i]->b, src[i]->N, src[i]->K, s)) return rc;
+      }
+    }
+    fold_valid = true;
+    return 0;
+  }
+
   // ---------------------------------------------------------------- run
   struct Run {
     dfh_unet* u; int B; hipStream_t s; bool dry;
     Bump persist, temp; size_t partial_need = 0;
     float* partial = nullptr; size_t partial_cap = 0;
     float* gn_partial = nullptr; bf16_t* zero = nullptr;
+    int temb_ld = 0;                 // row stride of the time-embedding rows: temb_total, or 0 when the whole batch shares one cached row
     int rc = 0;
 
     bf16_t* w16(const Mat& m) const { return u->arena16 + m.off; }
@@ -393,7 +433,9 @@ struct dfh_unet {
 
     // o / bump: the output tensor and the allocator it came from when the output feeds a GroupNorm -- the epilogue then leaves
     // that GroupNorm's statistics beside it (64x64 level: the launches the 256 x 160 tile takes).  DFH_GN_PRE=0 turns it off (A/B).
-    void gemm(GemmArgs g, Tensor* o = nullptr, Bump* bump = nullptr) {
+    // rs_bn (out): column tile of the row statistics the launch wrote into g.rowstat (0 = none)
+    void gemm(GemmArgs g, Tensor* o = nullptr, Bump* bump = nullptr, int* rs_bn = nullptr) {
+      if (rs_bn) *rs_bn = 0;
       if (rc) return;
       g.zero = zero; g.partial = partial;
       static const bool pre_off = [] { const char* e = getenv("DFH_GN_PRE"); return e && e[0] == '0'; }();
@@ -406,7 +448,7 @@ struct dfh_unet {
       if (dry) { partial_need = std::max(partial_need, dfh::gemm_partial_floats(g) * sizeof(float)); return; }
       if (dfh::gemm_partial_floats(g) * sizeof(float) > partial_cap) { dfh::set_error("split-K partial buffer too small"); rc = -1; return; }
       bool written = false;
-      rc = dfh::gemm_launch(g, s, 0, 0, -1, &written);
+      rc = dfh::gemm_launch(g, s, 0, 0, -1, &written, rs_bn);
       if (o && written) { o->gst = gst; o->gst_cpg = g.gstat_cpg; o->gst_chunks = g.gstat_hw / 256; }
     }
     static GemmArgs base(int M, int N) {
@@ -415,8 +457,10 @@ struct dfh_unet {
       return g;
     }
     // out = act(x . W^T + bias) (+resid); x rows [M][K]
+    // rowstat / rs_bn: ask the launch for the per-row statistics of its output (a LayerNorm folded into the consumers, gemm.h)
     void linear(const bf16_t* x, int M, int K, const Mat& W, const Vec* bias, int act, const bf16_t* resid, void* out,
-                int N, int out_mode = OUT_BF16, int ld_out = -1, int rows_per_b = 0, Tensor* o = nullptr, Bump* bump = nullptr) {
+                int N, int out_mode = OUT_BF16, int ld_out = -1, int rows_per_b = 0, Tensor* o = nullptr, Bump* bump = nullptr,
+                float* rowstat = nullptr, int* rs_bn = nullptr) {
       GemmArgs g = base(M, N);
       g.p_src[0] = x; g.p_c[0] = K; g.nplain = 1;
       g.W = w16(W); g.ldw = W.K;
@@ -424,7 +468,20 @@ struct dfh_unet {
       g.act = act; g.resid = resid; g.ld_res = N;
       g.out = out; g.out_mode = out_mode; g.ld_out = ld_out < 0 ? (act == ACT_GEGLU ? N / 2 : N) : ld_out;
       if (rows_per_b) g.rows_per_b = rows_per_b;
-      gemm(g, o, bump);
+      g.rowstat = rowstat;
+      gemm(g, o, bump, rs_bn);
+    }
+    // the consumer of a folded LayerNorm: raw rows x [M][K] (K = C of the LayerNorm), statistics st ([C / st_bn][M][2]) from x's producer
+    GemmArgs folded(const bf16_t* x, int M, const Fold& f, const float* st, int st_bn, int act, void* out, int out_mode, int ld_out,
+                    int rows_per_b) const {
+      GemmArgs g = base(M, f.N);
+      g.p_src[0] = x; g.p_c[0] = f.K; g.nplain = 1;
+      g.W = u->fold_w() + f.w; g.ldw = f.K;
+      g.bias = u->fold_v() + f.b; g.ln_s = u->fold_v() + f.s;
+      g.ln_stat = st; g.ln_cnt = st_bn; g.ln_parts = st_bn > 0 ? f.K / st_bn : 0; g.ln_eps = 1e-5f;
+      g.act = act; g.out = out; g.out_mode = out_mode; g.ld_out = ld_out < 0 ? (act == ACT_GEGLU ? f.N / 2 : f.N) : ld_out;
+      if (rows_per_b) g.rows_per_b = rows_per_b;
+      return g;
     }
     void groupnorm(const Tensor& x0, const Tensor* x1, const Vec& w, const Vec& b, float eps, int silu, Tensor& out) {
       if (rc || dry) return;
@@ -492,7 +549,7 @@ struct dfh_unet {
         g.conv_src = g1.p; g.conv_c = r.cin; g.ntaps = 9;
         g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.stride = 1;
         g.W = w16(r.w1); g.ldw = r.w1.K; g.bias = v32(r.b1);
-        g.rowvec = temb_all; g.rv_ld = u->temb_total; g.rv_off = r.temb_off; g.rows_per_b = H * W;
+        g.rowvec = temb_all; g.rv_ld = temb_ld; g.rv_off = r.temb_off; g.rows_per_b = H * W;
         g.out = h1.p;
         gemm(g, &h1, &temp);
       }
@@ -522,44 +579,66 @@ struct dfh_unet {
       const size_t mark = temp.off;
       Tensor gn = talloc(H, W, C);
       groupnorm(x, nullptr, a.nw, a.nb, 1e-6f, 0, gn);
+      // LayerNorm folding (gemm.h, lnfold.hip): the GEMM that produces a LayerNorm's input leaves per-row statistics of its output, the
+      // projections behind the LayerNorm run on the raw rows with gamma folded into their weights and fix the rows up in their
+      // epilogue -- no layernorm_kernel launch, no normalised copy of the tensor.  Falls back to the LayerNorm kernel + plain weights
+      // whenever the producer ran on a kernel that writes no statistics or a consumer would split K.  DFH_LN_FOLD=0 turns it off (A/B).
+      static const bool fold_off = [] { const char* e = getenv("DFH_LN_FOLD"); return e && e[0] == '0'; }();
+      const bool f8 = use8(a.qk8);                    // fp8 path: LayerNorm -> e4m3 + token scales -> block-scaled MFMA GEMM
+      const bool fold = u->fold_valid && !fold_off && !f8 && !dry;
+      float* st = (float*)temp.alloc((size_t)M * ((C + 63) / 64) * 2 * sizeof(float));       // [C / bn][M][2], bn >= 64
+      int bn = 0;
+      auto try_folded = [&](std::initializer_list<GemmArgs> gs) {
+        if (!fold || bn <= 0 || C % bn) return false;
+        for (const GemmArgs& g : gs) if (!dfh::gemm_ln_consumer_ok(g)) return false;
+        for (const GemmArgs& g : gs) gemm(g);
+        dfh::census(dfh::CK_LN_FOLDED);
+        return true;
+      };
       Tensor h0 = talloc(H, W, C);
-      linear(gn.p, M, C, a.pin, &a.pinb, ACT_NONE, nullptr, h0.p, C);
+      linear(gn.p, M, C, a.pin, &a.pinb, ACT_NONE, nullptr, h0.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
       // --- self attention
       Tensor n1 = talloc(H, W, C);
-      const bool f8 = use8(a.qk8);                    // fp8 path: LayerNorm -> e4m3 + token scales -> block-scaled MFMA GEMM
       uint8_t* n8 = f8 ? (uint8_t*)temp.alloc((size_t)M * C) : nullptr;
       float* s8 = f8 ? (float*)temp.alloc((size_t)M * sizeof(float)) : nullptr;
-      if (f8) layernorm8(h0.p, a.l1w, a.l1b, n8, s8, M, C);
-      else layernorm(h0.p, a.l1w, a.l1b, n1.p, M, C);
       Tensor qk = talloc(H, W, 2 * C);
-      if (f8) linear8(n8, s8, M, a.qk8, nullptr, ACT_NONE, qk.p);
-      else linear(n1.p, M, C, a.qk, nullptr, ACT_NONE, nullptr, qk.p, 2 * C);
       const int Np = (N + 7) & ~7;    // V^T rows padded to 8 keys (the 2x2 level of tiny configs has N = 4)
       bf16_t* vt = (bf16_t*)temp.alloc((size_t)B * C * Np * 2);   // [B][C][Np]
-      if (f8) linear8(n8, s8, M, a.v8, nullptr, ACT_NONE, vt, OUT_BF16_T, Np, N);
-      else linear(n1.p, M, C, a.v, nullptr, ACT_NONE, nullptr, vt, C, OUT_BF16_T, Np, N);
+      if (!try_folded({folded(h0.p, M, a.fqk, st, bn, ACT_NONE, qk.p, OUT_BF16, -1, 0),
+                       folded(h0.p, M, a.fv, st, bn, ACT_NONE, vt, OUT_BF16_T, Np, N)})) {
+        if (f8) layernorm8(h0.p, a.l1w, a.l1b, n8, s8, M, C);
+        else layernorm(h0.p, a.l1w, a.l1b, n1.p, M, C);
+        if (f8) linear8(n8, s8, M, a.qk8, nullptr, ACT_NONE, qk.p);
+        else linear(n1.p, M, C, a.qk, nullptr, ACT_NONE, nullptr, qk.p, 2 * C);
+        if (f8) linear8(n8, s8, M, a.v8, nullptr, ACT_NONE, vt, OUT_BF16_T, Np, N);
+        else linear(n1.p, M, C, a.v, nullptr, ACT_NONE, nullptr, vt, C, OUT_BF16_T, Np, N);
+      }
       Tensor at = talloc(H, W, C);
       attention(qk.p, 2 * C, qk.p + C, 2 * C, vt, Np, at.p, C, a.heads, N, N);
       Tensor h1 = talloc(H, W, C);
-      linear(at.p, M, C, a.o1, &a.o1b, ACT_NONE, h0.p, h1.p, C);
+      linear(at.p, M, C, a.o1, &a.o1b, ACT_NONE, h0.p, h1.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
       // --- cross attention over the T text tokens
       const int Tp = (T + 7) & ~7;
-      if (f8) { layernorm8(h1.p, a.l2w, a.l2b, n8, s8, M, C); linear8(n8, s8, M, a.q28, nullptr, ACT_NONE, qk.p); }
-      else {
-        layernorm(h1.p, a.l2w, a.l2b, n1.p, M, C);
-        linear(n1.p, M, C, a.q2, nullptr, ACT_NONE, nullptr, qk.p, C);
+      if (!try_folded({folded(h1.p, M, a.fq2, st, bn, ACT_NONE, qk.p, OUT_BF16, -1, 0)})) {
+        if (f8) { layernorm8(h1.p, a.l2w, a.l2b, n8, s8, M, C); linear8(n8, s8, M, a.q28, nullptr, ACT_NONE, qk.p); }
+        else {
+          layernorm(h1.p, a.l2w, a.l2b, n1.p, M, C);
+          linear(n1.p, M, C, a.q2, nullptr, ACT_NONE, nullptr, qk.p, C);
+        }
       }
       // text K / V^T of this layer live inside the batched projections computed once per forward
       const int XT = u->x_total;
       attention(qk.p, C, kx + a.x_off, XT, vxt + (size_t)a.x_off * Tp, Tp, at.p, C, a.heads, N, T, (long)XT * Tp);
       Tensor h2 = talloc(H, W, C);
-      linear(at.p, M, C, a.o2, &a.o2b, ACT_NONE, h1.p, h2.p, C);
+      linear(at.p, M, C, a.o2, &a.o2b, ACT_NONE, h1.p, h2.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
       // --- GEGLU feed-forward
       Tensor ff = talloc(H, W, 4 * C);
-      if (f8) { layernorm8(h2.p, a.l3w, a.l3b, n8, s8, M, C); linear8(n8, s8, M, a.ff18, &a.ff1b, ACT_GEGLU, ff.p); }
-      else {
-        layernorm(h2.p, a.l3w, a.l3b, n1.p, M, C);
-        linear(n1.p, M, C, a.ff1, &a.ff1b, ACT_GEGLU, nullptr, ff.p, 8 * C);
+      if (!try_folded({folded(h2.p, M, a.fff1, st, bn, ACT_GEGLU, ff.p, OUT_BF16, -1, 0)})) {
+        if (f8) { layernorm8(h2.p, a.l3w, a.l3b, n8, s8, M, C); linear8(n8, s8, M, a.ff18, &a.ff1b, ACT_GEGLU, ff.p); }
+        else {
+          layernorm(h2.p, a.l3w, a.l3b, n1.p, M, C);
+          linear(n1.p, M, C, a.ff1, &a.ff1b, ACT_GEGLU, nullptr, ff.p, 8 * C);
+        }
       }
       linear(ff.p, M, 4 * C, a.ff2, &a.ff2b, ACT_NONE, h2.p, h0.p, C);   // h0 is dead by now: reuse
       linear(h0.p, M, C, a.pout, &a.poutb, ACT_NONE, x.p, out.p, C, OUT_BF16, -1, 0, &out, &persist);   // feeds the next block's GroupNorm
@@ -568,14 +647,26 @@ struct dfh_unet {
     }
   };
 
+  // Per-run constants of a sampling loop (reference DiFashion/models/difashion.py:340-357: the prompt states are fixed for the run;
+  // :456: the timesteps are the schedule's): the cross-attention K / V^T of every transformer block and the time-embedding rows
+  // (all time_emb_proj outputs) per schedule entry, computed once by run_cache() into a caller-owned buffer.
+  struct RunCache { const bf16_t* kx = nullptr; const bf16_t* vxt = nullptr; const float* temb_row = nullptr; };
+  static size_t cache_kx_bytes(const dfh_unet& u, int B) { return ((size_t)B * u.cfg.text_len * u.x_total * 2 + 255) & ~(size_t)255; }
+  static size_t cache_vxt_bytes(const dfh_unet& u, int B) { return ((size_t)B * u.x_total * ((u.cfg.text_len + 7) & ~7) * 2 + 255) & ~(size_t)255; }
+  size_t run_cache_bytes(int B, int n_t) const {
+    return cache_kx_bytes(*this, B) + cache_vxt_bytes(*this, B) + (((size_t)n_t * temb_total * 4 + 255) & ~(size_t)255);
+  }
+
   int run(const void* sample, int sample_bf16, const float* timestep, const void* ehs, int ehs_bf16, float* out, int B,
-          hipStream_t s, bool dry) {
+          hipStream_t s, bool dry, const RunCache* rcache = nullptr) {
     Run r; r.u = this; r.B = B; r.s = s; r.dry = dry;
+    r.temb_ld = (rcache && rcache->temb_row) ? 0 : temb_total;
     const int S = cfg.sample_size, T = cfg.text_len, X = cfg.cross_attention_dim;
     const int* boc = cfg.block_out_channels;
     const int nb = cfg.num_blocks, temb = boc[0] * 4;
     // fixed regions at the head of the workspace
-    Bump head; head.base = dry ? nullptr : ws;
+    char* const wsb = dry ? nullptr : ws + fold_bytes();      // the fold region comes first (fold_layernorms)
+    Bump head; head.base = wsb;
     r.zero = (bf16_t*)head.alloc(256);
     r.gn_partial = (float*)head.alloc((size_t)B * GN_MAX_CHUNKS * 64 * 2 * sizeof(float));
     r.partial = (float*)head.alloc(dry ? 0 : plan_partial);
@@ -583,9 +674,9 @@ struct dfh_unet {
     const size_t head_bytes = (head.off + 255) & ~(size_t)255;
     if (!dry) {
       if (B != plan_batch) { dfh::set_error("forward batch differs from the planned batch"); return -1; }
-      r.persist.base = ws + head_bytes;
-      r.temp.base = ws + head_bytes + plan_persist;
-      if (head_bytes + plan_persist + plan_temp > ws_bytes) { dfh::set_error("workspace too small"); return -1; }
+      r.persist.base = wsb + head_bytes;
+      r.temp.base = wsb + head_bytes + plan_persist;
+      if (fold_bytes() + head_bytes + plan_persist + plan_temp > ws_bytes) { dfh::set_error("workspace too small"); return -1; }
       (void)hipMemsetAsync(r.zero, 0, 256, s);
     }
     taps.clear();
@@ -596,14 +687,19 @@ struct dfh_unet {
     bf16_t* e1 = (bf16_t*)r.persist.alloc((size_t)B * temb * 2);
     bf16_t* e2 = (bf16_t*)r.persist.alloc((size_t)B * temb * 2);
     float* temb_all = (float*)r.persist.alloc((size_t)B * temb_total * 4);
-    if (!dry) r.rc = dfh::timestep_embed_launch(timestep, tsin, B, boc[0], s);
-    r.linear(tsin, B, boc[0], te1, &te1b, ACT_SILU, nullptr, e1, temb);
-    r.linear(e1, B, temb, te2, &te2b, ACT_SILU, nullptr, e2, temb);
-    r.linear(e2, B, temb, tproj, &tprojb, ACT_NONE, nullptr, temb_all, temb_total, OUT_F32);
+    const bool t_cached = rcache && rcache->temb_row, x_cached = rcache && rcache->kx && rcache->vxt;
+    if (!dry && !t_cached) r.rc = dfh::timestep_embed_launch(timestep, tsin, B, boc[0], s);
+    if (dry || !t_cached) {          // the dry run plans for the uncached walk (same workspace either way)
+      r.linear(tsin, B, boc[0], te1, &te1b, ACT_SILU, nullptr, e1, temb);
+      r.linear(e1, B, temb, te2, &te2b, ACT_SILU, nullptr, e2, temb);
+      r.linear(e2, B, temb, tproj, &tprojb, ACT_NONE, nullptr, temb_all, temb_total, OUT_F32);
+    } else {
+      temb_all = const_cast<float*>(rcache->temb_row);
+    }
 
     // ---- inputs to kernel layout
     bf16_t* ehs16 = (bf16_t*)r.persist.alloc((size_t)B * T * X * 2);
-    if (!dry && !r.rc) {
+    if (!dry && !r.rc && !x_cached) {
       if (ehs_bf16) (void)hipMemcpyAsync(ehs16, ehs, (size_t)B * T * X * 2, hipMemcpyDeviceToDevice, s);
       else r.rc = dfh::cast_f32_to_bf16_launch((const float*)ehs, ehs16, (long)B * T * X, s);
     }
@@ -611,8 +707,13 @@ struct dfh_unet {
     const int Tp = (T + 7) & ~7;
     bf16_t* kx = (bf16_t*)r.persist.alloc((size_t)B * T * x_total * 2);
     bf16_t* vxt = (bf16_t*)r.persist.alloc((size_t)B * x_total * Tp * 2);
-    r.linear(ehs16, B * T, X, kx_all, nullptr, ACT_NONE, nullptr, kx, x_total);
-    r.linear(ehs16, B * T, X, vx_all, nullptr, ACT_NONE, nullptr, vxt, x_total, OUT_BF16_T, Tp, T);
+    if (dry || !x_cached) {
+      r.linear(ehs16, B * T, X, kx_all, nullptr, ACT_NONE, nullptr, kx, x_total);
+      r.linear(ehs16, B * T, X, vx_all, nullptr, ACT_NONE, nullptr, vxt, x_total, OUT_BF16_T, Tp, T);
+    } else {
+      kx = const_cast<bf16_t*>(rcache->kx); vxt = const_cast<bf16_t*>(rcache->vxt);
+      dfh::census(dfh::CK_TEXT_CACHED);
+    }
     Tensor x = r.palloc(S, S, conv_in.cin);   // in_channels padded to a multiple of 8
     if (!dry && !r.rc) r.rc = dfh::nchw_to_nhwc_launch(sample, sample_bf16, x.p, B, cfg.in_channels, S * S, s);
 
@@ -658,10 +759,51 @@ struct dfh_unet {
       plan_batch = B;
       // head is re-derived with the real partial size
       Bump hd; hd.alloc(256); hd.alloc((size_t)B * GN_MAX_CHUNKS * 64 * 2 * sizeof(float)); hd.alloc(plan_partial);
-      plan_total = ((hd.off + 255) & ~(size_t)255) + plan_persist + plan_temp;
+      plan_total = fold_bytes() + ((hd.off + 255) & ~(size_t)255) + plan_persist + plan_temp;
       taps.clear();
     } else {
       last_batch = B;
+    }
+    return r.rc;
+  }
+
+  // Fills a run cache (layout: kx | vxt | temb table [n_t][temb_total] fp32).  Uses the bound workspace as scratch, in chunks of the
+  // planned batch so that every launch has a shape the workspace plan covered (split-K slabs included).
+  int run_cache(const void* ehs, int ehs_bf16, int B, const float* timesteps, int n_t, void* cache, hipStream_t s) {
+    if (B != plan_batch) run(nullptr, 0, nullptr, nullptr, 0, nullptr, B, nullptr, true);
+    DFH_REQUIRE(plan_total <= ws_bytes, "workspace too small for this batch");
+    Run r; r.u = this; r.B = B; r.s = s; r.dry = false;
+    const int T = cfg.text_len, X = cfg.cross_attention_dim, Tp = (T + 7) & ~7;
+    const int temb = cfg.block_out_channels[0] * 4, c0 = cfg.block_out_channels[0];
+    Bump head; head.base = ws + fold_bytes();
+    r.zero = (bf16_t*)head.alloc(256);
+    r.gn_partial = (float*)head.alloc((size_t)B * GN_MAX_CHUNKS * 64 * 2 * sizeof(float));
+    r.partial = (float*)head.alloc(plan_partial); r.partial_cap = plan_partial;
+    Bump tmp; tmp.base = head.base + ((head.off + 255) & ~(size_t)255);
+    (void)hipMemsetAsync(r.zero, 0, 256, s);
+    bf16_t* kx = (bf16_t*)cache;
+    bf16_t* vxt = (bf16_t*)((char*)cache + cache_kx_bytes(*this, B));
+    float* table = (float*)((char*)cache + cache_kx_bytes(*this, B) + cache_vxt_bytes(*this, B));
+    bf16_t* ehs16 = (bf16_t*)tmp.alloc((size_t)B * T * X * 2);
+    if (ehs_bf16) (void)hipMemcpyAsync(ehs16, ehs, (size_t)B * T * X * 2, hipMemcpyDeviceToDevice, s);
+    else r.rc = dfh::cast_f32_to_bf16_launch((const float*)ehs, ehs16, (long)B * T * X, s);
+    r.linear(ehs16, B * T, X, kx_all, nullptr, ACT_NONE, nullptr, kx, x_total);
+    r.linear(ehs16, B * T, X, vx_all, nullptr, ACT_NONE, nullptr, vxt, x_total, OUT_BF16_T, Tp, T);
+    bf16_t* tsin = (bf16_t*)tmp.alloc((size_t)B * c0 * 2);
+    bf16_t* e1 = (bf16_t*)tmp.alloc((size_t)B * temb * 2);
+    bf16_t* e2 = (bf16_t*)tmp.alloc((size_t)B * temb * 2);
+    float* trow = (float*)tmp.alloc((size_t)B * temb_total * 4);
+    DFH_REQUIRE(fold_bytes() + ((head.off + 255) & ~(size_t)255) + tmp.off <= ws_bytes, "workspace too small for the run cache scratch");
+    for (int t0 = 0; t0 < n_t && !r.rc; t0 += B) {
+      // always B rows (the planned GEMM shapes); rows past n_t repeat the last timestep and are not copied out
+      const int n = std::min(B, n_t - t0);
+      r.rc = dfh::timestep_embed_launch(timesteps + t0, tsin, n, c0, s);
+      if (r.rc) break;
+      if (n < B) (void)hipMemsetAsync(tsin + (size_t)n * c0, 0, (size_t)(B - n) * c0 * 2, s);
+      r.linear(tsin, B, c0, te1, &te1b, ACT_SILU, nullptr, e1, temb);
+      r.linear(e1, B, temb, te2, &te2b, ACT_SILU, nullptr, e2, temb);
+      r.linear(e2, B, temb, tproj, &tprojb, ACT_NONE, nullptr, trow, temb_total, OUT_F32);
+      if (!r.rc) (void)hipMemcpyAsync(table + (size_t)t0 * temb_total, trow, (size_t)n * temb_total * 4, hipMemcpyDeviceToDevice, s);
     }
     return r.rc;
   }
@@ -681,6 +823,7 @@ struct dfh_unet {
     }
     if (int rc = tab_pack.launch(arena32, arena16, s)) return rc;
     if (int rc = tab_pack_acc.launch(arena32, arena16, s)) return rc;
-    return quantize_fp8(s);          // e4m3 copies of the LayerNorm-fed projections from the freshly packed bf16 matrices
+    if (int rc = quantize_fp8(s)) return rc;   // e4m3 copies of the LayerNorm-fed projections from the freshly packed bf16 matrices
+    return fold_layernorms(s);
   }
 };

@@ -139,6 +139,8 @@ class OutfitSampler:
         self.eps_all = None
         if hasattr(self.unet, "pack"):
             self.unet.pack()
+        if hasattr(self.unet, "prepare_run"):       # text K / V^T of every block + the schedule's time-embedding rows: once per run
+            self.unet.prepare_run(self.ehs, self.ts)
         return self
 
     @torch.no_grad()

@@ -331,12 +331,54 @@ class UNet2DConditionModel(nn.Module):
             _lib.call("dfh_unet_pack_train", self._ctx, arr, len(plist), _lib.stream_ptr())
         self._packed_sig = sig
 
+    # ------------------------------------------------------------------ per-run constants of a sampling loop
+    def prepare_run(self, encoder_hidden_states: torch.Tensor, timesteps) -> None:
+        """Compute, once, what every step of a sampling run shares (reference difashion.py:340-357 prompt states, :356 / :456
+        timestep list): the cross-attention K / V^T of all transformer blocks for ``encoder_hidden_states`` and the time-embedding
+        rows for every entry of ``timesteps``.  Afterwards ``forward(sample, t, encoder_hidden_states)`` with the SAME tensor object
+        (unmodified) and a scalar ``t`` from ``timesteps`` skips those launches (dfh_unet_forward_cached); any other call takes the
+        normal path.  ``end_run()`` (or a weight update / another prepare_run) drops the cache.  Inference only."""
+        ehs = encoder_hidden_states.contiguous()
+        B = ehs.shape[0]
+        self._ensure_ctx(min(B, self.max_batch))
+        self.pack()
+        ts = [float(t) for t in timesteps]
+        tdev = torch.tensor(ts, dtype=torch.float32, device=ehs.device)
+        nbytes = _lib.raw().dfh_unet_run_cache_bytes(self._ctx, B, len(ts))
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=ehs.device)
+        dt = {torch.float32: 0, torch.bfloat16: 1}
+        _lib.call("dfh_unet_run_cache", self._ctx, _lib.ptr(ehs), dt[ehs.dtype], B, _lib.ptr(tdev), len(ts), _lib.ptr(buf), nbytes,
+                  _lib.stream_ptr())
+        self._run_cache = dict(buf=buf, ehs=encoder_hidden_states, ehs_ptr=encoder_hidden_states.data_ptr(),
+                               ehs_version=encoder_hidden_states._version, batch=B, index={t: i for i, t in reversed(list(enumerate(ts)))},
+                               n=len(ts), sig=self._packed_sig, ctx_key=self._ctx_key)
+
+    def end_run(self) -> None:
+        self._run_cache = None
+
+    _run_cache = None
+
+    def _cached_index(self, sample, timestep, ehs):
+        """Index into the run cache when this call may use it (same text-state tensor, untouched; same batch; scalar timestep of the
+        prepared schedule; weights and context unchanged), else None."""
+        rc = self._run_cache
+        if rc is None:
+            return None
+        if (ehs is not rc["ehs"] or ehs.data_ptr() != rc["ehs_ptr"] or ehs._version != rc["ehs_version"] or sample.shape[0] != rc["batch"]
+                or rc["ctx_key"] != self._ctx_key or rc["sig"] != self._packed_sig):
+            return None
+        if torch.is_tensor(timestep):
+            if timestep.numel() != 1 or timestep.is_cuda:       # a device scalar would cost a sync to look up: normal path
+                return None
+            timestep = float(timestep)
+        return rc["index"].get(float(timestep))
+
     def workspace_bytes(self) -> int:
         n = 0 if self._buffers_dev is None else sum(b.numel() for b in self._buffers_dev)
         return n + (0 if self._train_buffers is None else sum(b.numel() for b in self._train_buffers))
 
     # ------------------------------------------------------------------ native calls
-    def _native_forward(self, sample, t, ehs, train: bool):
+    def _native_forward(self, sample, t, ehs, train: bool, cache_index=None):
         B = sample.shape[0]
         cfg = self.config
         if train:
@@ -347,8 +389,13 @@ class UNet2DConditionModel(nn.Module):
             self.pack()
         dt = {torch.float32: 0, torch.bfloat16: 1}
         out = torch.empty((B, cfg["out_channels"], sample.shape[2], sample.shape[3]), dtype=torch.float32, device=sample.device)
-        _lib.call("dfh_unet_forward_train" if train else "dfh_unet_forward", self._ctx, _lib.ptr(sample), dt[sample.dtype],
-                  _lib.ptr(t), _lib.ptr(ehs), dt[ehs.dtype], _lib.ptr(out), B, _lib.stream_ptr())
+        rc = self._run_cache
+        if (not train and cache_index is not None and rc is not None and rc["sig"] == self._packed_sig and rc["ctx_key"] == self._ctx_key):
+            _lib.call("dfh_unet_forward_cached", self._ctx, _lib.ptr(sample), dt[sample.dtype], _lib.ptr(rc["buf"]), B, rc["n"],
+                      int(cache_index), _lib.ptr(out), _lib.stream_ptr())
+        else:
+            _lib.call("dfh_unet_forward_train" if train else "dfh_unet_forward", self._ctx, _lib.ptr(sample), dt[sample.dtype],
+                      _lib.ptr(t), _lib.ptr(ehs), dt[ehs.dtype], _lib.ptr(out), B, _lib.stream_ptr())
         if sample.dtype != torch.float32:
             out = out.to(sample.dtype)
         return out
@@ -495,28 +542,35 @@ class UNet2DConditionModel(nn.Module):
             raise NotImplementedError("no gradient is produced for encoder_hidden_states (frozen text states in the reference)")
         self._ensure_ctx(min(B, self.max_batch))
         dev = sample.device
+        train = torch.is_grad_enabled() and (sample.requires_grad or any(p.requires_grad for p in self.parameters()))
+        idx = None
+        if not train and self._run_cache is not None:
+            if not (self.assume_static_weights and self._packed_sig is not None):
+                self.pack()                        # a weight update since prepare_run changes the signature and drops the cache
+            idx = self._cached_index(sample, timestep, encoder_hidden_states)
         # timestep forms of difashion.py:251 ((B,) int64) and :520 (0-d tensor) / python numbers
-        if not torch.is_tensor(timestep):
+        if idx is not None:
+            t = None                               # the cached time-embedding row of this schedule entry is used instead
+        elif not torch.is_tensor(timestep):
             t = torch.full((B,), float(timestep), dtype=torch.float32, device=dev)
         else:
             t = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
             if t.numel() == 1:
                 t = t.expand(B)
             t = t.contiguous()
-        if t.numel() != B:
+        if t is not None and t.numel() != B:
             raise ValueError("timestep must be a scalar or have one entry per batch row")
         dt = {torch.float32: 0, torch.bfloat16: 1}
         if sample.dtype not in dt or encoder_hidden_states.dtype not in dt:
             raise TypeError("sample / encoder_hidden_states must be float32 or bfloat16")
         sample = sample.contiguous()
         ehs = encoder_hidden_states.contiguous()
-        train = torch.is_grad_enabled() and (sample.requires_grad or any(p.requires_grad for p in self.parameters()))
         if train:
             if self._anchor is None or self._anchor.device != dev:
                 self._anchor = torch.zeros((), device=dev, requires_grad=True)   # makes autograd call the node's backward
             out = _UNetStep.apply(self, sample, t, ehs, self._anchor)
         else:
-            out = self._native_forward(sample, t, ehs, train=False)
+            out = self._native_forward(sample, t, ehs, train=False, cache_index=idx)
         return UNet2DConditionOutput(out) if return_dict else (out,)
 
     def debug_tap(self, name: str) -> torch.Tensor:

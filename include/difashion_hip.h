@@ -109,6 +109,18 @@ int dfh_unet_pack(dfh_unet* u, const float* const* master_params, int count, voi
 int dfh_unet_forward(dfh_unet* u, const void* sample, int sample_bf16, const float* timestep,
                      const void* ehs, int ehs_bf16, float* out, int batch, void* stream);
 
+/* Per-run constants of a sampling loop.  In fashion_generation the prompt states are fixed for the whole run (df.py:340-357, stacked
+ * once at :388-427) and the timesteps are the schedule's list (:356, :456), the same for every row of the CFG batch: the
+ * cross-attention K / V^T of all transformer blocks and the time-embedding rows (time_embedding MLP + all 22 time_emb_proj) depend on
+ * nothing else.  dfh_unet_run_cache computes them once into a caller-owned, 256-byte-aligned buffer of dfh_unet_run_cache_bytes;
+ * dfh_unet_forward_cached is dfh_unet_forward for a batch whose rows all sit at timesteps[t_index], with those launches skipped
+ * (5 GEMMs + 2 small kernels per step).  The cache is valid until the weights are re-packed or the text states change. */
+size_t dfh_unet_run_cache_bytes(const dfh_unet* u, int batch, int n_timesteps);
+int dfh_unet_run_cache(dfh_unet* u, const void* ehs, int ehs_bf16, int batch, const float* timesteps /* device [n] */, int n_timesteps,
+                       void* cache, size_t cache_bytes, void* stream);
+int dfh_unet_forward_cached(dfh_unet* u, const void* sample, int sample_bf16, const void* cache, int batch, int n_timesteps, int t_index,
+                            float* out, void* stream);
+
 /* ------------------------------------------------------------------ training step (train.py:691-716)
  * Replaces torch autograd through the U-Net: accelerator.backward(loss) at DiFashion/train.py:699 for the module
  * called at DiFashion/models/difashion.py:249-253.  Shares arena16/arena32 with the inference path
@@ -231,6 +243,18 @@ int dfh_groupnorm_pre(const void* src, int c, int batch, int hw, int groups, con
                       int silu, void* out, const float* gstat, int chunks, float* stats_out, void* stream);
 /* LayerNorm over the last dim of [M][C] bf16 (BasicTransformerBlock.norm1/2/3) */
 int dfh_layernorm(const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps, void* stream);
+/* ---- LayerNorm folded into the projections around it (inference walk of BasicTransformerBlock: x + attn1(LN1(x)), + attn2(LN2(x)),
+ * + ff(LN3(x)); reached from df.py:518-523).  LN(x) . W^T = rstd * (x . W'^T - mean * s) + b' with W' = W * gamma, s = rowsum(W'),
+ * b' = bias + W . beta: the consumer GEMM runs on the raw rows and fixes them up in its epilogue, the statistics come from the
+ * epilogue of the GEMM that produced x -- no LayerNorm launch, no normalised copy of the tensor in HBM.
+ *   dfh_ln_fold : packed bf16 W [N][ldw] -> WF [N][K] bf16, s [N], b [N] (bias may be NULL)
+ *   dfh_gemm_ln : dfh_gemm plus, as producer, rowstat (per output row and column tile (mean, centred sum of squares),
+ *                 [N / bn][M][2] floats; *rowstat_bn = bn, 0 when this launch could not write them) and / or, as consumer, ln_stat =
+ *                 the producer's rowstat (ln_parts column tiles of ln_cnt columns each), ln_s = s, d->bias = b', d->W = WF */
+int dfh_ln_fold(const void* W, int ldw, const float* gamma, const float* beta, const float* bias, void* WF, float* s, float* b, int N, int K,
+                void* stream);
+int dfh_gemm_ln(const dfh_gemm_desc* d, float* rowstat, int* rowstat_bn, const float* ln_stat, int ln_parts, int ln_cnt, float ln_eps,
+                const float* ln_s, void* stream);
 /* ---- fp8 (OCP e4m3fn) linears: BASELINE configs[4].  The reference has no fp8 path (fp16 autocast, run_inf4eval.sh:1); these
  * replace the same diffusers linears as dfh_gemm (BasicTransformerBlock attn1.to_q/k/v, attn2.to_q, ff.net.0.proj reached from
  * df.py:249-253,518-523) when the caller opts in.

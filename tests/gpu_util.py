@@ -27,10 +27,10 @@ def stream():
     return _lib.stream_ptr()
 
 
-def gemm(*, M, N, W, ldw, a0=None, a0_c=0, a1=None, a1_c=0, conv_src=None, conv_c=0, batch=0, Hin=0, Win=0, stride=1,
-         upsample=0, bias=None, rowvec=None, rv_ld=0, rv_off=0, rows_per_b=0, resid=None, act=0, out_mode=0,
-         out=None, ld_out=None, force_tile=0, force_split=0, force_order=-1, gstat=None, gstat_cpg=0, gstat_hw=0):
-    """gstat: a float32 device tensor for the output's GroupNorm statistics (dfh_gemm_gstat); the call then returns (out, written)."""
+def gemm_desc(*, M, N, W, ldw, a0=None, a0_c=0, a1=None, a1_c=0, conv_src=None, conv_c=0, batch=0, Hin=0, Win=0, stride=1,
+              upsample=0, bias=None, rowvec=None, rv_ld=0, rv_off=0, rows_per_b=0, resid=None, act=0, out_mode=0,
+              out=None, ld_out=None, force_tile=0, force_split=0, force_order=-1):
+    """A filled dfh_gemm_desc; the tensors it points at stay alive on the descriptor (``keep_*``), the output is ``d.keep_out``."""
     d = _lib.GemmDesc()
     if conv_src is not None:
         d.conv_src, d.conv_c, d.conv = conv_src.data_ptr(), conv_c, 1
@@ -61,6 +61,14 @@ def gemm(*, M, N, W, ldw, a0=None, a0_c=0, a1=None, a1_c=0, conv_src=None, conv_
     if need:
         part = torch.empty(need, dtype=torch.float32, device=DEV)
         d.partial, d.partial_floats = part.data_ptr(), need
+    d.keep_out, d.keep_alive = out, (z, part, W, a0, a1, conv_src, bias, rowvec, resid)
+    return d
+
+
+def gemm(*, gstat=None, gstat_cpg=0, gstat_hw=0, **kw):
+    """gstat: a float32 device tensor for the output's GroupNorm statistics (dfh_gemm_gstat); the call then returns (out, written)."""
+    d = gemm_desc(**kw)
+    out = d.keep_out
     if gstat is not None:
         d.gstat, d.gstat_cpg, d.gstat_hw = gstat.data_ptr(), gstat_cpg, gstat_hw
         written = C.c_int(0)

@@ -79,6 +79,88 @@ def test_gemm_geglu_epilogue(M, C, tile):
     gu.assert_close_bf16(out, a * F.gelu(gate), "geglu")
 
 
+@pytest.mark.parametrize("M,C,ptile,resid", [(700, 320, 10, True), (700, 320, 6, True), (1000, 640, 10, False), (300, 128, 5, True),
+                                              (520, 64, 3, False), (4096, 1280, 0, True)])
+def test_layernorm_folded_into_the_surrounding_gemms(M, C, ptile, resid):
+    """dfh_gemm_ln / dfh_ln_fold: the producer GEMM (proj_in / to_out + residual) leaves per-row (mean, centred sum of squares) records
+    of its bf16 output per column tile; the consumers (q|k, V^T, GEGLU input projection) run on the RAW rows with gamma folded into
+    their weights and fix the rows up in the epilogue.  Checked: the records against torch on the producer's own output; every
+    consumer against fp32 LayerNorm -> linear of the same bf16 operands (the tolerance of the unfolded kernels) and against the
+    unfolded kernel path (dfh_layernorm + dfh_gemm) -- rows with a large common offset included (mean >> std: the case where a
+    naive sum / sum-of-squares variance would cancel)."""
+    x = bf(rnd(M, C, seed=51) + 3.0)
+    w1 = bf(rnd(C, C, seed=52, scale=0.05))
+    b1 = rnd(C, seed=53)
+    res = bf(rnd(M, C, seed=54) * 2.0 + torch.linspace(-20, 20, M, device=DEV)[:, None]) if resid else None
+    # --- producer
+    d = gu.gemm_desc(M=M, N=C, W=w1, ldw=C, a0=x, a0_c=C, bias=b1, resid=res, force_tile=ptile)
+    h = d.keep_out
+    st = torch.full((8 * M * 2 + 16,), float("nan"), dtype=torch.float32, device=DEV)
+    import ctypes
+    bn = ctypes.c_int(0)
+    _lib.call("dfh_gemm_ln", ctypes.byref(d), _lib.ptr(st), ctypes.byref(bn), None, 0, 0, 0.0, None, gu.stream())
+    torch.cuda.synchronize()
+    bn = bn.value
+    assert bn in (64, 128, 160) and C % bn == 0, bn
+    parts = C // bn
+    href = x.float() @ w1.float().T + b1 + (res.float() if resid else 0)
+    gu.assert_close_bf16(h, href, "producer output")
+    rec = st[:parts * M * 2].view(parts, M, 2)
+    hp = h.float().view(M, parts, bn).transpose(0, 1)                         # [parts][M][bn]
+    mean_t = hp.mean(-1)
+    m2_t = ((hp - mean_t[..., None]) ** 2).sum(-1)
+    torch.testing.assert_close(rec[..., 0], mean_t, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rec[..., 1], m2_t, rtol=1e-4, atol=1e-4)
+    # --- consumers
+    gamma, beta = 1.0 + 0.2 * rnd(C, seed=55), 0.3 * rnd(C, seed=56)
+    ln = F.layer_norm(h.float(), (C,), gamma, beta, 1e-5)
+    y_ln = torch.empty_like(h)
+    _lib.call("dfh_layernorm", _lib.ptr(h), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y_ln), M, C, 1e-5, gu.stream())
+
+    def fold(w, bias):
+        N = w.shape[0]
+        wf = torch.empty_like(w)
+        s, b = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+        _lib.call("dfh_ln_fold", _lib.ptr(w), C, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bias), _lib.ptr(wf), _lib.ptr(s), _lib.ptr(b), N, C,
+                  gu.stream())
+        return wf, s, b
+
+    def consume(wf, s, b, **kw):
+        dd = gu.gemm_desc(M=M, W=wf, ldw=C, a0=h, a0_c=C, bias=b, **kw)
+        _lib.call("dfh_gemm_ln", ctypes.byref(dd), None, None, _lib.ptr(st), parts, bn, 1e-5, _lib.ptr(s), gu.stream())
+        torch.cuda.synchronize()
+        return dd.keep_out
+
+    # q|k: N = 2C, plain bf16 rows
+    wq = bf(rnd(2 * C, C, seed=57, scale=0.05))
+    wf, s, b = fold(wq, None)
+    torch.testing.assert_close(wf.float(), bf(wq.float() * gamma).float(), rtol=0, atol=0)
+    torch.testing.assert_close(s, wf.float().sum(1), rtol=1e-5, atol=1e-5)
+    got = consume(wf, s, b, N=2 * C)
+    gu.assert_close_bf16(got, ln @ wq.float().T, "folded q|k")
+    plain = gu.gemm(M=M, N=2 * C, W=wq, ldw=C, a0=y_ln, a0_c=C)
+    assert gu.rel_err(got, plain) < 8e-3
+    # V^T: transposed per batch of rows
+    if M % 4 == 0:
+        rows = M // 4
+        wv = bf(rnd(C, C, seed=58, scale=0.05))
+        wf, s, b = fold(wv, None)
+        out = torch.zeros((4, C, rows), dtype=torch.bfloat16, device=DEV)
+        consume(wf, s, b, N=C, out=out, ld_out=rows, out_mode=1, rows_per_b=rows)
+        gu.assert_close_bf16(out, (ln @ wv.float().T).view(4, rows, C).transpose(1, 2), "folded V^T")
+    # GEGLU input projection: packed (interleaved) rows + bias
+    wg, bg = rnd(8 * C, C, seed=59, scale=0.05), rnd(8 * C, seed=60, scale=0.5)
+    wp = torch.empty((8 * C, C), dtype=torch.bfloat16, device=DEV)
+    bp = torch.empty(8 * C, dtype=torch.float32, device=DEV)
+    _lib.call("dfh_pack_matrix", _lib.ptr(wg), _lib.ptr(wp), 8 * C, C, C, 0, 0, 1, gu.stream())
+    _lib.call("dfh_pack_vector", _lib.ptr(bg), _lib.ptr(bp), 8 * C, 0, 1, 0, gu.stream())
+    wf, s, b = fold(wp, bp)
+    got = consume(wf, s, b, N=8 * C, act=4)
+    hh = ln @ bf(wg).float().T + bg
+    av, gate = hh.chunk(2, -1)
+    gu.assert_close_bf16(got, av * F.gelu(gate), "folded GEGLU")
+
+
 def test_gemm_transposed_outputs():
     """OUT_BF16_T feeds attention's V^T (ragged 77 keys padded to 80); OUT_F32_T is conv_out's NCHW."""
     B, T, N, K = 3, 77, 64, 128

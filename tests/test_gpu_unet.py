@@ -42,9 +42,16 @@ def test_unet_matches_oracle_small(name, cfg):
     x, e = inputs(cfg, 3, 11)
     t = torch.tensor([7, 500, 981])
     taps = {}
+    from difashion_amd import _lib
     with torch.no_grad():
         ref = unet_ref.unet_forward(params, cfg, x, t, e, taps=taps)
+        _lib.census_reset()
         out = m(x.to(DEV), t.to(DEV), e.to(DEV)).sample
+    cen = _lib.census()
+    # the LayerNorms of the transformer blocks are folded into the projections around them wherever the producing GEMM can leave
+    # row statistics (csrc/lnfold.hip); what is left runs the LayerNorm kernel
+    print(name, "ln_folded", cen["ln_folded"], "layernorm launches", cen["layernorm"])
+    assert cen["ln_folded"] > 0
     report = {}
     for k in ("conv_in", "down0", "down1", "down2", "down3", "mid", "up0", "up1", "up2", "up3"):
         report[k] = rel_err(m.debug_tap(k).cpu(), taps[k])
@@ -67,6 +74,35 @@ def test_timestep_forms_and_return_dict():
     assert torch.equal(a, b) and torch.equal(a, c)
     with torch.no_grad():      # runs are deterministic (no float atomics anywhere on the path)
         assert torch.equal(a, m(x, 481, e).sample)
+
+
+def test_run_cache_reproduces_the_uncached_forward_bit_for_bit():
+    """prepare_run (dfh_unet_run_cache / dfh_unet_forward_cached): the per-run constants of a sampling loop -- cross-attention K / V^T
+    of every block, the schedule's time-embedding rows (difashion.py:340-357, :456) -- computed once.  The cached step must equal the
+    plain forward bit for bit (same kernels on the same operands), use the cache (census), and fall back to the plain path when the
+    text-state tensor, the timestep or the weights are not the prepared ones."""
+    from difashion_amd import _lib
+    cfg = unet_ref.TINY
+    m = hip_unet(cfg, unet_ref.init_params(cfg, seed=8), max_batch=4)
+    x, e = inputs(cfg, 4, 17)
+    x, e = x.to(DEV), e.to(DEV)
+    ts = [981, 961, 961, 501, 21]              # PLMS lists carry a duplicate entry
+    with torch.no_grad():
+        plain = {t: m(x, t, e).sample for t in set(ts)}
+        m.prepare_run(e, ts)
+        _lib.census_reset()
+        for t in ts:
+            assert torch.equal(m(x, t, e).sample, plain[t])
+        assert _lib.census()["text_cached"] == len(ts)
+        _lib.census_reset()
+        assert torch.equal(m(x, 777, e).sample, m(x, torch.tensor([777.0] * 4, device=DEV), e).sample)      # not in the schedule
+        assert torch.equal(m(x, 981, e.clone()).sample, plain[981])                                           # another tensor object
+        assert torch.equal(m(x[:2], 981, e[:2]).sample, m(x[:2], 981, e[:2].clone()).sample)                  # another batch
+        assert _lib.census()["text_cached"] == 0
+        m.conv_out.bias.add_(1.0)                                                                             # weights changed: cache dropped
+        torch.testing.assert_close(m(x, 981, e).sample, plain[981] + 1.0, rtol=0, atol=1e-5)
+        assert _lib.census()["text_cached"] == 0
+        m.end_run()
 
 
 def test_batch_rows_independent_and_bf16_inputs():
@@ -188,6 +224,7 @@ def test_unet_sd15_full_size_batch16_matches_oracle():
     assert cen["splitk_reduce"] + cen["splitk_fused"] > 0, cen         # split-K at the deep levels
     assert cen["attention_x32"] > 0, cen                               # the 32x32x16 attention kernel
     assert cen["gemm_lean"] + cen["gemm_row"] > 0, cen                 # the short-K token linears
+    assert cen["ln_folded"] >= 45 and cen["layernorm"] <= 3, cen       # LayerNorm folded into its consumers (all but the 8x8 block)
     m.enable_fp8()
     with torch.no_grad():
         m(xd, td, ed)

@@ -313,6 +313,9 @@ def test_checkpoints_written_by_the_reference_stack_load(tmp_path):
     torch.save(sd16, os.path.join(d, "diffusion_pytorch_model.fp16.bin"))
     u3 = da.UNet2DConditionModel.from_pretrained(str(tmp_path), subfolder="unet", variant="fp16")
     assert torch.equal(u3.state_dict()["conv_in.bias"], unet.state_dict()["conv_in.bias"] + 1)
+    # a variant that does not exist is an error, never a silent fall back to the plain file (other weights than asked for)
+    with pytest.raises(FileNotFoundError, match="no 'bf16' variant"):
+        da.UNet2DConditionModel.from_pretrained(str(tmp_path), subfolder="unet", variant="bf16")
     # EMA directory as the reference's hook writes it (.bin) -> EMAModel.from_pretrained
     ema = da.EMAModel(unet.parameters(), decay=0.99, model_cls=da.UNet2DConditionModel, model_config=unet.config)
     ed = os.path.join(str(tmp_path), "unet_ema")

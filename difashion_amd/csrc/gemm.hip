@@ -70,6 +70,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
   tile_coords(blockIdx.x, ntm, ntn, a.n_major, a.tm_xm, a.tm_gm, mt_, nt_);
   const int m0 = mt_ * BM, n0 = nt_ * BN;
 
+  // folded LayerNorm (consumer): this thread's row statistics, requested before anything else so that the loads are the oldest
+  // vector-memory operations of the wave (they retire first; the k-loop's counted waits are unaffected)
+  float2 lnmr = float2{0.f, 1.f};
+  if (a.ln_stat != nullptr && tid < BM) lnmr = ln_row_stats(a, m0 + tid);
+
   // k-step range of this split
   const int per = (a.ksteps + a.ksplit - 1) / a.ksplit;
   const int ks_begin = blockIdx.z * per;
@@ -336,8 +341,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
       if (rv_lds && n < a.N) rq = *(const float4*)(a.rowvec + (long)(m0 / a.rows_per_b) * a.rv_ld + a.rv_off + n);
       if (lnf && n < a.N) rq = *(const float4*)(a.ln_s + n);
     }
-    float2 lnmr = float2{0.f, 1.f};
-    if (lnf && tid < BM) lnmr = ln_row_stats(a, m0 + tid);
     __syncthreads();                                 // every wave is done reading the last pipeline stage
     if (lane < TN / 4) { *(float4*)(strip + lane * 4) = bq; *(float4*)(strip + TN + lane * 4) = rq; }
     if (lnf) {
@@ -428,8 +431,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
     const bool lnf = a.ln_stat != nullptr;
     constexpr int LNROWG = BM * RS;
     static_assert(LNROWG + BM * 8 <= NSTAGE * STAGE, "row statistics must fit behind the staged output tile");
-    float2 lnmr = float2{0.f, 1.f};
-    if (lnf && tid < BM) lnmr = ln_row_stats(a, m0 + tid);
     __syncthreads();
     if (lnf) {
       if (tid < BM) *(float2*)(smem + LNROWG + tid * 8) = lnmr;

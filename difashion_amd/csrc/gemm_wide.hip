@@ -93,6 +93,9 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
   tile_coords(blockIdx.x, ntm, ntn, a.n_major, a.tm_xm, a.tm_gm, mt_, nt_);
   const int m0 = mt_ * BM, n0 = nt_ * BN;
   const int nk = a.ksteps;                           // 32-deep steps (filled by the launcher)
+  // folded LayerNorm (consumer, GEGLU epilogue below): this thread's row statistics, the wave's oldest vector-memory operations
+  float2 lnmr = float2{0.f, 1.f};
+  if (a.ln_stat != nullptr && tid < BM) lnmr = ln_row_stats(a, m0 + tid);
 
   // staging geometry: piece p = i*4 + wave holds tile rows p*16 + lane/4; the LDS image is lane-linear, the SOURCE
   // 16-byte chunk is swizzled: slot s of row r holds channel chunk s ^ ((r >> 1) & 3)
@@ -291,8 +294,6 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
       static_assert(LNROWG + BM * 8 <= NSTAGE * STAGE, "staged GEGLU tile + row statistics must fit the pipeline buffers");
       static_assert(BM <= NWV * 64, "one thread per tile row");
       const bool lnf = a.ln_stat != nullptr;
-      float2 lnmr = float2{0.f, 1.f};
-      if (lnf && tid < BM) lnmr = ln_row_stats(a, m0 + tid);
       __syncthreads();                                 // every wave is done reading the last pipeline stage
       if (lnf) {
         if (tid < BM) *(float2*)(smem + LNROWG + tid * 8) = lnmr;
@@ -373,7 +374,8 @@ int gemm_wide_pick(const GemmArgs& a) {
   // profiles/r02/gemm_shortk2_probe.txt: 65536 x 960 x 320 72.7 -> 60.2 us, 65536 x 320 x 1280 + residual 75.3 -> 67.7 us,
   // 16384 x 1920 x 640 63.4 -> 47.6 us); the 3x3 convs keep the wide tile, and so do the K = 320 linears with a residual, whose
   // coalesced one-pass-ahead residual reads win (same-box A/B: 31.4 vs 33.7 us)
-  if (a.ntaps == 0 && a.N % 160 == 0 && !(a.resid && a.nplain == 1 && a.p_c[0] <= 320)) return 0;
+  // (with row statistics for a folded LayerNorm the eight-wave kernel wins again: the 256-row epilogue pays ~4.5 us per launch for them)
+  if (a.ntaps == 0 && a.N % 160 == 0 && !(a.resid && a.nplain == 1 && a.p_c[0] <= 320 && !a.rowstat)) return 0;
   const long nt = (a.N + 159) / 160;
   // the 128-row sibling (variant 2) is kept for experiments only: at equal tile size the 64-deep two-stage kernel of
   // gemm.hip wins (848 vs 724 TFLOP/s on conv 320->320 @64): the gain of this file is the larger tile

@@ -115,7 +115,15 @@ def test_batch_rows_independent_and_bf16_inputs():
         full = m(x, t, e).sample
         one = m(x[1:2], t[1:2], e[1:2]).sample
         xb = m(x.bfloat16(), t, e.bfloat16()).sample
-    assert rel_err(full[1:2], one) < 2e-3       # different tile shapes/split-K only reorder fp32 sums
+        # independence, the rigorous form: other rows' inputs must not reach this row AT ALL -- same batch size (same kernels, tiles
+        # and summation orders), rows 0 and 2 replaced: row 1 must come out bit for bit the same
+        x2, e2 = x.clone(), e.clone()
+        x2[0], x2[2], e2[0], e2[2] = x[2] * 3.0 + 1.0, -x[0], e[2] * 2.0, -e[0]
+        other = m(x2, torch.tensor([900, 300, 5], device=DEV), e2).sample
+    assert torch.equal(other[1], full[1])
+    # across batch sizes the launch heuristics pick other tiles / split factors / GroupNorm kernels: two valid bf16 evaluations of
+    # the same function, each ~1.6e-2 from the fp32 oracle (scripts/lnfold_diag.py prints both), differ by about as much
+    assert rel_err(full[1:2], one) < 3e-2
     assert xb.dtype == torch.bfloat16 and rel_err(xb.float(), full) < 3e-2
 
 

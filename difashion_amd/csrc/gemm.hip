@@ -22,6 +22,7 @@
 //     8x8 / 16x16 levels whose M is too small to fill 256 CUs.
 #include "gemm.h"
 #include "gemm_kiter.h"
+#include "gemm_wide_epilogue.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -38,11 +39,16 @@ template <int N> DFH_DEVICE void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0
 // sources are the previous k-step's plus 128 bytes, so the k-loop keeps one 64-bit pointer per staging piece and adds a
 // constant -- no segment iterator, no per-piece predicates / selects / multiplies (the generic loop spends ~190 SALU and
 // ~125 VALU instructions per k-step beside 20 MFMAs; with 2 waves per SIMD that, not the MFMA pipe, paces the loop).
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool LEAN = false>
+// WEPI: the tile's epilogue is the 256-row one of gemm_wide_epilogue.h (four 64-row passes through an fp32 LDS tile) -- the 256 x 320
+// eight-wave tile, whose bf16 staging tile would not fit beside nothing (168 KB).  That instantiation is the "big" tile: 64-deep
+// k-steps of 128-byte rows (LDS-DMA gathers 128-byte rows at twice the rate of the 64-byte rows of gemm_wide.hip), 128 x 80 per wave
+// (13 fragment reads per 40 MFMAs), 72 staging pieces per 640 MFMAs of a k-step (0.11 per MFMA against 0.16 for 256 x 160 x 32), two
+// stages = 144 KB, one workgroup per CU.
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool LEAN = false, bool WEPI = false>
 // second launch-bound = waves per SIMD the register allocation must leave room for: the eight-wave 128-row tiles run TWO workgroups
 // per CU (4 waves per SIMD, <= 128 VGPRs); without the bound the allocator settles at 130 and silently halves the occupancy
 // (+35 % on every 32x32 / 16x16-level conv, measured)
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) void gemm_bf16_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128 && BN <= 160) ? 4 : 1) void gemm_bf16_kernel(const GemmArgs a) {
   constexpr int NWV = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;       // per-wave output tile
   constexpr int FM = TM / 16, FN = TN / 16;       // 16x16 fragments per wave
@@ -231,10 +237,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
   // 1.6k cycles from the prologue to the first MFMA); behind it only the first wait has to let them stay in flight (+NRES).
   constexpr int RS = BN * 2 + 16;                  // LDS row stride of the staged output tile (bytes)
   constexpr int NRES = FM * FN;                    // residual loads per lane
-  static_assert(BM * RS <= 2 * STAGE, "staged output tile must fit the pipeline buffers");
+  static_assert(WEPI || BM * RS <= 2 * STAGE, "staged output tile must fit the pipeline buffers");
   static_assert(2 * N_HI + NRES <= 63, "vmcnt is a 6-bit counter");
-  const bool staged = a.ksplit == 1 && a.out_mode == OUT_BF16 && a.act != ACT_GEGLU && (a.N & 7) == 0 && (a.ld_out & 7) == 0;
-  const bool staged_geglu = a.ksplit == 1 && a.act == ACT_GEGLU && (a.ld_out & 7) == 0;
+  const bool staged = !WEPI && a.ksplit == 1 && a.out_mode == OUT_BF16 && a.act != ACT_GEGLU && (a.N & 7) == 0 && (a.ld_out & 7) == 0;
+  const bool staged_geglu = !WEPI && a.ksplit == 1 && a.act == ACT_GEGLU && (a.ld_out & 7) == 0;
   const bool res_pre = staged && a.resid != nullptr;
   uint2 rpre[FM][FN];
   auto fetch_resid = [&]() {
@@ -320,6 +326,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
   }
 
   // ---------------------------------------------------------------- epilogue
+  if constexpr (WEPI) {      // the launcher sends only single-pass bf16 launches here (gemm_big_pick)
+    wide_epilogue<BM, BN, WN, NSTAGE * STAGE>(a, acc, smem, tid, wm, wn, fr, fg, m0, n0);
+    return;
+  }
   const bool partial = a.ksplit > 1;
   if (staged) {
     if (nk <= 0 && res_pre) fetch_resid();
@@ -329,7 +339,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
     // (in-kernel stamps); batched into registers they cost 8 VGPRs too many for two workgroups per CU.
     constexpr int STRIP = 2 * TN * 4;                // bias | rowvec (or the folded-LayerNorm s slice), fp32
     constexpr int LNROW = BM * RS + NWV * STRIP;     // folded LayerNorm: (mean, rstd) of the tile's rows, fp32 pairs
-    static_assert(LNROW + BM * 8 <= NSTAGE * STAGE, "bias strips + row statistics must fit behind the staged output tile");
+    static_assert(WEPI || LNROW + BM * 8 <= NSTAGE * STAGE, "bias strips + row statistics must fit behind the staged output tile");
     float* strip = (float*)(smem + BM * RS + wave * STRIP);
     const bool lnf = a.ln_stat != nullptr;
     // the time-embedding row is per image: through the strip when the whole tile lies in one image, else per fragment
@@ -430,7 +440,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
     // value * gelu(gate) on 16-column value/gate blocks: the tile's BN packed columns give BN/2 outputs per row
     const bool lnf = a.ln_stat != nullptr;
     constexpr int LNROWG = BM * RS;
-    static_assert(LNROWG + BM * 8 <= NSTAGE * STAGE, "row statistics must fit behind the staged output tile");
+    static_assert(WEPI || LNROWG + BM * 8 <= NSTAGE * STAGE, "row statistics must fit behind the staged output tile");
     __syncthreads();
     if (lnf) {
       if (tid < BM) *(float2*)(smem + LNROWG + tid * 8) = lnmr;
@@ -600,19 +610,19 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(const GemmArgs a) {
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool LEAN = false>
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool LEAN = false, bool WEPI = false>
 int launch_tile(const GemmArgs& a, hipStream_t stream) {
   constexpr int lds = NSTAGE * (BM + BN) * BK * 2;
   static_assert(lds <= 160 * 1024, "LDS ring exceeds the CU's 160 KiB");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, LEAN>,
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, LEAN, WEPI>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   dim3 grid(ntm * ntn, 1, a.ksplit);
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, LEAN>), grid, dim3(WM * WN * 64), lds, stream, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, LEAN, WEPI>), grid, dim3(WM * WN * 64), lds, stream, a);
   return dfh::check_launch("gemm_bf16_kernel");
 }
 
@@ -636,6 +646,13 @@ bool lean_plain(const GemmArgs& a) {
   // 0-3 % at two workgroups per CU -- the LDS-DMA issue itself (~100 cycles per 1-KB piece), not its address arithmetic,
   // is what paces the loop
   return a.ntaps == 0 && a.nplain == 1 && a.p_c[0] % BK == 0 && a.p_c[0] > 0;
+}
+
+// the "big" tile: 256 x 320, eight waves, 64-deep k-steps (see the kernel's WEPI note)
+int launch_big(const GemmArgs& a, hipStream_t s, int bm) {
+  // 128-row sibling (one workgroup per CU as well: 112 KB): the 32x32-level launches, whose 256-row grid would fill half the chip
+  if (bm == 128) return lean_plain(a) ? launch_tile<128, 320, 2, 4, 2, true, true>(a, s) : launch_tile<128, 320, 2, 4, 2, false, true>(a, s);
+  return lean_plain(a) ? launch_tile<256, 320, 2, 4, 2, true, true>(a, s) : launch_tile<256, 320, 2, 4, 2, false, true>(a, s);
 }
 
 int launch_variant(int tile, const GemmArgs& a, hipStream_t s) {
@@ -731,6 +748,24 @@ static void gemm_pick_tile_order(GemmArgs& a, int split, int bm, int bn) {
   if (best != 8) { a.tm_xm = best; a.tm_gm = 8; }
 }
 
+// Launches for the 256 x 320 tile: one workgroup per CU, so the grid has to come out at whole rounds of the 256 CUs (a 257th tile
+// would run alone for a whole round).  DFH_GEMM_BIG=0 turns it off, =2 also sends the plain linears there (A/B).
+// returns the row tile (256 / 128) or 0
+int gemm_big_pick(const GemmArgs& a) {
+  static const int mode = [] { const char* e = getenv("DFH_GEMM_BIG"); return e ? atoi(e) : 2; }();   // 0 off, 1 convs, 2 + deep linears, 3 + all linears (A/B)
+  static const int m128 = [] { const char* e = getenv("DFH_GEMM_BIG128"); return e ? atoi(e) : 1; }();
+  if (mode == 0) return 0;
+  if (a.out_mode != OUT_BF16 || a.act == ACT_GEGLU || a.ln_stat) return 0;
+  if (a.N % 320 != 0 || (a.ld_out & 7) || (a.resid && (a.ld_res & 7))) return 0;
+  const int ksteps = gemm_count_ksteps(a);
+  if (ksteps < 16 && (a.ntaps || mode < 3)) return 0;   // conv_in (K = 72): prologue + four-pass epilogue outweigh two k-steps (34.6 vs 24.3 us)
+  if (a.ntaps == 0 && mode < 2) return 0;
+  auto rounds_ok = [](long tiles) { const long rem = tiles % 256; return tiles >= 224 && (rem == 0 || rem >= 224 || tiles >= 1024); };
+  if (rounds_ok((long)((a.M + 255) / 256) * (a.N / 320))) return 256;
+  if (m128 && rounds_ok((long)((a.M + 127) / 128) * (a.N / 320))) return 128;
+  return 0;
+}
+
 bool gemm_ln_consumer_ok(GemmArgs a) {
   if (a.rows_per_b <= 0) a.rows_per_b = a.M;
   a.ksteps = gemm_count_ksteps(a);
@@ -757,7 +792,7 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
   // microbench / tests: tile id 6 = the 256 x 160 wide kernel, 7 = its 128 x 160 sibling
   const bool force_deep = force_tile == 10;
   if (force_deep) { tile = kEightWave; force_tile = 0; }
-  const int force_wide = force_tile > kNumTiles ? force_tile - kNumTiles : 0;
+  int force_wide = force_tile > kNumTiles ? force_tile - kNumTiles : 0;
   if (force_wide) force_tile = 0;
   if (force_tile > 0) { DFH_REQUIRE(force_tile <= kNumTiles, "unknown tile variant"); tile = force_tile - 1; }
   if (force_split > 0) split = force_split;
@@ -794,7 +829,14 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     ProfScope ps(a.ntaps ? PC_CONV3 : PC_LINEAR, 2.0 * a.M * a.N * kreal, abytes + (double)a.N * kreal * 2.0 + obytes, stream);
     const bool wide_ok = split == 1 && a.out_mode == OUT_BF16 && (a.act != ACT_GEGLU || a.N % 160 == 0 || a.N % 128 == 0) && (a.N & 7) == 0 &&
                          (a.ld_out & 7) == 0 && (!a.resid || (a.ld_res & 7) == 0);
-    int wide = (!wide_ok || force_deep) ? 0 : (force_wide ? force_wide : ((force_tile == 0 && force_split == 0) ? gemm_wide_pick(a) : 0));
+    // tile id 21 pins the 256 x 320 tile (launches it cannot take -- fp32 / transposed outputs, GEGLU, N % 8 -- fall back to the
+    // heuristic tile, like the forced wide ids); otherwise gemm_big_pick decides
+    const bool force_big = force_wide == 16 || force_wide == 17;     // ids 21 / 22: 256 / 128 rows
+    const int force_bm = force_wide == 17 ? 128 : 256;
+    if (force_big) force_wide = 0;
+    const bool big_ok = wide_ok && !force_deep && a.act != ACT_GEGLU && !a.ln_stat;
+    const int big = !big_ok ? 0 : (force_big ? force_bm : ((!force_wide && force_tile == 0 && force_split == 0) ? gemm_big_pick(a) : 0));
+    int wide = (!wide_ok || force_deep || big || force_big) ? 0 : (force_wide ? force_wide : ((force_tile == 0 && force_split == 0) ? gemm_wide_pick(a) : 0));
     int ws = 0; bool halo = false;
 #ifdef DFH_PROBES
     // Probe builds only (scripts/probes/Makefile): tile ids 11 / 12 = the wave-specialised kernel (scripts/probes/kernels/gemm_ws.hip, opt-in
@@ -811,20 +853,22 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     DFH_REQUIRE(force_wide != 6 && force_wide != 7 && force_wide != 15 && !(force_wide >= 8 && force_wide <= 14),
                 "tile ids 11-20 are probe kernels: build scripts/probes (make -C scripts/probes) and load it with DFH_LIB");
 #endif
-    if (ws) gemm_pick_tile_order(a, split, 256, ws);
+    if (big) gemm_pick_tile_order(a, split, big, 320);
+    else if (ws) gemm_pick_tile_order(a, split, 256, ws);
     else if (wide) gemm_pick_tile_order(a, split, wide == 2 ? 128 : 256, wide == 3 ? 320 : (wide == 4 ? 128 : 160));
     else gemm_pick_tile_order(a, split, kTiles[tile].bm, kTiles[tile].bn);
     if (force_wide == 6 || force_wide == 7) wide = 0;                      // not eligible (odd N, transposed / fp32 output): the default tile runs
     if (force_wide == 15) wide = halo ? 1 : 0;
     // output statistics for the consuming GroupNorm: only the 256 x 160 epilogue writes them, on full tiles inside one image
-    const bool gst_ok = a.gstat && (halo || (wide == 1 && !ws)) && a.gstat_cpg > 0 && 160 % a.gstat_cpg == 0 && a.N % 160 == 0 &&
-                        a.N % a.gstat_cpg == 0 && a.M % 256 == 0 && a.gstat_hw % 256 == 0 && a.act != ACT_GEGLU;
+    const int gbn = big ? 320 : 160;
+    const bool gst_ok = a.gstat && (halo || big || (wide == 1 && !ws)) && a.gstat_cpg > 0 && gbn % a.gstat_cpg == 0 && a.N % gbn == 0 &&
+                        a.N % a.gstat_cpg == 0 && a.M % 256 == 0 && a.gstat_hw % 256 == 0 && a.act != ACT_GEGLU && big != 128;
     if (!gst_ok) a.gstat = nullptr;
     else if (gstat_written) *gstat_written = true;
     // per-row output statistics for a LayerNorm folded into the consumer: the staged bf16 epilogue of gemm_bf16_kernel and the 256-row
     // epilogue write them, on whole column tiles
     {
-      const int bn = wide == 1 ? 160 : (wide == 4 ? 128 : (wide || ws ? 0 : kTiles[tile].bn));
+      const int bn = big ? 320 : (wide == 1 ? 160 : (wide == 4 ? 128 : (wide || ws ? 0 : kTiles[tile].bn)));
       const bool staged_ok = split == 1 && a.out_mode == OUT_BF16 && a.act != ACT_GEGLU && (a.N & 7) == 0 && (a.ld_out & 7) == 0;
       if (!(a.rowstat && bn > 0 && staged_ok && a.N % bn == 0 && !halo)) a.rowstat = nullptr;
       else if (rowstat_bn) *rowstat_bn = bn;
@@ -834,9 +878,10 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     else if (ws) rc = gemm_ws_launch(a, stream, ws);
     else
 #endif
-    if (wide) rc = gemm_wide_launch(a, stream, wide);
+    if (big) rc = launch_big(a, stream, big);
+    else if (wide) rc = gemm_wide_launch(a, stream, wide);
     else rc = launch_variant(tile, a, stream);
-    census(wide ? CK_GEMM_WIDE : ((halo || ws) ? CK_GEMM_OTHER : (tile == kEightWave ? (lean_plain(a) ? CK_GEMM_LEAN : CK_GEMM_8WAVE) : CK_GEMM_OTHER)));
+    census(big ? CK_GEMM_ROW : wide ? CK_GEMM_WIDE : ((halo || ws) ? CK_GEMM_OTHER : (tile == kEightWave ? (lean_plain(a) ? CK_GEMM_LEAN : CK_GEMM_8WAVE) : CK_GEMM_OTHER)));
     if (a.gstat) census(CK_GSTAT_WRITTEN);
   }
   if (rc) return rc;

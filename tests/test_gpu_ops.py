@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 # ----------------------------------------------------------------------------- GEMM (linear / 1x1 conv)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 9, 10])  # every tile / pipeline-depth variant of gemm.hip; 6 / 9 = gemm_wide.hip (256x160 / 256x128); 10 = eight-wave 128x160
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 9, 10, 21, 22])  # every tile / pipeline-depth variant of gemm.hip; 6 / 9 = gemm_wide.hip (256x160 / 256x128); 10 = eight-wave 128x160; 21 / 22 = 256x320 / 128x320 eight-wave, 64-deep
 @pytest.mark.parametrize("order", [-1, 2, 3])     # tile enumeration: heuristic / n-major / m-major (placement never changes results)
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (128, 160, 64), (77 * 3, 64, 768), (16, 1280, 200), (4, 256, 2048)])
 def test_gemm_plain(tile, order, M, N, K):
@@ -50,7 +50,7 @@ def test_gemm_two_sources_is_channel_concat():
     gu.assert_close_bf16(out, ref, "concat")
 
 
-@pytest.mark.parametrize("tile", [0, 6, 9])
+@pytest.mark.parametrize("tile", [0, 6, 9, 21, 22])
 @pytest.mark.parametrize("act,fn", [(1, F.silu), (2, lambda x: F.leaky_relu(x, 0.01)), (3, torch.tanh)])
 def test_gemm_activations_and_rowvec(act, fn, tile):
     B, rows, N, K = 3, 40, 128, 96
@@ -79,7 +79,7 @@ def test_gemm_geglu_epilogue(M, C, tile):
     gu.assert_close_bf16(out, a * F.gelu(gate), "geglu")
 
 
-@pytest.mark.parametrize("M,C,ptile,resid", [(700, 320, 10, True), (700, 320, 6, True), (1000, 640, 10, False), (300, 128, 5, True),
+@pytest.mark.parametrize("M,C,ptile,resid", [(700, 320, 10, True), (700, 320, 6, True), (700, 320, 21, True), (700, 640, 22, True), (1000, 640, 10, False), (300, 128, 5, True),
                                               (520, 64, 3, False), (4096, 1280, 0, True)])
 def test_layernorm_folded_into_the_surrounding_gemms(M, C, ptile, resid):
     """dfh_gemm_ln / dfh_ln_fold: the producer GEMM (proj_in / to_out + residual) leaves per-row (mean, centred sum of squares) records
@@ -101,7 +101,7 @@ def test_layernorm_folded_into_the_surrounding_gemms(M, C, ptile, resid):
     _lib.call("dfh_gemm_ln", ctypes.byref(d), _lib.ptr(st), ctypes.byref(bn), None, 0, 0, 0.0, None, gu.stream())
     torch.cuda.synchronize()
     bn = bn.value
-    assert bn in (64, 128, 160) and C % bn == 0, bn
+    assert bn in (64, 128, 160, 320) and C % bn == 0, bn
     parts = C // bn
     href = x.float() @ w1.float().T + b1 + (res.float() if resid else 0)
     gu.assert_close_bf16(h, href, "producer output")
@@ -182,7 +182,7 @@ def test_gemm_transposed_outputs():
     (64, 4, 16, 1, 0),      # conv_out shape class
     (128, 128, 2, 1, 0),    # 2x2 level of the tiny configs: every tap hits padding somewhere
 ])
-@pytest.mark.parametrize("glds", [0, 1, 4, 6, 9, 10])   # here: forced tile variant (0 = heuristic, 1 = 256x160 ring, 4 = 128x160 2-stage, 6 = wide)
+@pytest.mark.parametrize("glds", [0, 1, 4, 6, 9, 10, 21, 22])   # here: forced tile variant (0 = heuristic, 1 = 256x160 ring, 4 = 128x160 2-stage, 6 = wide)
 def test_conv3x3(cin, cout, H, stride, ups, glds):
     B = 2
     x = bf(rnd(B, cin, H, H, seed=20))
@@ -196,7 +196,7 @@ def test_conv3x3(cin, cout, H, stride, ups, glds):
     gu.assert_close_bf16(gu.nchw(out.view(B, Ho, Ho, cout)), ref, f"conv {cin}->{cout}@{H} s{stride} u{ups}")
 
 
-@pytest.mark.parametrize("tile", [0, 1, 6, 10])
+@pytest.mark.parametrize("tile", [0, 1, 6, 10, 21, 22])
 @pytest.mark.parametrize("cin,H,W", [(64, 12, 20), (128, 5, 3), (192, 16, 1)])
 def test_conv3x3_lean_tap_staging_on_non_square_inputs(cin, H, W, tile):
     """The lean tap staging (centre-pixel offset + 9-bit validity mask per staging piece) on inputs whose height and
@@ -215,6 +215,8 @@ def test_conv3x3_lean_tap_staging_on_non_square_inputs(cin, H, W, tile):
 @pytest.mark.parametrize("kind,cin,cout,H,B,tile", [
     ("conv", 64, 320, 32, 2, 6),      # 3x3 conv on the wide kernel: 4 row tiles per image, cpg 10 (16 groups per column tile)
     ("conv", 32, 640, 16, 3, 6),      # one row tile per image, cpg 20
+    ("conv", 64, 320, 32, 2, 21),     # the 256 x 320 tile: all 32 groups of a row tile in one workgroup
+    ("conv", 32, 640, 16, 3, 21),
     ("linear", 320, 320, 32, 2, 6),   # proj_out shape class: linear + residual
 ])
 def test_gemm_writes_groupnorm_statistics_for_its_consumer(kind, cin, cout, H, B, tile):
@@ -264,7 +266,7 @@ def test_gemm_writes_groupnorm_statistics_for_its_consumer(kind, cin, cout, H, B
     assert not w2
 
 
-@pytest.mark.parametrize("tile", [0, 6, 9])
+@pytest.mark.parametrize("tile", [0, 6, 9, 21, 22])
 def test_conv3x3_with_fused_shortcut_and_temb(tile):
     """ResnetBlock2D tail: conv2(h) + conv_shortcut(cat(x, skip)) + biases, and conv1 + time embedding."""
     B, H, c0, c1, cout = 2, 8, 64, 32, 96

@@ -48,7 +48,7 @@ template <int BM, int BN, int WM, int WN, int NSTAGE, bool LEAN = false, bool WE
 // second launch-bound = waves per SIMD the register allocation must leave room for: the eight-wave 128-row tiles run TWO workgroups
 // per CU (4 waves per SIMD, <= 128 VGPRs); without the bound the allocator settles at 130 and silently halves the occupancy
 // (+35 % on every 32x32 / 16x16-level conv, measured)
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128 && BN <= 160) ? 4 : 1) void gemm_bf16_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) void gemm_bf16_kernel(const GemmArgs a) {
   constexpr int NWV = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;       // per-wave output tile
   constexpr int FM = TM / 16, FN = TN / 16;       // 16x16 fragments per wave
@@ -327,6 +327,67 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128 && BN <= 16
 
   // ---------------------------------------------------------------- epilogue
   if constexpr (WEPI) {      // the launcher sends only single-pass bf16 launches here (gemm_big_pick)
+    if constexpr (FN % 2 == 0) {
+      // GEGLU in registers (the epilogue of gemm_wide.hip's 256 x 128 tile, here for the 256 x 256 eight-wave tile): the packed weight rows
+      // interleave values and gates in 16-row blocks, so acc[i][j] / acc[i][j + 1] hold value and gate of the SAME four hidden units of
+      // one pixel in one lane; bias (or the folded-LayerNorm fix-up), exact-erf GELU and the product run on the accumulators and only the
+      // bf16 result (half the columns) is staged through LDS for full-row 16-byte stores.
+      if (a.act == ACT_GEGLU) {
+        constexpr int RSG = BN + 16;                     // bf16 row stride of the staged [BM][BN / 2] tile (bytes)
+        constexpr int LNROWG = BM * RSG;
+        static_assert(LNROWG + BM * 8 <= NSTAGE * STAGE, "staged GEGLU tile + row statistics must fit the pipeline buffers");
+        static_assert(BM <= NWV * 64, "one thread per tile row");
+        const bool lnf = a.ln_stat != nullptr;
+        __syncthreads();                                 // every wave is done reading the last pipeline stage
+        if (lnf) {
+          if (tid < BM) *(float2*)(smem + LNROWG + tid * 8) = lnmr;
+          __syncthreads();
+        }
+        float4 bv[FN / 2], bg[FN / 2], sv[FN / 2], sg[FN / 2];
+#pragma unroll
+        for (int jj = 0; jj < FN / 2; ++jj) {
+          const int n = n0 + wn * TN + jj * 32 + fg * 4;
+          bv[jj] = float4{0, 0, 0, 0}; bg[jj] = float4{0, 0, 0, 0}; sv[jj] = bv[jj]; sg[jj] = bv[jj];
+          if (a.bias && n + 16 < a.N) { bv[jj] = *(const float4*)(a.bias + n); bg[jj] = *(const float4*)(a.bias + n + 16); }
+          if (lnf && n + 16 < a.N) { sv[jj] = *(const float4*)(a.ln_s + n); sg[jj] = *(const float4*)(a.ln_s + n + 16); }
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int row = wm * TM + i * 16 + fr;
+          float2 mr = float2{0.f, 1.f};
+          if (lnf) mr = *(const float2*)(smem + LNROWG + row * 8);
+          const float ms = -mr.x * mr.y;                 // rstd * (acc - mean * s) + b' == rstd * acc + (b' - rstd * mean * s)
+#pragma unroll
+          for (int jj = 0; jj < FN / 2; ++jj) {
+            const f32x4_t v = acc[i][2 * jj], g = acc[i][2 * jj + 1];
+            float vv[4], gg[4];
+            if (lnf) {
+              vv[0] = fmaf(mr.y, v[0], fmaf(ms, sv[jj].x, bv[jj].x)); vv[1] = fmaf(mr.y, v[1], fmaf(ms, sv[jj].y, bv[jj].y));
+              vv[2] = fmaf(mr.y, v[2], fmaf(ms, sv[jj].z, bv[jj].z)); vv[3] = fmaf(mr.y, v[3], fmaf(ms, sv[jj].w, bv[jj].w));
+              gg[0] = fmaf(mr.y, g[0], fmaf(ms, sg[jj].x, bg[jj].x)); gg[1] = fmaf(mr.y, g[1], fmaf(ms, sg[jj].y, bg[jj].y));
+              gg[2] = fmaf(mr.y, g[2], fmaf(ms, sg[jj].z, bg[jj].z)); gg[3] = fmaf(mr.y, g[3], fmaf(ms, sg[jj].w, bg[jj].w));
+            } else {
+              vv[0] = v[0] + bv[jj].x; vv[1] = v[1] + bv[jj].y; vv[2] = v[2] + bv[jj].z; vv[3] = v[3] + bv[jj].w;
+              gg[0] = g[0] + bg[jj].x; gg[1] = g[1] + bg[jj].y; gg[2] = g[2] + bg[jj].z; gg[3] = g[3] + bg[jj].w;
+            }
+            uint2 o;
+            o.x = pack2bf(vv[0] * gelu_erf_f(gg[0]), vv[1] * gelu_erf_f(gg[1]));
+            o.y = pack2bf(vv[2] * gelu_erf_f(gg[2]), vv[3] * gelu_erf_f(gg[3]));
+            const int ocl = ((wn * TN) >> 1) + jj * 16 + fg * 4;           // output column inside the tile
+            *(uint2*)(smem + row * RSG + ocl * 2) = o;
+          }
+        }
+        __syncthreads();
+        constexpr int CPRG = BN / 16;                    // 16-byte chunks per output row of the tile
+        for (int c = tid; c < BM * CPRG; c += NWV * 64) {
+          const int row = c / CPRG, cc = c - row * CPRG;
+          const int m = m0 + row, oc = (n0 >> 1) + cc * 8;
+          if (m < a.M && oc < (a.N >> 1))
+            *(uint4*)((bf16_t*)a.out + (long)m * a.ld_out + oc) = *(const uint4*)(smem + row * RSG + cc * 16);
+        }
+        return;
+      }
+    }
     wide_epilogue<BM, BN, WN, NSTAGE * STAGE>(a, acc, smem, tid, wm, wn, fr, fg, m0, n0);
     return;
   }
@@ -649,9 +710,14 @@ bool lean_plain(const GemmArgs& a) {
 }
 
 // the "big" tile: 256 x 320, eight waves, 64-deep k-steps (see the kernel's WEPI note)
-int launch_big(const GemmArgs& a, hipStream_t s, int bm) {
-  // 128-row sibling (one workgroup per CU as well: 112 KB): the 32x32-level launches, whose 256-row grid would fill half the chip
-  if (bm == 128) return lean_plain(a) ? launch_tile<128, 320, 2, 4, 2, true, true>(a, s) : launch_tile<128, 320, 2, 4, 2, false, true>(a, s);
+// the GEGLU projections on a 256 x 256 eight-wave tile (128 x 64 per wave: whole (value, gate) block pairs inside a wave)
+int launch_big_geglu(const GemmArgs& a, hipStream_t s) {
+  return lean_plain(a) ? launch_tile<256, 256, 2, 4, 2, true, true>(a, s) : launch_tile<256, 256, 2, 4, 2, false, true>(a, s);
+}
+
+int launch_big(const GemmArgs& a, hipStream_t s) {
+  // (a 128 x 320 sibling for the 32x32 level -- one tile per CU there too -- was measured and dropped: equal to the eight-wave
+  //  128 x 160 kernel in isolation, conv3x3 class +0.3 ms per step in situ: profiles/r03/big_tile_probe.txt)
   return lean_plain(a) ? launch_tile<256, 320, 2, 4, 2, true, true>(a, s) : launch_tile<256, 320, 2, 4, 2, false, true>(a, s);
 }
 
@@ -750,20 +816,25 @@ static void gemm_pick_tile_order(GemmArgs& a, int split, int bm, int bn) {
 
 // Launches for the 256 x 320 tile: one workgroup per CU, so the grid has to come out at whole rounds of the 256 CUs (a 257th tile
 // would run alone for a whole round).  DFH_GEMM_BIG=0 turns it off, =2 also sends the plain linears there (A/B).
-// returns the row tile (256 / 128) or 0
 int gemm_big_pick(const GemmArgs& a) {
   static const int mode = [] { const char* e = getenv("DFH_GEMM_BIG"); return e ? atoi(e) : 2; }();   // 0 off, 1 convs, 2 + deep linears, 3 + all linears (A/B)
-  static const int m128 = [] { const char* e = getenv("DFH_GEMM_BIG128"); return e ? atoi(e) : 1; }();
   if (mode == 0) return 0;
   if (a.out_mode != OUT_BF16 || a.act == ACT_GEGLU || a.ln_stat) return 0;
   if (a.N % 320 != 0 || (a.ld_out & 7) || (a.resid && (a.ld_res & 7))) return 0;
   const int ksteps = gemm_count_ksteps(a);
   if (ksteps < 16 && (a.ntaps || mode < 3)) return 0;   // conv_in (K = 72): prologue + four-pass epilogue outweigh two k-steps (34.6 vs 24.3 us)
   if (a.ntaps == 0 && mode < 2) return 0;
-  auto rounds_ok = [](long tiles) { const long rem = tiles % 256; return tiles >= 224 && (rem == 0 || rem >= 224 || tiles >= 1024); };
-  if (rounds_ok((long)((a.M + 255) / 256) * (a.N / 320))) return 256;
-  if (m128 && rounds_ok((long)((a.M + 127) / 128) * (a.N / 320))) return 128;
-  return 0;
+  const long tiles = (long)((a.M + 255) / 256) * (a.N / 320), rem = tiles % 256;
+  return (tiles >= 224 && (rem == 0 || rem >= 224 || tiles >= 1024)) ? 1 : 0;
+}
+
+// GEGLU projections for the 256 x 256 tile: whole rounds of the CUs, as above.  DFH_GEMM_BIGG=0 turns it off (A/B).
+int gemm_big_geglu_pick(const GemmArgs& a) {
+  static const int mode = [] { const char* e = getenv("DFH_GEMM_BIGG"); return e ? atoi(e) : 1; }();
+  if (mode == 0 || a.act != ACT_GEGLU || a.out_mode != OUT_BF16 || a.resid || a.rowvec) return 0;
+  if (a.N % 256 != 0 || (a.ld_out & 7)) return 0;
+  const long tiles = (long)((a.M + 255) / 256) * (a.N / 256), rem = tiles % 256;
+  return (tiles >= 224 && (rem == 0 || rem >= 224 || tiles >= 1024)) ? 1 : 0;
 }
 
 bool gemm_ln_consumer_ok(GemmArgs a) {
@@ -831,12 +902,16 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
                          (a.ld_out & 7) == 0 && (!a.resid || (a.ld_res & 7) == 0);
     // tile id 21 pins the 256 x 320 tile (launches it cannot take -- fp32 / transposed outputs, GEGLU, N % 8 -- fall back to the
     // heuristic tile, like the forced wide ids); otherwise gemm_big_pick decides
-    const bool force_big = force_wide == 16 || force_wide == 17;     // ids 21 / 22: 256 / 128 rows
-    const int force_bm = force_wide == 17 ? 128 : 256;
+    const bool force_big = force_wide == 16;     // id 21
     if (force_big) force_wide = 0;
+    // tile id 23: the 256 x 256 GEGLU tile
+    const bool force_bigg = force_wide == 18;
+    if (force_bigg) force_wide = 0;
+    const bool bigg = wide_ok && !force_deep && a.act == ACT_GEGLU && a.N % 32 == 0 && !a.resid && !a.rowvec &&
+                      (force_bigg || (!force_wide && force_tile == 0 && force_split == 0 && gemm_big_geglu_pick(a)));
     const bool big_ok = wide_ok && !force_deep && a.act != ACT_GEGLU && !a.ln_stat;
-    const int big = !big_ok ? 0 : (force_big ? force_bm : ((!force_wide && force_tile == 0 && force_split == 0) ? gemm_big_pick(a) : 0));
-    int wide = (!wide_ok || force_deep || big || force_big) ? 0 : (force_wide ? force_wide : ((force_tile == 0 && force_split == 0) ? gemm_wide_pick(a) : 0));
+    const bool big = big_ok && (force_big || (!force_wide && force_tile == 0 && force_split == 0 && gemm_big_pick(a)));
+    int wide = (!wide_ok || force_deep || big || force_big || bigg || force_bigg) ? 0 : (force_wide ? force_wide : ((force_tile == 0 && force_split == 0) ? gemm_wide_pick(a) : 0));
     int ws = 0; bool halo = false;
 #ifdef DFH_PROBES
     // Probe builds only (scripts/probes/Makefile): tile ids 11 / 12 = the wave-specialised kernel (scripts/probes/kernels/gemm_ws.hip, opt-in
@@ -853,7 +928,8 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     DFH_REQUIRE(force_wide != 6 && force_wide != 7 && force_wide != 15 && !(force_wide >= 8 && force_wide <= 14),
                 "tile ids 11-20 are probe kernels: build scripts/probes (make -C scripts/probes) and load it with DFH_LIB");
 #endif
-    if (big) gemm_pick_tile_order(a, split, big, 320);
+    if (bigg) gemm_pick_tile_order(a, split, 256, 256);
+    else if (big) gemm_pick_tile_order(a, split, 256, 320);
     else if (ws) gemm_pick_tile_order(a, split, 256, ws);
     else if (wide) gemm_pick_tile_order(a, split, wide == 2 ? 128 : 256, wide == 3 ? 320 : (wide == 4 ? 128 : 160));
     else gemm_pick_tile_order(a, split, kTiles[tile].bm, kTiles[tile].bn);
@@ -862,7 +938,7 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     // output statistics for the consuming GroupNorm: only the 256 x 160 epilogue writes them, on full tiles inside one image
     const int gbn = big ? 320 : 160;
     const bool gst_ok = a.gstat && (halo || big || (wide == 1 && !ws)) && a.gstat_cpg > 0 && gbn % a.gstat_cpg == 0 && a.N % gbn == 0 &&
-                        a.N % a.gstat_cpg == 0 && a.M % 256 == 0 && a.gstat_hw % 256 == 0 && a.act != ACT_GEGLU && big != 128;
+                        a.N % a.gstat_cpg == 0 && a.M % 256 == 0 && a.gstat_hw % 256 == 0 && a.act != ACT_GEGLU;
     if (!gst_ok) a.gstat = nullptr;
     else if (gstat_written) *gstat_written = true;
     // per-row output statistics for a LayerNorm folded into the consumer: the staged bf16 epilogue of gemm_bf16_kernel and the 256-row
@@ -878,10 +954,11 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     else if (ws) rc = gemm_ws_launch(a, stream, ws);
     else
 #endif
-    if (big) rc = launch_big(a, stream, big);
+    if (bigg) rc = launch_big_geglu(a, stream);
+    else if (big) rc = launch_big(a, stream);
     else if (wide) rc = gemm_wide_launch(a, stream, wide);
     else rc = launch_variant(tile, a, stream);
-    census(big ? CK_GEMM_ROW : wide ? CK_GEMM_WIDE : ((halo || ws) ? CK_GEMM_OTHER : (tile == kEightWave ? (lean_plain(a) ? CK_GEMM_LEAN : CK_GEMM_8WAVE) : CK_GEMM_OTHER)));
+    census((big || bigg) ? CK_GEMM_ROW : wide ? CK_GEMM_WIDE : ((halo || ws) ? CK_GEMM_OTHER : (tile == kEightWave ? (lean_plain(a) ? CK_GEMM_LEAN : CK_GEMM_8WAVE) : CK_GEMM_OTHER)));
     if (a.gstat) census(CK_GSTAT_WRITTEN);
   }
   if (rc) return rc;

@@ -26,7 +26,13 @@ shapes += [
     ("lin 32^2 C640 +res", dict(M=16384, N=640, K=640)),
     ("qk 32^2 N1280", dict(M=16384, N=1280, K=640, bias=False, resid=False)),
 ]
-for rnd in range(2):
+from scripts.gemm_microbench import run as _run
+for rnd in range(2):       # the GEGLU projections: heuristic pick, the 256 x 256 eight-wave tile (23), the wide 256 x 128 tile (9)
+    for name, kw in (("geglu 64^2 N2560", dict(M=65536, N=2560, K=320)), ("geglu 32^2 N5120", dict(M=16384, N=5120, K=640)),
+                     ("geglu 16^2 N10240", dict(M=4096, N=10240, K=1280))):
+        for tile, tag in ((0, "auto"), (23, "256x256"), (9, "wide 256x128")):
+            _run(f"{name} [{tag}]", tile=tile, act=4, iters=30, warm=5, **kw)
+for rnd in range(0):
     for name, kw in shapes:
-        for tile, tag in ((0, "auto"), (21, "256x320"), (22, "128x320"), (6, "wide 256x160"), (10, "8-wave 128x160")):
+        for tile, tag in ((0, "auto"), (21, "256x320"), (6, "wide 256x160"), (10, "8-wave 128x160")):
             run(f"{name} [{tag}]", tile=tile, iters=30, warm=5, **kw)

@@ -140,6 +140,8 @@ def run_train(args, da, _lib, ddist, rank, world, dev):
     sched = da.DDIMScheduler()
     kw = train_inputs(dev, unet.config.cross_attention_dim, rank, args.outfits)
     K, W = args.steps, args.warmup
+    if args.wire is None:
+        args.wire = "bf16" if world > 1 else "fp32"
     unet.grad_wire_dtype = args.wire
     unet.measure_comm = world > 1          # two event records per step on the compute stream around its wait for the side stream
     step = lambda: da.train_step(unet, enc, sched, opt, ema_unet=ema, **kw)
@@ -347,8 +349,9 @@ def main():
     ap.add_argument("--mode", default="sample", choices=["sample", "train", "vae"],
                     help="sample: the headline metric (default); train: BASELINE configs[2]/[3] training step; vae: SURVEY 8f-1")
     ap.add_argument("--outfits", type=int, default=8, help="--mode train: outfits per GPU per step")
-    ap.add_argument("--wire", default="fp32", choices=["fp32", "bf16"],
-                    help="--mode train: gradient exchange format (bf16: all_to_all + fp32 accumulate + all_gather, half the bytes per link)")
+    ap.add_argument("--wire", default=None, choices=["fp32", "bf16"],
+                    help="--mode train: gradient exchange format (bf16: all_to_all + fp32 accumulate + all_gather, half the bytes per link); "
+                         "default: bf16 when more than one GPU takes part, fp32 (nothing is exchanged) on one")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: BASELINE configs[4] -- the LayerNorm-fed transformer projections in e4m3 on the block-scaled MFMA")
     args = ap.parse_args()

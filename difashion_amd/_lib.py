@@ -152,6 +152,9 @@ SIGNATURES = {
     "dfh_adamw": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
     "dfh_ema": (_i, [_vp, _vp, _sz, _f, _vp]),
     "dfh_adamw_ema": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp]),
+    "dfh_wire_pack": (_i, [_vp, _vp, _sz, _sz, _vp]),
+    "dfh_wire_shard_mean": (_i, [_vp, _vp, _i, _sz, _vp]),
+    "dfh_wire_unpack": (_i, [_vp, _vp, _sz, _vp]),
     "dfh_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "dfh_ln_fold": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "dfh_gemm_ln": (_i, [C.POINTER(GemmDesc), _vp, C.POINTER(C.c_int), _vp, _i, _i, _f, _vp, _vp]),

@@ -302,6 +302,16 @@ int dfh_ema(float* shadow, const float* p, size_t n, float decay, void* stream) 
   return dfh::ema_launch(shadow, p, (long)n, decay, (hipStream_t)stream);
 }
 
+int dfh_wire_pack(const float* g, void* wire, size_t n, size_t n_pad, void* stream) {
+  return dfh::wire_pack_launch(g, (bf16_t*)wire, (long)n, (long)n_pad, (hipStream_t)stream);
+}
+int dfh_wire_shard_mean(const void* recv, void* shard, int world, size_t per, void* stream) {
+  return dfh::wire_shard_mean_launch((const bf16_t*)recv, (bf16_t*)shard, world, (long)per, (hipStream_t)stream);
+}
+int dfh_wire_unpack(const void* wire, float* g, size_t n, void* stream) {
+  return dfh::wire_unpack_launch((const bf16_t*)wire, g, (long)n, (hipStream_t)stream);
+}
+
 int dfh_layernorm(const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps, void* stream) {
   return dfh::layernorm_launch((const bf16_t*)x, gamma, beta, (bf16_t*)y, M, C, eps, (hipStream_t)stream);
 }

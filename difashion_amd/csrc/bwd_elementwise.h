@@ -25,5 +25,9 @@ int assemble_bwd_launch(const float* dx, const unsigned char* mutual_real, float
 int sumsq_launch(const float* g, long n, float* out, hipStream_t s);
 int adamw_launch(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
                  int step, const float* sumsq, float max_norm, hipStream_t s, float* shadow = nullptr, float ema_decay = 0.f);
+// bf16 wire format of the gradient exchange (dist.py exchange_bf16)
+int wire_pack_launch(const float* g, bf16_t* wire, long n, long n_pad, hipStream_t s);
+int wire_shard_mean_launch(const bf16_t* recv, bf16_t* shard, int world, long per, hipStream_t s);
+int wire_unpack_launch(const bf16_t* wire, float* g, long n, hipStream_t s);
 int ema_launch(float* shadow, const float* p, long n, float decay, hipStream_t s);
 }  // namespace dfh

@@ -276,6 +276,53 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 // diffusers EMAModel.step: shadow -= (1 - decay) * (shadow - param)
+// ---- bf16 wire format of the data-parallel gradient exchange (difashion_amd/dist.py exchange_bf16; reference: DDP's all-reduce behind
+//      accelerator.backward, train.py:611,699).  Eight elements per thread, 16-byte accesses.
+// fp32 range -> bf16 wire (round to nearest even), zero-filled up to the padded length (a multiple of 8 per shard)
+__global__ void wire_pack_kernel(const float* __restrict__ g, bf16_t* __restrict__ wire, long n, long n_pad8) {
+  const long i = gtid();
+  if (i >= n_pad8) return;
+  float f[8];
+  if (i * 8 + 8 <= n) {
+    const float4 a = *(const float4*)(g + i * 8), b = *(const float4*)(g + i * 8 + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) f[r] = (i * 8 + r < n) ? g[i * 8 + r] : 0.f;
+  }
+  *(uint4*)(wire + i * 8) = pack8(f);
+}
+// this rank's shard: the W contributions summed in fp32 IN RANK ORDER (deterministic; every rank computes its own shard only, so all
+// ranks end with identical values), divided by W, rounded to bf16 once
+__global__ void wire_shard_mean_kernel(const bf16_t* __restrict__ recv, bf16_t* __restrict__ shard, int world, long per8, float wf) {
+  const long i = gtid();
+  if (i >= per8) return;
+  float acc[8];
+  unpack8(*(const uint4*)(recv + i * 8), acc);
+  for (int r = 1; r < world; ++r) {
+    float f[8];
+    unpack8(*(const uint4*)(recv + ((long)r * per8 + i) * 8), f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += f[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = acc[k] / wf;
+  *(uint4*)(shard + i * 8) = pack8(acc);
+}
+// bf16 wire -> fp32 range
+__global__ void wire_unpack_kernel(const bf16_t* __restrict__ wire, float* __restrict__ g, long n) {
+  const long i = gtid();
+  if (i * 8 >= n) return;
+  float f[8];
+  unpack8(*(const uint4*)(wire + i * 8), f);
+  if (i * 8 + 8 <= n) {
+    *(float4*)(g + i * 8) = float4{f[0], f[1], f[2], f[3]};
+    *(float4*)(g + i * 8 + 4) = float4{f[4], f[5], f[6], f[7]};
+  } else {
+    for (int r = 0; i * 8 + r < n; ++r) g[i * 8 + r] = f[r];
+  }
+}
+
 __global__ void ema_kernel(float* __restrict__ shadow, const float* __restrict__ p, long n, float one_minus_decay) {
   const long i = gtid();
   if (i >= n) return;
@@ -377,6 +424,18 @@ int adamw_launch(float* p, const float* g, float* m, float* v, long n, float lr,
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
   ProfScope ps(PC_OPTIM, 0.0, (shadow ? 36.0 : 28.0) * n, s);      // p r+w, g r, m r+w, v r+w (+ shadow r+w)
   EW_LAUNCH(adamw_kernel, n, p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2, sumsq, max_norm, shadow, 1.0f - ema_decay);
+}
+int wire_pack_launch(const float* g, bf16_t* wire, long n, long n_pad, hipStream_t s) {
+  DFH_REQUIRE(n >= 0 && n_pad >= n && n_pad % 8 == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)wire % 16) == 0, "wire_pack: padded length % 8, 16-byte aligned buffers");
+  EW_LAUNCH(wire_pack_kernel, n_pad / 8, g, wire, n, n_pad / 8);
+}
+int wire_shard_mean_launch(const bf16_t* recv, bf16_t* shard, int world, long per, hipStream_t s) {
+  DFH_REQUIRE(world >= 1 && per % 8 == 0 && ((uintptr_t)recv % 16) == 0 && ((uintptr_t)shard % 16) == 0, "wire_shard_mean: shard length % 8, 16-byte aligned buffers");
+  EW_LAUNCH(wire_shard_mean_kernel, per / 8, recv, shard, world, per / 8, (float)world);
+}
+int wire_unpack_launch(const bf16_t* wire, float* g, long n, hipStream_t s) {
+  DFH_REQUIRE(((uintptr_t)g % 16) == 0 && ((uintptr_t)wire % 16) == 0, "wire_unpack: 16-byte aligned buffers");
+  EW_LAUNCH(wire_unpack_kernel, (n + 7) / 8, wire, g, n);
 }
 int ema_launch(float* shadow, const float* p, long n, float decay, hipStream_t s) {
   ProfScope ps(PC_OPTIM, 0.0, 12.0 * n, s);

@@ -833,8 +833,9 @@ int gemm_big_geglu_pick(const GemmArgs& a) {
   static const int mode = [] { const char* e = getenv("DFH_GEMM_BIGG"); return e ? atoi(e) : 1; }();
   if (mode == 0 || a.act != ACT_GEGLU || a.out_mode != OUT_BF16 || a.resid || a.rowvec) return 0;
   if (a.N % 256 != 0 || (a.ld_out & 7)) return 0;
+  // (16x16 level: 640 tiles = 2.5 rounds, still 5 % ahead of the 256 x 128 tile in isolation: profiles/r03/geglu_tile_probe.txt)
   const long tiles = (long)((a.M + 255) / 256) * (a.N / 256), rem = tiles % 256;
-  return (tiles >= 224 && (rem == 0 || rem >= 224 || tiles >= 1024)) ? 1 : 0;
+  return (tiles >= 224 && (rem == 0 || rem >= 224 || tiles >= 512)) ? 1 : 0;
 }
 
 bool gemm_ln_consumer_ok(GemmArgs a) {

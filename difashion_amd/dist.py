@@ -83,43 +83,90 @@ def gather_mean(value: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def exchange_bf16(t: torch.Tensor) -> torch.Tensor:
+class Bf16Exchange:
+    """Persistent buffers of the bf16-wire gradient exchange: ``wire`` (this rank's range rounded to bf16, later the gathered averages),
+    ``recv`` (the W contributions to this rank's shard) and ``shard`` -- sized once for the largest range (``capacity`` floats) and reused
+    for every range of every step, so the exchange allocates NOTHING on the device inside the backward (2 x 128 MB per
+    256 MB range, ~14 ranges per step before).  One object per (device, capacity); ``for_range`` hands out the cached one."""
+
+    _cache = {}
+
+    def __init__(self, capacity: int, device, world: int):
+        self.world = world
+        self.per_max = ((capacity + world - 1) // world + 7) // 8 * 8          # shard length: a multiple of 8 (16-byte kernels)
+        self.wire = torch.zeros(world * self.per_max, dtype=torch.bfloat16, device=device)
+        self.recv = torch.zeros(world * self.per_max, dtype=torch.bfloat16, device=device)
+        self.shard = torch.zeros(self.per_max, dtype=torch.bfloat16, device=device)
+
+    @classmethod
+    def for_range(cls, n: int, device, world: int, capacity: int = 0) -> "Bf16Exchange":
+        key = (str(device), world)
+        ex = cls._cache.get(key)
+        need = max(n, capacity)
+        if ex is None or ex.per_max * world < ((need + world - 1) // world + 7) // 8 * 8 * world:
+            ex = cls(need, device, world)
+            cls._cache[key] = ex
+        return ex
+
+
+def exchange_bf16(t: torch.Tensor, capacity: int = 0) -> torch.Tensor:
     """Gradient average with a bf16 WIRE format and fp32 accumulation, in place on the fp32 range ``t``: half the bytes of an
     fp32 all-reduce on every xGMI link.  Direct reduce-scatter + all-gather, the natural pattern of the fully connected 8-GPU
     mesh (each pair of GPUs owns a link):
-      1. every rank rounds its range to bf16 and sends shard j to rank j (all_to_all: (W-1)/W of the bf16 range leaves the GPU);
-      2. rank j sums the W bf16 contributions of its shard IN FP32, in rank order (deterministic), divides by W, rounds to bf16;
-      3. the averaged shards are all-gathered in bf16 ((W-1)/W of the bf16 range arrives) and widened back to fp32.
+      1. every rank rounds its range to bf16 (dfh_wire_pack) and sends shard j to rank j (all_to_all: (W-1)/W of the bf16 range leaves
+         the GPU);
+      2. rank j sums the W bf16 contributions of its shard IN FP32, in rank order (deterministic), divides by W, rounds to bf16 -- ONE
+         kernel (dfh_wire_shard_mean);
+      3. the averaged shards are all-gathered in bf16 ((W-1)/W of the bf16 range arrives) and widened back to fp32 (dfh_wire_unpack).
     Every rank ends with the SAME values (each shard is computed by exactly one rank), so the replicas stay bit-identical.
-    gloo has no all_to_all: there step 1 is an all_gather of the whole bf16 range (test path only, same arithmetic)."""
+    The buffers are persistent (Bf16Exchange; ``capacity`` = the largest range the caller will pass, in floats): no device allocation
+    per call.  gloo has no all_to_all: there step 1 is an all_gather of the whole bf16 range staged through the host (test path only,
+    same arithmetic, same device buffers)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return t
     world, rank = dist.get_world_size(), dist.get_rank()
     n = t.numel()
-    per = (n + world - 1) // world
-    wire = torch.zeros(world * per, dtype=torch.bfloat16, device=t.device)
-    wire[:n].copy_(t.reshape(-1))
-    if dist.get_backend() == "nccl":
-        recv = torch.empty_like(wire)
-        dist.all_to_all_single(recv, wire)                       # recv[r * per:(r + 1) * per] = rank r's copy of MY shard
-        mine = recv.view(world, per)
-    else:
-        stage = (wire.cpu() if wire.is_cuda else wire).view(torch.uint8)          # raw 16-bit words: raw bytes: gloo transports neither bf16 nor int16
+    flat = t.reshape(-1)
+    if not t.is_cuda:                       # CPU tensors (gloo unit tests): the same arithmetic in torch ops
+        per = (n + world - 1) // world
+        wire = torch.zeros(world * per, dtype=torch.bfloat16)
+        wire[:n].copy_(flat)
+        stage = wire.view(torch.uint8)      # raw bytes: gloo transports neither bf16 nor int16
         bufs = [torch.empty_like(stage) for _ in range(world)]
         dist.all_gather(bufs, stage)
-        mine = torch.stack([b[2 * rank * per:2 * (rank + 1) * per] for b in bufs]).view(torch.bfloat16).to(t.device)
-    acc = mine[0].float()
-    for r in range(1, world):                                    # fixed order: deterministic
-        acc += mine[r].float()
-    shard = (acc / world).to(torch.bfloat16)
+        mine = torch.stack([b[2 * rank * per:2 * (rank + 1) * per] for b in bufs]).view(torch.bfloat16)
+        acc = mine[0].float()
+        for r in range(1, world):
+            acc += mine[r].float()
+        shard = (acc / world).to(torch.bfloat16)
+        bufs = [torch.empty(2 * per, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(bufs, shard.view(torch.uint8))
+        flat.copy_(torch.cat(bufs).view(torch.bfloat16)[:n])
+        return t
+    from . import _lib
+    ex = Bf16Exchange.for_range(n, t.device, world, capacity)
+    per = ((n + world - 1) // world + 7) // 8 * 8
+    wire, recv, shard = ex.wire[:world * per], ex.recv[:world * per], ex.shard[:per]
+    sp = _lib.stream_ptr()
+    _lib.call("dfh_wire_pack", _lib.ptr(flat), _lib.ptr(wire), n, world * per, sp)
+    if dist.get_backend() == "nccl":
+        dist.all_to_all_single(recv, wire)                       # recv[r * per:(r + 1) * per] = rank r's copy of MY shard
+    else:
+        torch.cuda.current_stream(t.device).synchronize()
+        stage = wire.cpu().view(torch.uint8)
+        bufs = [torch.empty_like(stage) for _ in range(world)]
+        dist.all_gather(bufs, stage)
+        recv.copy_(torch.cat([b[2 * rank * per:2 * (rank + 1) * per] for b in bufs]).view(torch.bfloat16))
+    _lib.call("dfh_wire_shard_mean", _lib.ptr(recv), _lib.ptr(shard), world, per, sp)
     if dist.get_backend() == "nccl":
         dist.all_gather_into_tensor(wire, shard)
     else:
-        stage = (shard.cpu() if shard.is_cuda else shard).view(torch.uint8)
+        torch.cuda.current_stream(t.device).synchronize()
+        stage = shard.cpu().view(torch.uint8)
         bufs = [torch.empty_like(stage) for _ in range(world)]
         dist.all_gather(bufs, stage)
-        wire = torch.cat(bufs).view(torch.bfloat16).to(t.device)
-    t.reshape(-1).copy_(wire[:n])
+        wire.copy_(torch.cat(bufs).view(torch.bfloat16))
+    _lib.call("dfh_wire_unpack", _lib.ptr(wire), _lib.ptr(flat), n, sp)
     return t
 
 

@@ -78,7 +78,29 @@ class FusedAdamW(torch.optim.Optimizer):
         since the last ``zero_grad`` -- never-used parameters (``MutualEncoder.category_embedding``, reference
         difashion.py:28), frozen ones, a module whose backward did not run this step (its lazily kept stale gradients must not
         be re-applied) all stay untouched, exactly as with the reference's optimizer."""
+        if self._collective_fresh is not None:            # data-parallel: the union over the ranks (see _sync_freshness)
+            return id(p) in self._collective_fresh
         return p.requires_grad and (self._all_fresh or getattr(p, "_dfh_grad_epoch", -1) >= self._zero_epoch)
+
+    _collective_fresh = None
+
+    def _sync_freshness(self) -> None:
+        """Data-parallel runs: ``step()`` runs after the gradients were AVERAGED over the ranks, so every rank holds the same gradient
+        for every parameter -- but the freshness stamps are local (autograd hook / native-backward stamp).  A parameter that received a
+        gradient on only some ranks (any data-dependent branch) would be updated only there and the replicas would drift apart
+        silently; torch DDP updates it everywhere.  So the fresh set is made collective: one all-reduce(MAX) of a per-parameter mask
+        (a few hundred bytes) per step.  No-op without an initialised process group."""
+        import torch.distributed as tdist
+        self._collective_fresh = None
+        if not (tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1):
+            return
+        plist = [p for g in self.param_groups for p in g["params"]]
+        local = [1 if self._fresh(p) else 0 for p in plist]
+        dev = self.flat_param.device if tdist.get_backend() == "nccl" else torch.device("cpu")
+        mask = torch.tensor(local, dtype=torch.int32, device=dev)
+        tdist.all_reduce(mask, op=tdist.ReduceOp.MAX)
+        union = mask.cpu().tolist()
+        self._collective_fresh = {id(p) for p, f in zip(plist, union) if f and p.requires_grad}
 
     def mark_fresh(self, params=None) -> None:
         """Declare gradients written by hand (``p.grad.copy_(g)``, a kernel writing into ``flat_grad``) as this step's:
@@ -167,6 +189,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 raise _lib.DfhError("FusedAdamW.step(ema=...): the EMA must cover a prefix of the optimizer's parameters")
         s = _lib.stream_ptr()
         self._step += 1
+        self._sync_freshness()
         total = self.flat_grad.numel()
         for g in self.param_groups:            # this update's per-parameter step counts
             for p in g["params"]:
@@ -199,6 +222,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 if hi > fe:
                     _lib.call("dfh_adamw", self.flat_param.data_ptr() + 4 * fe, self.flat_grad.data_ptr() + 4 * fe,
                               self.exp_avg.data_ptr() + 4 * fe, self.exp_avg_sq.data_ptr() + 4 * fe, hi - fe, *hyper, s)
+        self._collective_fresh = None
         _lib.bump_weight_epoch()          # packed bf16 copies of these weights are stale now
         return loss
 

@@ -501,7 +501,7 @@ class UNet2DConditionModel(nn.Module):
                 # on enqueuing the next layers on the compute stream.  (gloo, CPU-staged, blocks the host instead.)
                 if self.grad_wire_dtype == "bf16":
                     from .dist import exchange_bf16
-                    exchange_bf16(t)
+                    exchange_bf16(t, capacity=max(1, self.grad_bucket_bytes // 4))       # persistent wire buffers: no allocation here
                 else:
                     tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
                     t.div_(world)

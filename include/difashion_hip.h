@@ -329,6 +329,12 @@ int dfh_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, 
 int dfh_adamw_ema(float* p, const float* g, float* m, float* v, float* shadow, size_t n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, const float* sumsq, float max_norm, float ema_decay, void* stream);
 int dfh_ema(float* shadow, const float* p, size_t n, float decay, void* stream);
+/* bf16 wire format of the data-parallel gradient exchange (replaces DDP's fp32 all-reduce behind accelerator.backward, train.py:611,699;
+ * difashion_amd/dist.py exchange_bf16): fp32 range -> bf16 wire of n_pad elements (zero padding, n_pad % 8 == 0) | this rank's shard =
+ * the `world` received contributions ([world][per] bf16) summed in fp32 in rank order, / world, rounded once | bf16 wire -> fp32 range */
+int dfh_wire_pack(const float* g, void* wire, size_t n, size_t n_pad, void* stream);
+int dfh_wire_shard_mean(const void* recv, void* shard, int world, size_t per, void* stream);
+int dfh_wire_unpack(const void* wire, float* g, size_t n, void* stream);
 
 /* ------------------------------------------------------------------ DiFashion glue (reference-owned arithmetic)
  * Sibling reduce feeding MutualEncoder: df.py:160-170 (training mean) / df.py:475-489 (sampling sum).

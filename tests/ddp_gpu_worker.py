@@ -84,6 +84,24 @@ def main():
     both16 = [torch.zeros_like(d16) for _ in range(world)]
     tdist.all_gather(both16, d16)
     assert torch.equal(both16[0], both16[1]), both16          # identical averages on every rank -> identical replicas
+    # the exchange allocates nothing on the device once its buffers exist (dist.Bf16Exchange): the second step's overlapped backward
+    # must leave the caching allocator's allocation count where it was
+    orig = unet._backward_overlapped
+    counts = {}
+
+    def counted(*a, **k):
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_stats()["allocation.all.allocated"]
+        out = orig(*a, **k)
+        torch.cuda.synchronize()
+        counts["delta"] = torch.cuda.memory_stats()["allocation.all.allocated"] - before
+        return out
+
+    unet._backward_overlapped = counted
+    da.train_step(unet, enc, sched, opt, ema_unet=ema, **mine)
+    unet._backward_overlapped = orig
+    print(f"[rank {rank}] device allocations inside the overlapped backward (second step): {counts.get('delta')}", flush=True)
+    assert counts.get("delta") == 0, counts
     del unet, enc, opt, ema
     for overlapped in (False, True):
         unet, enc, opt, ema = build(rec)
@@ -115,6 +133,21 @@ def main():
     mine_d = torch.tensor([digest(opt.flat_param), digest(ema.flat)], dtype=torch.int64, device=DEV if NCCL else "cpu")
     tdist.all_gather(both, mine_d)
     assert torch.equal(both[0], both[1]), both
+    # freshness is collective: a parameter whose gradient was written on ONE rank only (a data-dependent branch) holds
+    # the same averaged gradient everywhere after the exchange and must be updated everywhere, as torch DDP would -- here the category
+    # embedding, which nothing uses in the product's loss: stamped on rank 0 only
+    emb = enc.category_embedding.weight
+    opt.zero_grad(lazy_modules=[unet])
+    emb.grad.fill_(0.25)
+    if rank == 0:
+        opt.mark_fresh([emb])
+    before = emb.detach().clone()
+    opt.step()
+    moved = float((emb.detach() - before).abs().max())
+    mine_d = torch.tensor([digest(opt.flat_param), 0], dtype=torch.int64, device=DEV if NCCL else "cpu")
+    tdist.all_gather(both, mine_d)
+    print(f"[rank {rank}] embedding stamped on rank 0 only: moved by {moved:.3e} on this rank", flush=True)
+    assert moved > 0.0 and torch.equal(both[0], both[1]), (moved, both)
     torch.cuda.synchronize()
     tdist.barrier()
     if rank == 0:

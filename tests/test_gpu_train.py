@@ -428,3 +428,31 @@ def test_segmented_backward_equals_the_monolithic_one():
         grads.append({n_: p.grad.clone() for n_, p in m.named_parameters()})
     for k in grads[0]:
         torch.testing.assert_close(grads[1][k], grads[0][k], rtol=1e-5, atol=1e-7, msg=k)
+
+
+def test_bf16_wire_kernels_match_the_torch_formulation():
+    """dist.exchange_bf16 on the device: dfh_wire_pack / dfh_wire_shard_mean / dfh_wire_unpack against the torch ops the CPU (gloo) path
+    uses -- bit for bit (the replicas of a data-parallel run must agree whichever path computed a shard): round to nearest even, zero
+    padding, rank-ordered fp32 sum, one division, one rounding."""
+    from difashion_amd import _lib
+    sp = _lib.stream_ptr
+    world, n = 4, 100003                                    # a range whose length is no multiple of anything
+    per = ((n + world - 1) // world + 7) // 8 * 8
+    g = torch.randn(n, device=DEV) * 3.0
+    wire = torch.full((world * per,), 7.0, dtype=torch.bfloat16, device=DEV)
+    _lib.call("dfh_wire_pack", _lib.ptr(g), _lib.ptr(wire), n, world * per, sp())
+    assert torch.equal(wire[:n], g.to(torch.bfloat16)) and float(wire[n:].abs().max()) == 0.0
+    recv = (torch.randn(world, per, device=DEV) * 2.0).to(torch.bfloat16)
+    shard = torch.empty(per, dtype=torch.bfloat16, device=DEV)
+    _lib.call("dfh_wire_shard_mean", _lib.ptr(recv), _lib.ptr(shard), world, per, sp())
+    acc = recv[0].float()
+    for r in range(1, world):
+        acc += recv[r].float()
+    assert torch.equal(shard, (acc / world).to(torch.bfloat16))
+    back = torch.full((n,), -1.0, device=DEV)
+    _lib.call("dfh_wire_unpack", _lib.ptr(wire), _lib.ptr(back), n, sp())
+    assert torch.equal(back, wire[:n].float())
+    # three ranks (no power of two: the division is a real division)
+    recv3 = recv[:3].contiguous()
+    _lib.call("dfh_wire_shard_mean", _lib.ptr(recv3), _lib.ptr(shard), 3, per, sp())
+    assert torch.equal(shard, ((recv3[0].float() + recv3[1].float() + recv3[2].float()) / 3).to(torch.bfloat16))

@@ -102,6 +102,7 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile = 0, int force_sp
 // lnfold.hip: W' = bf16(W * gamma) [N][K], s[n] = sum_k W'[n][k], b[n] = bias[n] (or 0) + sum_k W[n][k] * beta[k]
 int ln_fold_launch(const bf16_t* W, int ldw, const float* gamma, const float* beta, const float* bias, bf16_t* WF, float* s, float* b,
                    int N, int K, hipStream_t stream);
+int matvec_bias_launch(const bf16_t* W, int ldw, const float* v, const float* b_add, float* b_out, int N, int K, hipStream_t stream);
 // can a launch of this shape consume folded-LayerNorm statistics (single pass, an epilogue that implements the fix-up)?
 bool gemm_ln_consumer_ok(GemmArgs a);
 int gemm_pick_split(const GemmArgs& a, int* tile_out);

@@ -46,9 +46,28 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t* __restrict__
   }
 }
 
+// b_out[n] = b_add[n] + sum_j W[n][j] * v[j]   (bias of two chained linears folded into one: W = the second layer's weights)
+__global__ __launch_bounds__(256) void matvec_bias_kernel(const bf16_t* __restrict__ W, int ldw, const float* __restrict__ v,
+                                                          const float* __restrict__ b_add, float* __restrict__ b_out, int K) {
+  const int n = blockIdx.x;
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) acc = fmaf(bf2f(W[(long)n * ldw + k]), v[k], acc);
+  __shared__ float red[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) b_out[n] = (b_add ? b_add[n] : 0.f) + ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
 }  // namespace
 
 namespace dfh {
+
+int matvec_bias_launch(const bf16_t* W, int ldw, const float* v, const float* b_add, float* b_out, int N, int K, hipStream_t stream) {
+  DFH_REQUIRE(W && v && b_out && N > 0 && K > 0, "bad argument");
+  hipLaunchKernelGGL(matvec_bias_kernel, dim3(N), dim3(256), 0, stream, W, ldw, v, b_add, b_out, K);
+  return check_launch("matvec_bias_kernel");
+}
 
 int ln_fold_launch(const bf16_t* W, int ldw, const float* gamma, const float* beta, const float* bias, bf16_t* WF, float* s, float* b,
                    int N, int K, hipStream_t stream) {

@@ -15,6 +15,7 @@
 #include "gemm.h"
 #include "norm.h"
 #include "packtab.h"
+#include "bwd_elementwise.h"
 
 namespace dfhm {
 
@@ -48,6 +49,10 @@ struct Fold { size_t w = 0, s = 0, b = 0; int N = 0, K = 0; };
 struct AttL {
   int C = 0, heads = 0, x_off = 0;   // x_off: this layer's row offset in the batched cross K / V matrices
   Fold fqk, fv, fq2, fff1;
+  // ff.net.2 and proj_out folded into ONE linear over [GEGLU output | h2] (inference walk): W = [pout . ff2 | pout] ([C][5C]), bias =
+  // pout . ff2b + poutb -- proj_out(ff2(f) + ff2b + h2) + poutb as written, minus one launch, one bf16 rounding and one round trip
+  // of a [tokens][C] tensor per transformer block
+  Fold fffp;
   Vec nw, nb, pinb, l1w, l1b, o1b, l2w, l2b, o2b, l3w, l3b, ff1b, ff2b, poutb;
   Mat pin, qk, v, o1, q2, o2, ff1, ff2, pout;
   std::string pre; Mat pint, qkvt, o1t, q2t, o2t, ff1t, ff2t, poutt;
@@ -118,7 +123,7 @@ struct dfh_unet {
   int temb_total = 0, x_total = 0;   // x_total: sum of C over all transformer layers (batched text K/V)
   // folded-LayerNorm copies of the LayerNorm-fed projections (derived data, re-made by every pack): they live at the head of the
   // WORKSPACE, not in arena16 / arena32 -- the training path sizes its gradient arenas and its all-reduce by those
-  size_t fold16 = 0, fold32 = 0; bool fold_valid = false;
+  size_t fold16 = 0, fold32 = 0; bool fold_valid = false, fold_dirty = false;
   size_t fold_bytes() const { return ((fold16 * 2 + 255) & ~(size_t)255) + ((fold32 * 4 + 255) & ~(size_t)255); }
   bf16_t* fold_w() const { return (bf16_t*)ws; }
   float* fold_v() const { return (float*)(ws + ((fold16 * 2 + 255) & ~(size_t)255)); }
@@ -255,6 +260,7 @@ struct dfh_unet {
     a.pout = mat(pre + ".proj_out.weight", C, C, !lin);
     a.poutb = vec(pre + ".proj_out.bias", C);
     a.fqk = fold_alloc(2 * C, C); a.fv = fold_alloc(C, C); a.fq2 = fold_alloc(C, C); a.fff1 = fold_alloc(8 * C, C);
+    a.fffp = fold_alloc(C, 5 * C);
   }
 
   void build_conv(const std::string& pre, int cout, int cin, ConvL& c) {
@@ -413,7 +419,29 @@ struct dfh_unet {
                                          fold_w() + dst[i]->w, fold_v() + dst[i]->s, fold_v() + dst[i]->b, src[i]->N, src[i]->K, s)) return rc;
       }
     }
-    fold_valid = true;
+    // ff.net.2 . proj_out: [pout . ff2 | pout] and its bias.  The product runs on the GEMM kernel itself (A = pout [C][C], the W operand
+    // = ff2^T [4C][C], transposed into the activation workspace, which no walk is using while the weights are being derived)
+    bf16_t* scratch = (bf16_t*)(ws + fold_bytes());
+    bf16_t* zero = scratch;                                   // 256 zero bytes, then the transposed matrix
+    if (hipMemsetAsync(zero, 0, 256, s) != hipSuccess) { dfh::set_error("hipMemsetAsync failed"); return -2; }
+    for (AttL* a : all_att()) {
+      const int C = a->C;
+      if (C % 8) continue;
+      DFH_REQUIRE(fold_bytes() + 256 + (size_t)4 * C * C * 2 <= ws_bytes, "workspace too small for the weight-fold scratch");
+      bf16_t* w2t = scratch + 128;
+      if (int rc = dfh::transpose_bf16_launch(arena16 + a->ff2.off, w2t, 1, C, 4 * C, 4 * C, C, 0, 0, s)) return rc;
+      GemmArgs g; std::memset(&g, 0, sizeof(g));
+      g.M = C; g.N = 4 * C; g.rows_per_b = C;
+      g.p_src[0] = arena16 + a->pout.off; g.p_c[0] = C; g.nplain = 1;
+      g.W = w2t; g.ldw = C; g.zero = zero;
+      g.out = fold_w() + a->fffp.w; g.ld_out = 5 * C; g.out_mode = OUT_BF16;
+      if (int rc = dfh::gemm_launch(g, s, 0, /*force_split=*/1)) return rc;
+      if (hipMemcpy2DAsync(fold_w() + a->fffp.w + 4 * C, (size_t)5 * C * 2, arena16 + a->pout.off, (size_t)C * 2, (size_t)C * 2, C,
+                           hipMemcpyDeviceToDevice, s) != hipSuccess) { dfh::set_error("hipMemcpy2DAsync failed"); return -2; }
+      if (int rc = dfh::matvec_bias_launch(arena16 + a->pout.off, C, arena32 + a->ff2b.off, arena32 + a->poutb.off,
+                                           fold_v() + a->fffp.b, C, C, s)) return rc;
+    }
+    fold_valid = true; fold_dirty = false;
     return 0;
   }
 
@@ -640,8 +668,19 @@ struct dfh_unet {
           linear(n1.p, M, C, a.ff1, &a.ff1b, ACT_GEGLU, nullptr, ff.p, 8 * C);
         }
       }
-      linear(ff.p, M, 4 * C, a.ff2, &a.ff2b, ACT_NONE, h2.p, h0.p, C);   // h0 is dead by now: reuse
-      linear(h0.p, M, C, a.pout, &a.poutb, ACT_NONE, x.p, out.p, C, OUT_BF16, -1, 0, &out, &persist);   // feeds the next block's GroupNorm
+      static const bool ffp_off = [] { const char* e = getenv("DFH_FFP_FOLD"); return e && e[0] == '0'; }();      // A/B switch
+      // ff.net.2 and proj_out as ONE linear over the two K segments [GEGLU output | h2] (AttL::fffp) + the block's residual
+      GemmArgs gf = base(M, C);
+      gf.p_src[0] = ff.p; gf.p_c[0] = 4 * C; gf.p_src[1] = h2.p; gf.p_c[1] = C; gf.nplain = 2;
+      gf.ldw = 5 * C; gf.resid = x.p; gf.ld_res = C; gf.out = out.p;
+      if (dry) gemm(gf);                                                   // planning: its split-K slabs, whichever path runs later
+      if (u->fold_valid && !ffp_off && !dry) {
+        gf.W = u->fold_w() + a.fffp.w; gf.bias = u->fold_v() + a.fffp.b;
+        gemm(gf, &out, &persist);                                          // feeds the next block's GroupNorm
+      } else {
+        linear(ff.p, M, 4 * C, a.ff2, &a.ff2b, ACT_NONE, h2.p, h0.p, C);   // h0 is dead by now: reuse
+        linear(h0.p, M, C, a.pout, &a.poutb, ACT_NONE, x.p, out.p, C, OUT_BF16, -1, 0, &out, &persist);   // feeds the next block's GroupNorm
+      }
       temp.off = mark;
       return out;
     }
@@ -679,6 +718,7 @@ struct dfh_unet {
       if (fold_bytes() + head_bytes + plan_persist + plan_temp > ws_bytes) { dfh::set_error("workspace too small"); return -1; }
       (void)hipMemsetAsync(r.zero, 0, 256, s);
     }
+    if (!dry && fold_dirty) { if (int rc = fold_layernorms(s)) return rc; }      // derived weights (LayerNorm / ff2 . proj_out folds): lazily
     taps.clear();
 
     // ---- time embedding: sinusoid -> MLP (SiLU folded into both epilogues: only silu(emb) is ever
@@ -824,6 +864,7 @@ struct dfh_unet {
     if (int rc = tab_pack.launch(arena32, arena16, s)) return rc;
     if (int rc = tab_pack_acc.launch(arena32, arena16, s)) return rc;
     if (int rc = quantize_fp8(s)) return rc;   // e4m3 copies of the LayerNorm-fed projections from the freshly packed bf16 matrices
-    return fold_layernorms(s);
+    fold_valid = false; fold_dirty = true;     // the folded copies are re-derived by the next INFERENCE walk (a training step never pays)
+    return 0;
   }
 };

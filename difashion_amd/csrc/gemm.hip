@@ -192,15 +192,23 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
     }
   };
 
-  // LEAN staging: per-piece source pointers (the zero page with a zero stride for rows beyond M / N)
+  // LEAN staging: per-piece source pointers (the zero page with a zero stride for rows beyond M / N).  One or two plain segments of
+  // whole 64-channel slices: the W columns of the two are contiguous, the A pointers are re-based once, where the first segment ends
+  // (the [GEGLU output | h2] operand of the folded ff.net.2 . proj_out linear)
   const bf16_t* lp_a[IA]; const bf16_t* lp_w[IB];
   unsigned ls_a[IA], ls_w[IB];
+  int lean_left = 0x7fffffff;                        // k-steps left in the segment the A pointers walk
   if (LEAN) {
+    const int steps0 = a.p_c[0] / BK;
+    const bool in0 = ks_begin < steps0 || a.nplain < 2;
+    const unsigned ka = (unsigned)(in0 ? ks_begin : ks_begin - steps0) * BK + (unsigned)sslot * 8;
     const unsigned k0 = (unsigned)ks_begin * BK + (unsigned)sslot * 8;
+    if (in0 && a.nplain == 2) lean_left = steps0 - ks_begin;
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
       const bool ok = a_pix[i] >= 0;
-      lp_a[i] = ok ? psrc0 + ((size_t)(unsigned)a_pix[i] * (unsigned)a.p_c[0] + k0) : a.zero;
+      lp_a[i] = ok ? (in0 ? psrc0 + ((size_t)(unsigned)a_pix[i] * (unsigned)a.p_c[0] + ka)
+                          : psrc1 + ((size_t)(unsigned)a_pix[i] * (unsigned)a.p_c[1] + ka)) : a.zero;
       ls_a[i] = ok ? BK : 0;
     }
 #pragma unroll
@@ -213,6 +221,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
   auto issue_lean = [&](int buf) {
     unsigned char* As = smem + buf * STAGE + wave * 1024;
     unsigned char* Bs = As + A_BYTES;
+    if (lean_left == 0) {                            // block-uniform: the second segment starts here
+#pragma unroll
+      for (int i = 0; i < IA; ++i)
+        if (a_pix[i] >= 0) lp_a[i] = psrc1 + ((size_t)(unsigned)a_pix[i] * (unsigned)a.p_c[1] + (unsigned)sslot * 8);
+      lean_left = 0x7fffffff;
+    }
+    --lean_left;
 #pragma unroll
     for (int i = 0; i < IA; ++i) { glds(lp_a[i], As + i * NWV * 1024); lp_a[i] += ls_a[i]; }
 #pragma unroll
@@ -239,7 +254,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
   constexpr int NRES = FM * FN;                    // residual loads per lane
   static_assert(WEPI || BM * RS <= 2 * STAGE, "staged output tile must fit the pipeline buffers");
   static_assert(2 * N_HI + NRES <= 63, "vmcnt is a 6-bit counter");
-  const bool staged = !WEPI && a.ksplit == 1 && a.out_mode == OUT_BF16 && a.act != ACT_GEGLU && (a.N & 7) == 0 && (a.ld_out & 7) == 0;
+  // ... and the per-batch TRANSPOSED bf16 output (attention's V^T) as well when the tile lies inside one batch element: the tile is
+  // staged transposed and leaves as 16-byte pieces of the [channel][pixel] rows (the fragment layout alone writes 2-byte elements:
+  // 40 store instructions of 128 bytes per lane set)
+  const int tb_ = m0 / a.rows_per_b;
+  const bool tr = !WEPI && a.ksplit == 1 && a.out_mode == OUT_BF16_T && a.act != ACT_GEGLU && !a.resid && (a.ld_out & 7) == 0 &&
+                  (a.rows_per_b & 7) == 0 && tb_ == (min(m0 + BM, a.M) - 1) / a.rows_per_b;
+  const bool staged = tr || (!WEPI && a.ksplit == 1 && a.out_mode == OUT_BF16 && a.act != ACT_GEGLU && (a.N & 7) == 0 && (a.ld_out & 7) == 0);
   const bool staged_geglu = !WEPI && a.ksplit == 1 && a.act == ACT_GEGLU && (a.ld_out & 7) == 0;
   const bool res_pre = staged && a.resid != nullptr;
   uint2 rpre[FM][FN];
@@ -399,9 +420,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
     // every load behind its branch: ten dependent L2 round trips, 4.4-5.5k cycles of a tile whose K = 320 loop takes 6.6k
     // (in-kernel stamps); batched into registers they cost 8 VGPRs too many for two workgroups per CU.
     constexpr int STRIP = 2 * TN * 4;                // bias | rowvec (or the folded-LayerNorm s slice), fp32
-    constexpr int LNROW = BM * RS + NWV * STRIP;     // folded LayerNorm: (mean, rstd) of the tile's rows, fp32 pairs
+    constexpr int RST = BM * 2 + 16;                 // row stride of the TRANSPOSED staged tile ([BN][BM] bf16)
+    constexpr int TILE_B = BM * RS > BN * RST ? BM * RS : BN * RST;
+    constexpr int LNROW = TILE_B + NWV * STRIP;      // folded LayerNorm: (mean, rstd) of the tile's rows, fp32 pairs
     static_assert(WEPI || LNROW + BM * 8 <= NSTAGE * STAGE, "bias strips + row statistics must fit behind the staged output tile");
-    float* strip = (float*)(smem + BM * RS + wave * STRIP);
+    float* strip = (float*)(smem + TILE_B + wave * STRIP);
     const bool lnf = a.ln_stat != nullptr;
     // the time-embedding row is per image: through the strip when the whole tile lies in one image, else per fragment
     const bool rv_lds = a.rowvec != nullptr && (a.rv_ld == 0 || (m0 / a.rows_per_b) == ((min(m0 + BM, a.M) - 1) / a.rows_per_b));   // rv_ld == 0: one row for every image (cached timestep row)
@@ -455,11 +478,27 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
           v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
           v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
         }
-        uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-        *(uint2*)(smem + row * RS + col * 2) = o;
+        if (tr) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) *(bf16_t*)(smem + (col + r) * RST + row * 2) = f2bf(v[r]);
+        } else {
+          uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+          *(uint2*)(smem + row * RS + col * 2) = o;
+        }
       }
     }
     __syncthreads();
+    if (tr) {
+      constexpr int CPT = BM / 8;                    // 16-byte chunks per transposed row (one output channel, BM pixels)
+      const int mm0 = m0 - tb_ * a.rows_per_b;
+      for (int c = tid; c < BN * CPT; c += NWV * 64) {
+        const int col = c / CPT, cc = c - col * CPT;
+        const int n = n0 + col, m = m0 + cc * 8;
+        if (n < a.N && m < a.M)                      // M and rows_per_b are multiples of 8 here: whole chunks
+          *(uint4*)((bf16_t*)a.out + ((long)tb_ * a.N + n) * a.ld_out + mm0 + cc * 8) = *(const uint4*)(smem + col * RST + cc * 16);
+      }
+      return;
+    }
     constexpr int CPR = BN / 8;                      // 16-byte chunks per tile row
     for (int c = tid; c < BM * CPR; c += NWV * 64) {
       const int row = c / CPR, cc = c - row * CPR;
@@ -706,7 +745,8 @@ bool lean_plain(const GemmArgs& a) {
   // same-box A/B (scripts/gemm_lean_probe.py): 4096 x 1280 x {1280, 5120} 26.8 -> 25.7 / 77 -> 71 us (one workgroup per CU),
   // 0-3 % at two workgroups per CU -- the LDS-DMA issue itself (~100 cycles per 1-KB piece), not its address arithmetic,
   // is what paces the loop
-  return a.ntaps == 0 && a.nplain == 1 && a.p_c[0] % BK == 0 && a.p_c[0] > 0;
+  if (a.ntaps != 0 || a.nplain < 1 || a.p_c[0] % BK != 0 || a.p_c[0] <= 0) return false;
+  return a.nplain == 1 || (a.p_c[1] % BK == 0 && a.p_c[1] > 0);
 }
 
 // the "big" tile: 256 x 320, eight waves, 64-deep k-steps (see the kernel's WEPI note)

@@ -40,13 +40,20 @@ def test_gemm_splitk_matches_single_pass(split):
     assert gu.rel_err(out32, ref) < 2e-5      # fp32 output: only accumulation order differs
 
 
-def test_gemm_two_sources_is_channel_concat():
-    """K segments = torch.cat([h, skip], dim=1) feeding a 1x1 conv (up-path resnet shortcut)."""
-    M, N, C0, C1 = 256, 160, 192, 96
+@pytest.mark.parametrize("M,N,C0,C1,tile,split", [
+    (256, 160, 192, 96, 0, 0),        # ragged segment lengths: the general k-step iterator
+    (300, 320, 256, 64, 10, 0),       # whole 64-channel slices: the lean k-loop re-bases its A pointers where segment 0 ends
+    (300, 320, 256, 64, 21, 0),       # ... on the 256 x 320 tile ([GEGLU output | h2] of the folded ff.net.2 . proj_out linear)
+    (200, 160, 128, 320, 10, 3),      # split-K: the second and third slice START inside segment 1
+    (520, 640, 1280, 320, 0, 0),
+])
+def test_gemm_two_sources_is_channel_concat(M, N, C0, C1, tile, split):
+    """K segments = torch.cat([h, skip], dim=1) feeding a 1x1 conv (up-path resnet shortcut) / a folded pair of linears."""
     a0, a1 = bf(rnd(M, C0, seed=8)), bf(rnd(M, C1, seed=9))
     w = bf(rnd(N, C0 + C1, seed=10, scale=0.05))
-    out = gu.gemm(M=M, N=N, W=w, ldw=C0 + C1, a0=a0, a0_c=C0, a1=a1, a1_c=C1)
-    ref = torch.cat([a0, a1], 1).float() @ w.float().T
+    bias, res = rnd(N, seed=11), bf(rnd(M, N, seed=12))
+    out = gu.gemm(M=M, N=N, W=w, ldw=C0 + C1, a0=a0, a0_c=C0, a1=a1, a1_c=C1, bias=bias, resid=res, force_tile=tile, force_split=split)
+    ref = torch.cat([a0, a1], 1).float() @ w.float().T + bias + res.float()
     gu.assert_close_bf16(out, ref, "concat")
 
 
@@ -177,6 +184,20 @@ def test_gemm_transposed_outputs():
     out32 = torch.zeros((B, N, T), dtype=torch.float32, device=DEV)
     gu.gemm(M=B * T, N=N, W=w, ldw=K, a0=a, a0_c=K, out=out32, ld_out=T, out_mode=3, rows_per_b=T)
     assert gu.rel_err(out32, ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,rows,N,K,tile", [(3, 256, 160, 128, 0), (2, 1024, 320, 320, 10), (5, 64, 64, 64, 0), (2, 136, 96, 64, 4)])
+def test_gemm_transposed_output_staged_through_lds(B, rows, N, K, tile):
+    """V^T for the self-attention: tiles that lie inside one batch element leave as 16-byte pieces of the [channel][pixel] rows
+    (staged transposed through LDS); tiles that straddle two batch elements (rows = 64 < the 128-row tile; rows = 136) take the
+    element-wise path.  Row pitch larger than the row count (the walk pads to 8 keys)."""
+    a, w = bf(rnd(B * rows, K, seed=91)), bf(rnd(N, K, seed=92, scale=0.1))
+    ld = rows + 8
+    out = torch.zeros((B, N, ld), dtype=torch.bfloat16, device=DEV)
+    gu.gemm(M=B * rows, N=N, W=w, ldw=K, a0=a, a0_c=K, out=out, ld_out=ld, out_mode=1, rows_per_b=rows, force_tile=tile)
+    ref = (a.float() @ w.float().T).view(B, rows, N).transpose(1, 2)
+    gu.assert_close_bf16(out[:, :, :rows], ref, "bf16_T staged")
+    assert float(out[:, :, rows:].abs().max()) == 0.0
 
 
 # ----------------------------------------------------------------------------- conv3x3 as implicit GEMM

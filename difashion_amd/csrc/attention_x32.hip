@@ -37,6 +37,7 @@
 #include "dfh_common.h"
 #include "attention.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -439,6 +440,248 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Short key ranges: the cross-attention over the 77 text tokens (attn2 of BasicTransformerBlock, reference difashion.py:518-523).
+// With at most 2 * KVT keys the whole K / V^T of a (batch, head) fits the two LDS buffers: they are staged ONCE, and then every wave
+// walks `qrep` blocks of 32 * QB queries with no further barrier -- Q in, two score tiles, softmax, P.V, O out.  In the streaming
+// kernel above such a launch is all prologue and epilogue (one dependent chain of Q load -> tile staging -> barrier -> ... per 256
+// queries: 44 us for 84 MB at the 64x64 level); here the chain is paid once per workgroup and the per-block work of the four
+// waves of a workgroup (and of the two workgroups of a CU) overlaps freely.  The softmax is the exact deferred-max form of the
+// streaming kernel's SAFE pass on both tiles (two tiles: nothing to win from the fast pass), same fragment layouts, same numerics.
+template <int D, int QB>
+__global__ __launch_bounds__(256, 2) void attention_xs_kernel(const AttnArgs a, const int qrep) {
+  using G = X32Geom<D>;
+  constexpr int KS = G::KS, DB = G::DB, DCH = G::DCH, NCH = G::NCH, KROW = G::KROW, NKI = G::NKI, NVI = G::NVI;
+  constexpr int WQ = QB * 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, hi = lane >> 5;
+  const int per_wg = 4 * WQ * qrep;
+  const int nqb = (a.Nq + per_wg - 1) / per_wg;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lb / nqb, qblk = lb - bh * nqb;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const bf16_t* Qb = a.Q + (long)b * a.Nq * a.ldq + h * D;
+  const bf16_t* Kb = a.K + (long)b * a.Nk * a.ldk + h * D;
+  const bf16_t* Vb = a.Vt + (long)b * (a.vt_bstride ? a.vt_bstride : (long)a.H * D * a.ldvt) + (long)h * D * a.ldvt;
+  const int ntiles = (a.Nk + KVT - 1) / KVT;                 // 1 or 2 (the launcher guarantees Nk <= 2 * KVT)
+  const int tail_valid = a.Nk - (ntiles - 1) * KVT;
+
+  // ---- stage every key once: tile t -> buffer t (ragged tail zero-filled, mask column set), constant chunks as in the streaming kernel
+  for (int t = 0; t < ntiles; ++t) {
+    unsigned char* Ks = smem + t * G::BUF;
+    unsigned char* Vs = Ks + G::K_BYTES;
+    const int kv0 = t * KVT, first_masked = (t == ntiles - 1) ? tail_valid : KVT;
+    for (int idx = tid; idx < KVT * DCH; idx += 256) {
+      const int key = idx / DCH, ch = idx - key * DCH;
+      uint4 v = uint4{0u, 0u, 0u, 0u};
+      if (kv0 + key < a.Nk) v = *(const uint4*)(Kb + (long)(kv0 + key) * a.ldk + ch * 8);
+      *(uint4*)(Ks + key * KROW + ((ch ^ k_swz<KROW>(key)) << 4)) = v;
+    }
+    for (int idx = tid; idx < KVT * (NCH - DCH); idx += 256) {
+      const int key = idx / (NCH - DCH), ch = DCH + (idx - key * (NCH - DCH));
+      uint4 v = uint4{0u, 0u, 0u, 0u};
+      if (ch == DCH) v.x = key >= first_masked ? 0x3f803f80u : 0x00003f80u;      // {1.0, mask}
+      *(uint4*)(Ks + key * KROW + ((ch ^ k_swz<KROW>(key)) << 4)) = v;
+    }
+    for (int idx = tid; idx < D * 8; idx += 256) {
+      const int row = idx >> 3, ch = idx & 7;
+      const int k0 = kv0 + ch * 8;
+      uint4 v = uint4{0u, 0u, 0u, 0u};
+      if (k0 < a.Nk) {
+        v = *(const uint4*)(Vb + (long)row * a.ldvt + k0);       // ldvt >= roundup8(Nk): the chunk exists
+        if (k0 + 8 > a.Nk) {                                      // ragged tail: zero the padding keys (NaN-proof)
+          const int valid = a.Nk - k0;
+          uint32_t* w = (uint32_t*)&v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (e >= valid) w[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+        }
+      }
+      *(uint4*)(Vs + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = v;
+    }
+    if (tid < 16) {
+      const int row = D + (tid >> 3), ch = tid & 7;
+      const uint32_t w = row == D ? 0x3f803f80u : 0u;
+      *(uint4*)(Vs + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = uint4{w, w, w, w};
+    }
+  }
+  __syncthreads();
+
+  // ---- fragment read offsets (fixed per lane), as in the streaming kernel
+  const int kkey = swap23(ql);
+  int k_off[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) k_off[ks] = kkey * KROW + (((2 * ks + hi) ^ k_swz<KROW>(kkey)) << 4);
+  int v_row[DB], v_sw[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db) {
+    const int pr = min(db * 32 + ql, D + 1);
+    v_row[db] = pr * 128; v_sw[db] = (pr >> 1) & 7;
+  }
+  const float c = a.scale * 1.44269504088896340736f;
+
+  for (int rep = 0; rep < qrep; ++rep) {
+    const int q0 = qblk * per_wg + rep * 4 * WQ + wave * WQ;
+    if (q0 >= a.Nq) break;                                    // wave-uniform
+    uint4 qf[QB][KS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const int q = q0 + qb * 32 + ql;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        uint4 v = uint4{0u, 0u, 0u, 0u};
+        const int ch = 2 * ks + hi;
+        if (ch < DCH && q < a.Nq) {
+          const uint4 raw = *(const uint4*)(Qb + (long)q * a.ldq + ch * 8);
+          float f[8];
+          unpack8(raw, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] *= c;
+          v = pack8(f);
+        } else if (ch == DCH) {
+          v.x = pack2bf(0.0f, MASK_Q);
+        }
+        qf[qb][ks] = v;
+      }
+    }
+    f32x16_t o[DB][QB];
+    float m_run[QB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][qb][r] = 0.f;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) m_run[qb] = 0.f;
+
+    for (int t = 0; t < ntiles; ++t) {
+      const unsigned char* Ks = smem + t * G::BUF;
+      const unsigned char* Vs = Ks + G::K_BYTES;
+      f32x16_t s[2][QB];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8_t kf = *(const bf16x8_t*)(Ks + kb * 32 * KROW + k_off[ks]);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            if (ks == 0) {
+              f32x16_t z;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) z[r] = 0.f;
+              s[kb][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, __builtin_bit_cast(bf16x8_t, qf[qb][ks]), z, 0, 0, 0);
+            } else {
+              s[kb][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, __builtin_bit_cast(bf16x8_t, qf[qb][ks]), s[kb][qb], 0, 0, 0);
+            }
+          }
+        }
+      }
+      // deferred max (exact form): lane-local maxima, rescale when some score exceeds the running offset by 2^8 (always on tile 0)
+      float mx[QB];
+      bool over = false;
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        float c4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          c4[j] = fmaxf(s[0][qb][4 * j], s[1][qb][4 * j]);
+#pragma unroll
+          for (int r = 1; r < 4; ++r) c4[j] = fmaxf(fmaxf(c4[j], s[0][qb][4 * j + r]), s[1][qb][4 * j + r]);
+        }
+        mx[qb] = fmaxf(fmaxf(c4[0], c4[1]), fmaxf(c4[2], c4[3]));
+        over |= mx[qb] > THR;
+      }
+      if (t == 0 || __any(over)) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const float ml = fmaxf(mx[qb], lane_xor32(mx[qb]));
+          float m_new = m_run[qb] + ml;
+          if (t > 0) m_new = fmaxf(m_new, m_run[qb]);
+          m_new = bf2f(f2bf(m_new));                        // rides in a bf16 contraction slot of Q
+          const float delta = m_new - m_run[qb];
+          m_run[qb] = m_new;
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][qb][r] -= delta;
+          if (t > 0) {
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) o[db][qb][r] *= alpha;
+          }
+          if (hi == G::PAD_HI) qf[qb][G::PAD_KS].x = pack2bf(-m_new, MASK_Q);
+        }
+      }
+      uint32_t pw[2][QB][8];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2)
+            pw[kb][qb][r >> 1] = pack2bf(__builtin_amdgcn_exp2f(s[kb][qb][r]), __builtin_amdgcn_exp2f(s[kb][qb][r + 1]));
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+          for (int db = 0; db < DB; ++db) {
+            const bf16x8_t vf = *(const bf16x8_t*)(Vs + v_row[db] + (((kb * 4 + m2 * 2 + hi) ^ v_sw[db]) << 4));
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+              const uint4 pv = uint4{pw[kb][qb][4 * m2], pw[kb][qb][4 * m2 + 1], pw[kb][qb][4 * m2 + 2], pw[kb][qb][4 * m2 + 3]};
+              o[db][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8_t, pv), o[db][qb], 0, 0, 0);
+            }
+          }
+    }
+    // ---- normalise and store (layout as in the streaming kernel)
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const float lv = o[D / 32][qb][G::L_REG];
+      const float lo = lane_xor32(lv);
+      const float l = hi == G::L_HI ? lv : lo;
+      const float inv = 1.0f / l;
+      const int q = q0 + qb * 32 + ql;
+      if (q >= a.Nq) continue;
+      bf16_t* orow = a.O + ((long)b * a.Nq + q) * a.ldo + h * D;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = db * 32 + g * 8 + hi * 4;
+          if (d0 < D) {
+            uint2 w;
+            w.x = pack2bf(o[db][qb][4 * g] * inv, o[db][qb][4 * g + 1] * inv);
+            w.y = pack2bf(o[db][qb][4 * g + 2] * inv, o[db][qb][4 * g + 3] * inv);
+            *(uint2*)(orow + d0) = w;
+          }
+        }
+    }
+  }
+}
+
+template <int D, int QB>
+int launch_xs(const AttnArgs& a, hipStream_t stream) {
+  constexpr int lds = 2 * X32Geom<D>::BUF + 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attention_xs_kernel<D, QB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  // query blocks per wave: enough workgroups to give every CU its two, few enough to amortise the one-time K / V^T staging
+  const long units = (long)a.B * a.H * ((a.Nq + 128 * QB - 1) / (128 * QB));
+  int qrep = (int)std::max(1L, std::min(8L, units / 512));
+  const int nqb = (a.Nq + 128 * QB * qrep - 1) / (128 * QB * qrep);
+  dfh::ProfScope ps(dfh::PC_ATTN, 4.0 * a.B * a.H * (double)a.Nq * a.Nk * D,
+                    2.0 * a.B * a.H * D * (2.0 * a.Nq + 2.0 * a.Nk), stream);
+  hipLaunchKernelGGL((attention_xs_kernel<D, QB>), dim3(nqb * a.H * a.B), dim3(256), lds, stream, a, qrep);
+  return dfh::check_launch("attention_xs_kernel");
+}
+
 template <int D, int QB, int MINW, bool PROF = false>
 int launch_x32(const AttnArgs& a, hipStream_t stream) {
   constexpr int lds = 2 * X32Geom<D>::BUF + 16;
@@ -466,6 +709,12 @@ bool attention_x32_eligible(const AttnArgs& a) {
 
 int attention_x32_launch(const AttnArgs& a, hipStream_t stream) {
   census(CK_ATTN_X32);
+  // short key ranges (cross-attention): keys staged once, waves stream query blocks.  DFH_ATTN_XS=0 turns it off (A/B).
+  static const bool xs_off = [] { const char* e = getenv("DFH_ATTN_XS"); return e && e[0] == '0'; }();
+  if (!xs_off && a.Nk <= 2 * KVT && a.lse == nullptr) {
+    if (a.D == 40) return launch_xs<40, 2>(a, stream);
+    if (a.D == 80) return launch_xs<80, 1>(a, stream);
+  }
 #ifdef DFH_PROBES   // experiment instantiations (one / four query blocks per wave, phase stamps): probe builds only (scripts/probes/Makefile)
   static const int variant = [] { const char* e = getenv("DFH_ATTN_VARIANT"); return e ? atoi(e) : 0; }();   // experiments
   switch (a.D) {

@@ -403,6 +403,25 @@ def test_attention_x32_shapes(d, heads, Nq, Nk):
     gu.assert_close_bf16(o, ref, f"attention_x32 d={d} {Nq}x{Nk}", rel=1e-2, max_rel=4e-2)
 
 
+@pytest.mark.parametrize("d,heads", [(40, 8), (80, 4)])
+@pytest.mark.parametrize("B,Nq,Nk,gain", [(8, 4096, 77, 1.0), (2, 300, 13, 1.0), (3, 1024, 128, 1.0), (2, 512, 65, 4.0), (16, 1024, 77, 1.0)])
+def test_attention_short_key_ranges_stream_query_blocks(d, heads, B, Nq, Nk, gain):
+    """attention_xs_kernel (attention_x32.hip): cross-attention over <= 128 keys -- K / V^T staged once, every wave walks several query
+    blocks (B = 8 / 16 at 4096 / 1024 queries: two and more blocks per wave), one or two key tiles, ragged tails incl. a second tile of
+    ONE key, ragged query blocks, and scores whose maximum moves in the second tile (gain 4, one aligned key beyond key 64)."""
+    Cc = d * heads
+    q, k, v = bf(rnd(B, Nq, Cc, seed=70) * gain), bf(rnd(B, Nk, Cc, seed=71) * gain), bf(rnd(B, Nk, Cc, seed=72))
+    if Nk > 64:
+        k[:, Nk - 1] = q[:, 5] * 3.0       # the LAST key dominates query 5: the running offset is raised in tile 1
+    from difashion_amd import _lib as L
+    L.census_reset()
+    o = _attention(q, k, v, heads)
+    assert L.census()["attention_x32"] == 1
+    qh, kh, vh = (t.float().view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Nq, Cc)
+    gu.assert_close_bf16(o, ref, f"attention_xs d={d} {Nq}x{Nk}", rel=1.5e-2 if gain > 1 else 1e-2, max_rel=0.12 if gain > 1 else 4e-2)
+
+
 @pytest.mark.parametrize("d", [40, 80])
 @pytest.mark.parametrize("gain", [1.0, 4.0])
 def test_attention_x32_running_max_moves(d, gain):

@@ -337,6 +337,15 @@ int dfh_gemm_ln(const dfh_gemm_desc* d, float* rowstat, int* rowstat_bn, const f
   return rc;
 }
 
+int dfh_gemm_out2(const dfh_gemm_desc* d, void* out2, int ld_out2, int n_split, void* stream) {
+  GemmArgs g;
+  if (int rc = fill_gemm(d, &g)) return rc;
+  DFH_REQUIRE(out2 != nullptr, "null argument");
+  g.out2 = out2; g.ld_out2 = ld_out2; g.n_split = n_split;
+  DFH_REQUIRE(dfh::gemm_out2_ok(g), "this launch cannot carry a second destination (split-K, or n_split is no multiple of its column tile)");
+  return dfh::gemm_launch(g, (hipStream_t)stream, 0, 0, d->force_order);
+}
+
 int dfh_gemm_fp8(const void* A, const float* sA, const void* W, const float* sW, int M, int N, int K, const float* bias,
                  const void* resid, int ld_res, int act, void* out, int ld_out, int out_mode, int rows_per_b, const void* zero_page,
                  void* stream) {

@@ -38,6 +38,10 @@ struct GemmArgs {
   const bf16_t* resid; int ld_res;
   int act;
   void* out; int ld_out; int out_mode;
+  // optional SECOND destination: output columns [n_split, N) leave as OUT_BF16_T into out2 ([batch][N - n_split][ld_out2], batches of
+  // rows_per_b rows) while columns [0, n_split) follow out / out_mode -- attention's q | k and V^T from ONE launch over the shared
+  // LayerNorm-ed (or folded-LayerNorm) rows.  n_split must be a multiple of the column tile; single-pass gemm_bf16_kernel launches only.
+  void* out2; int ld_out2; int n_split;
   float* partial;  // [ksplit][M][N] fp32 when ksplit > 1
   // --- optional GroupNorm statistics of the OUTPUT, written by the 256-row epilogue (gemm_wide_epilogue.h) when the launcher finds
   //     the launch eligible: per (image, group, row tile) the sum and the sum of squares of the bf16-rounded outputs, in the layout
@@ -103,6 +107,8 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile = 0, int force_sp
 int ln_fold_launch(const bf16_t* W, int ldw, const float* gamma, const float* beta, const float* bias, bf16_t* WF, float* s, float* b,
                    int N, int K, hipStream_t stream);
 int matvec_bias_launch(const bf16_t* W, int ldw, const float* v, const float* b_add, float* b_out, int N, int K, hipStream_t stream);
+// can a launch carry GemmArgs::out2 (its heuristic tile divides n_split, no split-K)?
+bool gemm_out2_ok(GemmArgs a);
 // can a launch of this shape consume folded-LayerNorm statistics (single pass, an epilogue that implements the fix-up)?
 bool gemm_ln_consumer_ok(GemmArgs a);
 int gemm_pick_split(const GemmArgs& a, int* tile_out);

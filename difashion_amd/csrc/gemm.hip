@@ -258,9 +258,15 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
   // staged transposed and leaves as 16-byte pieces of the [channel][pixel] rows (the fragment layout alone writes 2-byte elements:
   // 40 store instructions of 128 bytes per lane set)
   const int tb_ = m0 / a.rows_per_b;
-  const bool tr = !WEPI && a.ksplit == 1 && a.out_mode == OUT_BF16_T && a.act != ACT_GEGLU && !a.resid && (a.ld_out & 7) == 0 &&
+  // second destination (GemmArgs::out2): the column tiles from n_split on are a transposed output of their own
+  const bool part2 = a.out2 != nullptr && n0 >= a.n_split;                      // block-uniform
+  const int omode = part2 ? (int)OUT_BF16_T : a.out_mode;
+  bf16_t* const tbase = part2 ? (bf16_t*)a.out2 : (bf16_t*)a.out;               // base / row pitch / channel count / first channel of the
+  const int tld = part2 ? a.ld_out2 : a.ld_out;                                  // transposed destination this tile writes (if any)
+  const int tN = part2 ? a.N - a.n_split : a.N, tn0 = part2 ? a.n_split : 0;
+  const bool tr = !WEPI && a.ksplit == 1 && omode == OUT_BF16_T && a.act != ACT_GEGLU && !a.resid && (tld & 7) == 0 &&
                   (a.rows_per_b & 7) == 0 && tb_ == (min(m0 + BM, a.M) - 1) / a.rows_per_b;
-  const bool staged = tr || (!WEPI && a.ksplit == 1 && a.out_mode == OUT_BF16 && a.act != ACT_GEGLU && (a.N & 7) == 0 && (a.ld_out & 7) == 0);
+  const bool staged = tr || (!WEPI && a.ksplit == 1 && omode == OUT_BF16 && a.act != ACT_GEGLU && (a.N & 7) == 0 && (a.ld_out & 7) == 0);
   const bool staged_geglu = !WEPI && a.ksplit == 1 && a.act == ACT_GEGLU && (a.ld_out & 7) == 0;
   const bool res_pre = staged && a.resid != nullptr;
   uint2 rpre[FM][FN];
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
         const int col = c / CPT, cc = c - col * CPT;
         const int n = n0 + col, m = m0 + cc * 8;
         if (n < a.N && m < a.M)                      // M and rows_per_b are multiples of 8 here: whole chunks
-          *(uint4*)((bf16_t*)a.out + ((long)tb_ * a.N + n) * a.ld_out + mm0 + cc * 8) = *(const uint4*)(smem + col * RST + cc * 16);
+          *(uint4*)(tbase + ((long)tb_ * tN + (n - tn0)) * tld + mm0 + cc * 8) = *(const uint4*)(smem + col * RST + cc * 16);
       }
       return;
     }
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
   for (int i = 0; i < FM; ++i) {
     const int m = m0 + wm * TM + i * 16 + fr;
     if (m >= a.M) continue;
-    const int b = (a.rowvec || a.out_mode == OUT_BF16_T || a.out_mode == OUT_F32_T) ? m / a.rows_per_b : 0;
+    const int b = (a.rowvec || omode == OUT_BF16_T || omode == OUT_F32_T) ? m / a.rows_per_b : 0;
     float2 lmr = float2{0.f, 1.f};
     if (a.ln_stat) lmr = ln_row_stats(a, m);              // the launcher refuses ln_stat with split-K or the GEGLU branch below
     if (a.act == ACT_GEGLU && !partial) {
@@ -644,16 +650,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
         v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
         v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
       }
-      if (a.out_mode == OUT_BF16) {
+      if (omode == OUT_BF16) {
         uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
         *(uint2*)((bf16_t*)a.out + (long)m * a.ld_out + n) = o;
-      } else if (a.out_mode == OUT_F32) {
+      } else if (omode == OUT_F32) {
         *(float4*)((float*)a.out + (long)m * a.ld_out + n) = float4{v[0], v[1], v[2], v[3]};
-      } else if (a.out_mode == OUT_BF16_T) {
+      } else if (omode == OUT_BF16_T) {
         const int mm = m - b * a.rows_per_b;
-        bf16_t* o = (bf16_t*)a.out + ((long)b * a.N + n) * a.ld_out + mm;
+        bf16_t* o = tbase + ((long)b * tN + (n - tn0)) * tld + mm;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[(long)r * a.ld_out] = f2bf(v[r]);
+        for (int r = 0; r < 4; ++r) o[(long)r * tld] = f2bf(v[r]);
       } else {  // OUT_F32_T
         const int mm = m - b * a.rows_per_b;
         float* o = (float*)a.out + ((long)b * a.N + n) * a.ld_out + mm;
@@ -878,6 +884,15 @@ int gemm_big_geglu_pick(const GemmArgs& a) {
   return (tiles >= 224 && (rem == 0 || rem >= 224 || tiles >= 512)) ? 1 : 0;
 }
 
+bool gemm_out2_ok(GemmArgs a) {
+  if (a.rows_per_b <= 0) a.rows_per_b = a.M;
+  a.ksteps = gemm_count_ksteps(a);
+  int tile;
+  if (gemm_pick_split(a, &tile) != 1) return false;
+  return a.out2 != nullptr && a.n_split > 0 && a.n_split < a.N && a.n_split % kTiles[tile].bn == 0 && a.act != ACT_GEGLU &&
+         a.out_mode == OUT_BF16 && !a.resid;
+}
+
 bool gemm_ln_consumer_ok(GemmArgs a) {
   if (a.rows_per_b <= 0) a.rows_per_b = a.M;
   a.ksteps = gemm_count_ksteps(a);
@@ -929,6 +944,8 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
                 "folded LayerNorm: single-pass launches without rowvec / residual only (gemm_ln_consumer_ok)");
     DFH_REQUIRE(a.act != ACT_GEGLU || (a.ld_out & 7) == 0, "folded LayerNorm + GEGLU needs 16-byte aligned output rows");
   }
+  if (a.out2) DFH_REQUIRE(split == 1 && a.n_split > 0 && a.n_split % kTiles[tile].bn == 0 && a.out_mode == OUT_BF16 && a.act != ACT_GEGLU &&
+                          !a.resid && force_tile == 0, "second destination: single pass, n_split a multiple of the column tile (gemm_out2_ok)");
   if (a.resid) DFH_REQUIRE((double)a.M * a.ld_res * 2.0 < 4.0e9, "residual tensor must be smaller than 4 GB (32-bit lane offsets)");
   int rc;
   {
@@ -939,7 +956,7 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     const double obytes = (double)a.M * (a.act == ACT_GEGLU ? a.N / 2 : a.N) * ((a.out_mode == OUT_F32 || a.out_mode == OUT_F32_T) ? 4.0 : 2.0) +
                           (a.resid ? (double)a.M * a.N * 2.0 : 0.0);      // the residual is an operand too: read once
     ProfScope ps(a.ntaps ? PC_CONV3 : PC_LINEAR, 2.0 * a.M * a.N * kreal, abytes + (double)a.N * kreal * 2.0 + obytes, stream);
-    const bool wide_ok = split == 1 && a.out_mode == OUT_BF16 && (a.act != ACT_GEGLU || a.N % 160 == 0 || a.N % 128 == 0) && (a.N & 7) == 0 &&
+    const bool wide_ok = split == 1 && a.out2 == nullptr && a.out_mode == OUT_BF16 && (a.act != ACT_GEGLU || a.N % 160 == 0 || a.N % 128 == 0) && (a.N & 7) == 0 &&
                          (a.ld_out & 7) == 0 && (!a.resid || (a.ld_res & 7) == 0);
     // tile id 21 pins the 256 x 320 tile (launches it cannot take -- fp32 / transposed outputs, GEGLU, N % 8 -- fall back to the
     // heuristic tile, like the forced wide ids); otherwise gemm_big_pick decides

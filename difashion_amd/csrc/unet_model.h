@@ -48,7 +48,7 @@ struct Fold { size_t w = 0, s = 0, b = 0; int N = 0, K = 0; };
 
 struct AttL {
   int C = 0, heads = 0, x_off = 0;   // x_off: this layer's row offset in the batched cross K / V matrices
-  Fold fqk, fv, fq2, fff1;
+  Fold fqkv, fqk, fv, fq2, fff1;
   // ff.net.2 and proj_out folded into ONE linear over [GEGLU output | h2] (inference walk): W = [pout . ff2 | pout] ([C][5C]), bias =
   // pout . ff2b + poutb -- proj_out(ff2(f) + ff2b + h2) + poutb as written, minus one launch, one bf16 rounding and one round trip
   // of a [tokens][C] tensor per transformer block
@@ -259,7 +259,12 @@ struct dfh_unet {
     a.ff2b = vec(tb + ".ff.net.2.bias", C);
     a.pout = mat(pre + ".proj_out.weight", C, C, !lin);
     a.poutb = vec(pre + ".proj_out.bias", C);
-    a.fqk = fold_alloc(2 * C, C); a.fv = fold_alloc(C, C); a.fq2 = fold_alloc(C, C); a.fff1 = fold_alloc(8 * C, C);
+    // q | k and v share one folded matrix [3C][C] (and one s / b' vector): ONE launch writes q | k and V^T (GemmArgs::out2); fqk / fv
+    // are views of it for the two-launch fallback
+    a.fqkv = fold_alloc(3 * C, C);
+    a.fqk = a.fqkv; a.fqk.N = 2 * C;
+    a.fv = a.fqkv; a.fv.N = C; a.fv.w += (size_t)2 * C * C; a.fv.s += 2 * C; a.fv.b += 2 * C;
+    a.fq2 = fold_alloc(C, C); a.fff1 = fold_alloc(8 * C, C);
     a.fffp = fold_alloc(C, 5 * C);
   }
 
@@ -632,14 +637,37 @@ struct dfh_unet {
       Tensor qk = talloc(H, W, 2 * C);
       const int Np = (N + 7) & ~7;    // V^T rows padded to 8 keys (the 2x2 level of tiny configs has N = 4)
       bf16_t* vt = (bf16_t*)temp.alloc((size_t)B * C * Np * 2);   // [B][C][Np]
-      if (!try_folded({folded(h0.p, M, a.fqk, st, bn, ACT_NONE, qk.p, OUT_BF16, -1, 0),
-                       folded(h0.p, M, a.fv, st, bn, ACT_NONE, vt, OUT_BF16_T, Np, N)})) {
+      // q | k and V^T from ONE launch (columns 2C .. 3C leave transposed into vt: GemmArgs::out2) wherever the column tile divides 2C;
+      // DFH_QKV_MERGE=0 keeps the two launches (A/B)
+      static const bool merge_off = [] { const char* e = getenv("DFH_QKV_MERGE"); return e && e[0] == '0'; }();
+      auto with_v = [&](GemmArgs g) {               // q | k launch -> q | k | v: same rows, N = 3C, the v columns into vt
+        g.N = 3 * C; g.out2 = vt; g.ld_out2 = Np; g.n_split = 2 * C; g.rows_per_b = N;
+        return g;
+      };
+      const bool v_contig = a.v.off == a.qk.off + (size_t)2 * C * C && a.v.K == a.qk.K;   // packed back to back (build_attn)
+      bool done = false;
+      if (!f8 && !merge_off && !dry) {
+        GemmArgs gq = with_v(folded(h0.p, M, a.fqk, st, bn, ACT_NONE, qk.p, OUT_BF16, 2 * C, 0));
+        if (dfh::gemm_out2_ok(gq)) done = try_folded({gq});
+      }
+      if (!done) done = try_folded({folded(h0.p, M, a.fqk, st, bn, ACT_NONE, qk.p, OUT_BF16, -1, 0),
+                                    folded(h0.p, M, a.fv, st, bn, ACT_NONE, vt, OUT_BF16_T, Np, N)});
+      if (!done) {
         if (f8) layernorm8(h0.p, a.l1w, a.l1b, n8, s8, M, C);
         else layernorm(h0.p, a.l1w, a.l1b, n1.p, M, C);
-        if (f8) linear8(n8, s8, M, a.qk8, nullptr, ACT_NONE, qk.p);
-        else linear(n1.p, M, C, a.qk, nullptr, ACT_NONE, nullptr, qk.p, 2 * C);
-        if (f8) linear8(n8, s8, M, a.v8, nullptr, ACT_NONE, vt, OUT_BF16_T, Np, N);
-        else linear(n1.p, M, C, a.v, nullptr, ACT_NONE, nullptr, vt, C, OUT_BF16_T, Np, N);
+        bool merged = false;
+        if (!f8 && !merge_off && !dry && v_contig) {
+          GemmArgs g = base(M, 2 * C);
+          g.p_src[0] = n1.p; g.p_c[0] = C; g.nplain = 1; g.W = w16(a.qk); g.ldw = C; g.out = qk.p; g.ld_out = 2 * C;
+          g = with_v(g);
+          if (dfh::gemm_out2_ok(g)) { gemm(g); merged = true; }
+        }
+        if (!merged) {
+          if (f8) linear8(n8, s8, M, a.qk8, nullptr, ACT_NONE, qk.p);
+          else linear(n1.p, M, C, a.qk, nullptr, ACT_NONE, nullptr, qk.p, 2 * C);
+          if (f8) linear8(n8, s8, M, a.v8, nullptr, ACT_NONE, vt, OUT_BF16_T, Np, N);
+          else linear(n1.p, M, C, a.v, nullptr, ACT_NONE, nullptr, vt, C, OUT_BF16_T, Np, N);
+        }
       }
       Tensor at = talloc(H, W, C);
       attention(qk.p, 2 * C, qk.p + C, 2 * C, vt, Np, at.p, C, a.heads, N, N);

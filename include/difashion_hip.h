@@ -243,6 +243,11 @@ int dfh_groupnorm_pre(const void* src, int c, int batch, int hw, int groups, con
                       int silu, void* out, const float* gstat, int chunks, float* stats_out, void* stream);
 /* LayerNorm over the last dim of [M][C] bf16 (BasicTransformerBlock.norm1/2/3) */
 int dfh_layernorm(const void* x, const float* gamma, const float* beta, void* y, int M, int C, float eps, void* stream);
+/* dfh_gemm with a SECOND destination: output columns [n_split, N) leave transposed per batch of d->rows_per_b rows into out2
+ * ([batch][N - n_split][ld_out2] bf16), columns [0, n_split) into d->out as usual -- attention's q | k and V^T from one launch over the
+ * rows both projections share (diffusers Attention.to_q / to_k / to_v of attn1).  Fails when the launch heuristics would split K or
+ * pick a column tile that does not divide n_split. */
+int dfh_gemm_out2(const dfh_gemm_desc* d, void* out2, int ld_out2, int n_split, void* stream);
 /* ---- LayerNorm folded into the projections around it (inference walk of BasicTransformerBlock: x + attn1(LN1(x)), + attn2(LN2(x)),
  * + ff(LN3(x)); reached from df.py:518-523).  LN(x) . W^T = rstd * (x . W'^T - mean * s) + b' with W' = W * gamma, s = rowsum(W'),
  * b' = bias + W . beta: the consumer GEMM runs on the raw rows and fixes them up in its epilogue, the statistics come from the

@@ -200,6 +200,30 @@ def test_gemm_transposed_output_staged_through_lds(B, rows, N, K, tile):
     assert float(out[:, :, rows:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,rows,C", [(2, 1024, 320), (3, 256, 64), (2, 136, 128), (5, 64, 256)])
+def test_gemm_second_transposed_destination(B, rows, C):
+    """dfh_gemm_out2: q | k (columns 0 .. 2C, row-major) and V^T (columns 2C .. 3C, transposed per batch element) from ONE launch over
+    the shared rows -- against the two separate launches (bit for bit: same products, same order) and the fp32 reference; batch
+    elements smaller than / not a multiple of the row tile (the element-wise transposed path)."""
+    import ctypes
+    M, K = B * rows, C
+    a, w = bf(rnd(M, K, seed=95)), bf(rnd(3 * C, K, seed=96, scale=0.08))
+    ld = rows + 8
+    qk = torch.zeros((M, 2 * C), dtype=torch.bfloat16, device=DEV)
+    vt = torch.zeros((B, C, ld), dtype=torch.bfloat16, device=DEV)
+    d = gu.gemm_desc(M=M, N=3 * C, W=w, ldw=K, a0=a, a0_c=K, out=qk, ld_out=2 * C, rows_per_b=rows)
+    _lib.call("dfh_gemm_out2", ctypes.byref(d), _lib.ptr(vt), ld, 2 * C, gu.stream())
+    torch.cuda.synchronize()
+    ref = a.float() @ w.float().T
+    gu.assert_close_bf16(qk, ref[:, :2 * C], "q|k part")
+    gu.assert_close_bf16(vt[:, :, :rows], ref[:, 2 * C:].view(B, rows, C).transpose(1, 2), "V^T part")
+    assert float(vt[:, :, rows:].abs().max()) == 0.0
+    qk2 = gu.gemm(M=M, N=2 * C, W=w[:2 * C].contiguous(), ldw=K, a0=a, a0_c=K)
+    vt2 = torch.zeros_like(vt)
+    gu.gemm(M=M, N=C, W=w[2 * C:].contiguous(), ldw=K, a0=a, a0_c=K, out=vt2, ld_out=ld, out_mode=1, rows_per_b=rows)
+    assert torch.equal(qk, qk2) and torch.equal(vt, vt2)
+
+
 # ----------------------------------------------------------------------------- conv3x3 as implicit GEMM
 @pytest.mark.parametrize("cin,cout,H,stride,ups", [
     (64, 160, 16, 1, 0), (32, 64, 8, 1, 0), (320, 320, 16, 1, 0), (64, 64, 16, 2, 0), (64, 128, 8, 1, 1),
@@ -416,7 +440,7 @@ def test_attention_short_key_ranges_stream_query_blocks(d, heads, B, Nq, Nk, gai
     from difashion_amd import _lib as L
     L.census_reset()
     o = _attention(q, k, v, heads)
-    assert L.census()["attention_x32"] == 1
+    assert L.census()["attention_x32"] == (1 if Nk >= 64 else 0)      # fewer than 64 keys: the 16x16 kernel
     qh, kh, vh = (t.float().view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
     ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Nq, Cc)
     gu.assert_close_bf16(o, ref, f"attention_xs d={d} {Nq}x{Nk}", rel=1.5e-2 if gain > 1 else 1e-2, max_rel=0.12 if gain > 1 else 4e-2)

@@ -200,7 +200,7 @@ def test_gemm_transposed_output_staged_through_lds(B, rows, N, K, tile):
     assert float(out[:, :, rows:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("B,rows,C", [(2, 1024, 320), (3, 256, 64), (2, 136, 128), (5, 64, 256)])
+@pytest.mark.parametrize("B,rows,C", [(2, 1024, 320), (3, 256, 160), (2, 136, 128), (5, 64, 256)])
 def test_gemm_second_transposed_destination(B, rows, C):
     """dfh_gemm_out2: q | k (columns 0 .. 2C, row-major) and V^T (columns 2C .. 3C, transposed per batch element) from ONE launch over
     the shared rows -- against the two separate launches (bit for bit: same products, same order) and the fp32 reference; batch

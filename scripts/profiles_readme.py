@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Regenerates the numbers of a round's section in profiles/README.md FROM the committed artefacts of that round (bench JSON lines,
+rocprofv3 kernel_stats.csv, pmc_traffic.json), so that the prose cannot drift away from the files it cites (hygiene).
+Usage: python scripts/profiles_readme.py r03 [--check]     (--check: exit 1 if the committed block differs; tests/test_host_logic_cpu.py)"""
+import csv, json, os, re, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def last_json(path):
+    try:
+        lines = [l for l in open(path).read().strip().splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if lines else None
+    except OSError:
+        return None
+
+
+def gemm_family(stats_csv):
+    """(launches, total ms, avg us) of the implicit-GEMM family in a rocprofv3 kernel_stats.csv."""
+    n, ns = 0, 0.0
+    for r in csv.DictReader(open(stats_csv)):
+        name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        if name.startswith(("gemm_bf16_kernel", "gemm_wide_kernel")):
+            n += int(r["Calls"]); ns += float(r["TotalDurationNs"])
+    return n, ns / 1e6, (ns / n / 1e3 if n else 0.0)
+
+
+def block(tag):
+    d = os.path.join(ROOT, "profiles", tag)
+    out = []
+    b = last_json(os.path.join(d, "bench_n1.json"))
+    if b:
+        rf, kc = b["roofline"], b.get("kernel_classes", {})
+        out.append(f"* sampling (`{tag}/bench_n1.json`): **{b['value']:.1f} outfit-steps/s** ({b['ms_per_step']:.2f} ms per step), "
+                   f"`roofline.frac` {rf['frac']:.3f} ({rf['achieved']:.0f} TFLOP/s over {rf['launches_per_step']} GEMM launches per step, "
+                   f"{rf['avg_launch_us']:.1f} us per launch from the HIP events)"
+                   + (f", `roofline.traffic` {rf['traffic'] / 1e6:.1f} MB per launch against {rf['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic "
+                      f"({rf['traffic'] / rf['algorithmic_bytes_per_launch']:.2f} x)" if rf.get("traffic") else ", `roofline.traffic` null (no PMC summary for these sources)") + ".")
+        if kc:
+            out.append("* per class, ms per step (launches): " + "; ".join(
+                f"{k} {v['ms_per_step']:.2f} ({v['launches_per_step']})" + (f" at {v['tflops']:.0f} TFLOP/s" if v.get("tflops") else "")
+                for k, v in kc.items() if v["launches_per_step"]) + ".")
+        sec = rf.get("secondary", {})
+        if sec:
+            out.append("* secondary rooflines: " + "; ".join(f"{k} {v['achieved']:.0f} {v['unit']} = {v['frac']:.3f} of {v['peak']:.0f}" for k, v in sec.items()) + ".")
+        cb = b.get("cpu_baseline")
+        if cb:
+            out.append(f"* CPU baseline beside it: {cb['value']:.4f} {cb['unit']} on {cb['cores']} host threads ({cb['kind']}).")
+    f8 = last_json(os.path.join(d, "bench_fp8_n1.json"))
+    if f8:
+        out.append(f"* `--dtype fp8` (`{tag}/bench_fp8_n1.json`): {f8['value']:.1f} steps/s ({f8['ms_per_step']:.2f} ms per step).")
+    tr = last_json(os.path.join(d, "bench_train_n1.json"))
+    if tr:
+        out.append(f"* training step (`{tag}/bench_train_n1.json`): {tr['value']:.1f} {tr['unit']} ({tr['ms_per_step']:.1f} ms per step).")
+    va = last_json(os.path.join(d, "bench_vae_n1.json"))
+    if va:
+        out.append(f"* VAE (`{tag}/bench_vae_n1.json`): {va['value']:.1f} {va['unit']}.")
+    st = os.path.join(d, "kernel_stats.csv")
+    if os.path.exists(st):
+        n, ms, us = gemm_family(st)
+        line = f"* rocprofv3 (`{tag}/kernel_stats.csv`): {n} launches of the GEMM family total {ms:.2f} ms = {us:.1f} us per launch"
+        if b:
+            line += f"; `roofline.avg_launch_us` of the committed bench line (another run, HIP events): {b['roofline']['avg_launch_us']:.1f} us"
+        out.append(line + ".")
+    pt = os.path.join(d, "pmc_traffic.json")
+    if os.path.exists(pt):
+        p = json.load(open(pt))
+        out.append(f"* PMC (`{tag}/pmc_traffic.json`): FETCH_SIZE {p['fetch_size_kb_per_launch']:.0f} KiB (x2 on gfx950) + WRITE_SIZE "
+                   f"{p['write_size_kb_per_launch']:.0f} KiB per launch = {p['hbm_bytes_per_launch'] / 1e6:.1f} MB over {p['launches']} launches.")
+    return "\n".join(out) + "\n"
+
+
+def main():
+    tag = sys.argv[1]
+    readme = os.path.join(ROOT, "profiles", "README.md")
+    s = open(readme).read()
+    begin, end = f"<!-- {tag}:generated (scripts/profiles_readme.py {tag}) -->\n", f"<!-- {tag}:end -->\n"
+    new = begin + block(tag) + end
+    pat = re.compile(re.escape(begin) + ".*?" + re.escape(end), re.S)
+    if "--check" in sys.argv:
+        m = pat.search(s)
+        ok = m is not None and m.group(0) == new
+        print("profiles/README.md", tag, "block is", "up to date" if ok else "STALE")
+        sys.exit(0 if ok else 1)
+    s = pat.sub(lambda _: new, s) if pat.search(s) else s + "\n" + new
+    open(readme, "w").write(s)
+    print(new)
+
+
+if __name__ == "__main__":
+    main()

@@ -389,3 +389,18 @@ def test_world_size_2_gloo_bf16_wire_gradient_exchange():
     assert res[0][2] == res[1][2]                                                          # bit-identical on both ranks
     assert torch.equal(torch.tensor(res[0][2]), want)
     assert bool(((want - (g0 + g1) / 2).abs() <= 2.0 ** -7 * (g0.abs() + g1.abs()) / 2 + 1e-30).all())   # bf16-close to the fp32 average
+
+
+def test_profiles_readme_numbers_are_generated_from_the_artefacts():
+    """profiles/README.md quotes each round's numbers between generated markers; the block must equal what scripts/profiles_readme.py
+    derives from the committed artefacts of that round (bench JSON lines, rocprofv3 kernel_stats.csv, pmc_traffic.json), so prose and
+    artefacts cannot drift apart (the r02 prose quoted 80.3 ms where the committed CSV summed to 85.05)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    readme = open(os.path.join(root, "profiles", "README.md")).read()
+    tags = sorted(set(m for m in __import__("re").findall(r"<!-- (r\d\d):generated", readme)))
+    assert tags, "no generated block in profiles/README.md"
+    for tag in tags:
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "profiles_readme.py"), tag, "--check"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr

@@ -346,6 +346,30 @@ int dfh_gemm_out2(const dfh_gemm_desc* d, void* out2, int ld_out2, int n_split, 
   return dfh::gemm_launch(g, (hipStream_t)stream, 0, 0, d->force_order);
 }
 
+// nearest-2x upsample + 3x3 conv as four phase planes over the source image (gemm.h GemmArgs::phase2x)
+int dfh_ups_phase_fold(const void* W, int ldw, void* WP, int N, int C, void* stream) {
+  return dfh::ups_phase_fold_launch((const bf16_t*)W, ldw, (bf16_t*)WP, N, C, (hipStream_t)stream);
+}
+int dfh_conv_up2x(const void* src, int batch, int H, int W, int C, const void* WP, int N, const float* bias, void* out,
+                  const void* zero_page, void* stream) {
+  DFH_REQUIRE(src && WP && out && zero_page, "null argument");
+  DFH_REQUIRE(batch > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && N > 0 && N % 8 == 0, "bad shape (C and N multiples of 8)");
+  GemmArgs g; std::memset(&g, 0, sizeof(g));
+  g.M = batch * H * W; g.N = N; g.rows_per_b = H * W; g.out_mode = OUT_BF16; g.ld_out = N;
+  g.conv_src = (const bf16_t*)src; g.conv_c = C; g.ntaps = 4; g.phase2x = 1; g.nbatch = 4; g.w_bs = (long)N * 4 * C;
+  g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.stride = 1;
+  g.W = (const bf16_t*)WP; g.ldw = 4 * C; g.bias = bias; g.out = out; g.zero = (const bf16_t*)zero_page;
+  return dfh::gemm_launch(g, (hipStream_t)stream, 0, 0, -1);
+}
+// dfh_gemm over nbatch independent planes in one launch: plane z reads a0 + z * a_bs, W + z * w_bs and writes out + z * o_bs (elements)
+int dfh_gemm_batched(const dfh_gemm_desc* d, int nbatch, long a_bs, long w_bs, long o_bs, void* stream) {
+  GemmArgs g;
+  if (int rc = fill_gemm(d, &g)) return rc;
+  DFH_REQUIRE(nbatch >= 1, "nbatch must be positive");
+  g.nbatch = nbatch; g.a_bs = a_bs; g.w_bs = w_bs; g.o_bs = o_bs;
+  return dfh::gemm_launch(g, (hipStream_t)stream, d->force_tile, 0, d->force_order);
+}
+
 int dfh_gemm_fp8(const void* A, const float* sA, const void* W, const float* sW, int M, int N, int K, const float* bias,
                  const void* resid, int ld_res, int act, void* out, int ld_out, int out_mode, int rows_per_b, const void* zero_page,
                  void* stream) {

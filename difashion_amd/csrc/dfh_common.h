@@ -62,7 +62,24 @@ DFH_DEVICE float erf_as_f(float x) {
   const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
   return copysignf(1.0f - p * t * e, x);
 }
-DFH_DEVICE float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f)); }
+// GELU (erf form) as used by every GEGLU epilogue: 84 M gate elements per ff.net.0 launch, all on the VALU while the MFMA pipe
+// idles, so the op count is launch time.  erfc(|x|/sqrt2) = 2^P(|x|) with P a degree-6 polynomial (minimax fit of log2 erfc on
+// [0, 4 sqrt2], the 1/sqrt2 folded into the coefficients; beyond the clamp erfc < 1.6e-8): one v_exp and six FMAs, no
+// reciprocal, and gelu(x) = max(x, 0) - |x/2 * 2^P| covers both signs without a select.  |error| <= 5.5e-7 absolute over all x
+// (the same as the Abramowitz-Stegun form above at |x| ~ 4, three orders below the bf16 rounding of the product) at ~10 VALU
+// slots against ~19.
+DFH_DEVICE float gelu_erf_f(float x) {
+  const float ax = fminf(fabsf(x), 5.65685424949f);
+  float p = 1.917432119e-05f;
+  p = fmaf(p, ax, -6.586021110e-04f);
+  p = fmaf(p, ax, 7.754402186e-03f);
+  p = fmaf(p, ax, -5.296538429e-02f);
+  p = fmaf(p, ax, -4.590602584e-01f);
+  p = fmaf(p, ax, -1.151122051e+00f);
+  p = fmaf(p, ax, 3.063254510e-07f);
+  const float h = 0.5f * x * __builtin_amdgcn_exp2f(p);
+  return fmaxf(x, 0.0f) - fabsf(h);
+}
 
 // Value of lane (l ^ 16) / (l ^ 32): gfx950's v_permlane{16,32}_swap exchange 16- / 32-lane rows between two registers in
 // the VALU (a few cycles); __shfl_xor goes through ds_bpermute_b32, an LDS round trip of ~100+ cycles on the critical path

@@ -42,6 +42,17 @@ struct GemmArgs {
   // rows_per_b rows) while columns [0, n_split) follow out / out_mode -- attention's q | k and V^T from ONE launch over the shared
   // LayerNorm-ed (or folded-LayerNorm) rows.  n_split must be a multiple of the column tile; single-pass gemm_bf16_kernel launches only.
   void* out2; int ld_out2; int n_split;
+  // BATCHED launch (grid.y): batch z reads plain segment 0 at p_src[0] + z * a_bs, the weights at W + z * w_bs and writes out + z * o_bs
+  // (elements).  The sixteen transform-domain GEMMs of a Winograd F(2x2, 3x3) convolution (winograd.hip) in ONE launch: 16 x the tiles of
+  // one, so the deep levels fill the chip without split-K.  Single plain segment, bf16 row-major output, gemm_bf16_kernel tiles only.
+  int nbatch; long a_bs, w_bs, o_bs;
+  // PHASE-DECOMPOSED nearest-2x upsample + 3x3 conv (the up-block upsamplers): output pixel (2y + py, 2x + px) sees only a 2 x 2
+  // neighbourhood of the SOURCE image -- rows {y - 1 + py, y + py}, columns likewise -- each with the SUM of the 3x3 taps that land on
+  // it, so the conv is four independent 2x2 convs (4/9 of the multiply-adds of the conv over the upsampled image).  phase2x = 1:
+  // nbatch = 4 planes (grid.y = py * 2 + px), ntaps = 4 (tap s = (s >> 1, s & 1) reads the 3x3-tap position (s >> 1) + py,
+  // (s & 1) + px of the source), W plane z = the summed weights [N][4 * conv_c] (lnfold.hip ups_phase_fold), Hin = Win = Hout = Wout =
+  // source size, M = rows of ONE phase; row m = (b, y, x) is stored at output pixel (b, 2y + py, 2x + px) of the 2H x 2W image.
+  int phase2x;
   float* partial;  // [ksplit][M][N] fp32 when ksplit > 1
   // --- optional GroupNorm statistics of the OUTPUT, written by the 256-row epilogue (gemm_wide_epilogue.h) when the launcher finds
   //     the launch eligible: per (image, group, row tile) the sum and the sum of squares of the bf16-rounded outputs, in the layout
@@ -106,6 +117,8 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile = 0, int force_sp
 // lnfold.hip: W' = bf16(W * gamma) [N][K], s[n] = sum_k W'[n][k], b[n] = bias[n] (or 0) + sum_k W[n][k] * beta[k]
 int ln_fold_launch(const bf16_t* W, int ldw, const float* gamma, const float* beta, const float* bias, bf16_t* WF, float* s, float* b,
                    int N, int K, hipStream_t stream);
+// summed phase weights [4][N][4 * C] of a nearest-2x upsample + 3x3 conv from its packed [N][9 * C] matrix (GemmArgs::phase2x)
+int ups_phase_fold_launch(const bf16_t* W, int ldw, bf16_t* WP, int N, int C, hipStream_t stream);
 int matvec_bias_launch(const bf16_t* W, int ldw, const float* v, const float* b_add, float* b_out, int N, int K, hipStream_t stream);
 // can a launch carry GemmArgs::out2 (its heuristic tile divides n_split, no split-K)?
 bool gemm_out2_ok(GemmArgs a);

@@ -122,7 +122,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
   const unsigned cc = (unsigned)a.conv_c;
   // Lean tap staging (stride-1 3x3 convs over whole 64-channel slices), see gemm_wide.hip: centre-pixel offset + 9-bit
   // tap-validity mask per staging piece, fixed for the kernel
-  const bool leanc = a.ntaps == 9 && a.stride == 1 && a.ups == 0 && !a.pad0 && (a.conv_c % BK) == 0;
+  const bool leanc = (a.ntaps == 9 || a.phase2x) && a.stride == 1 && a.ups == 0 && !a.pad0 && (a.conv_c % BK) == 0;
+  // phase-decomposed upsample conv (GemmArgs::phase2x): segment s of this plane is 3x3-tap position ((s >> 1) + py, (s & 1) + px)
+  const int ppy = a.phase2x ? (int)(blockIdx.y >> 1) : 0, ppx = a.phase2x ? (int)(blockIdx.y & 1) : 0;
+  auto tap_of = [&](int seg) { return a.phase2x ? ((seg >> 1) + ppy) * 3 + (seg & 1) + ppx : seg; };
   unsigned c_pre[IA], c_mask[IA];
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
@@ -138,9 +141,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
   }
   // Plain-segment pointers pinned in SGPRs: left to itself hipcc re-loads them from the kernel-argument segment with an
   // s_load + s_waitcnt lgkmcnt(0) in EVERY k-step of a linear layer (it selects the argument offset, not the value).
-  const bf16_t* psrc0 = a.p_src[0];
+  // batched launch (GemmArgs::nbatch): grid.y selects the operand / output planes
+  const long bz = (long)blockIdx.y;
+  const bf16_t* psrc0 = a.p_src[0] + bz * a.a_bs;
   const bf16_t* psrc1 = a.p_src[1];
-  asm volatile("" : "+s"(psrc0), "+s"(psrc1));
+  const bf16_t* Wb = a.W + bz * a.w_bs;
+  bf16_t* const outb = (bf16_t*)a.out + bz * a.o_bs;
+  asm volatile("" : "+s"(psrc0), "+s"(psrc1), "+s"(Wb));
   auto glds = [&](const bf16_t* src, unsigned char* dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -153,14 +160,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
     const int ch = it.c0 + sslot * 8;                 // channel of this lane's 16-byte chunk
     const bool kin = ch < it.seglen;
     if (it.seg < a.ntaps && leanc) {
-      const int ky = it.seg / 3, kx = it.seg - ky * 3;
+      const int tp = tap_of(it.seg);
+      const int ky = tp / 3, kx = tp - ky * 3;
       const unsigned delta = (unsigned)(((ky - 1) * a.Win + (kx - 1)) * (int)cc + it.c0);     // wave-uniform
-      const unsigned bit = 1u << it.seg;
+      const unsigned bit = 1u << tp;
 #pragma unroll
       for (int i = 0; i < IA; ++i)
         glds((c_mask[i] & bit) ? a.conv_src + (c_pre[i] + delta) : a.zero, As + i * NWV * 1024);
     } else if (it.seg < a.ntaps) {
-      const int ky = it.seg / 3, kx = it.seg - ky * 3;
+      const int tp = tap_of(it.seg);
+      const int ky = tp / 3, kx = tp - ky * 3;
 #pragma unroll
       for (int i = 0; i < IA; ++i) {
         const int yy = a_y[i] + ky, xx = a_x[i] + kx;
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
     for (int i = 0; i < IB; ++i) {
       if (i * NWV + wave >= PB) continue;             // wave-uniform
       const bool ok = kin & (w_row[i] >= 0);
-      glds(ok ? a.W + ((unsigned)w_row[i] + wc) : a.zero, Bs + i * NWV * 1024);
+      glds(ok ? Wb + ((unsigned)w_row[i] + wc) : a.zero, Bs + i * NWV * 1024);
     }
   };
 
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
       const bool ok = w_row[i] >= 0;
-      lp_w[i] = ok ? a.W + ((size_t)(unsigned)w_row[i] + k0) : a.zero;
+      lp_w[i] = ok ? Wb + ((size_t)(unsigned)w_row[i] + k0) : a.zero;
       ls_w[i] = ok ? BK : 0;
     }
   }
@@ -509,8 +518,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
     for (int c = tid; c < BM * CPR; c += NWV * 64) {
       const int row = c / CPR, cc = c - row * CPR;
       const int m = m0 + row, n = n0 + cc * 8;
+      long orow = m;
+      if (a.phase2x) {                               // source pixel (b, y, x) -> pixel (2y + py, 2x + px) of the 2H x 2W output
+        const int b = m / HWo, rem = m - b * HWo;
+        const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+        orow = (long)b * 4 * HWo + (long)(2 * oy + ppy) * (2 * a.Wout) + 2 * ox + ppx;
+      }
       if (m < a.M && n < a.N)
-        *(uint4*)((bf16_t*)a.out + (long)m * a.ld_out + n) = *(const uint4*)(smem + row * RS + cc * 16);
+        *(uint4*)(outb + orow * a.ld_out + n) = *(const uint4*)(smem + row * RS + cc * 16);
     }
     if (a.rowstat) {
       // Row statistics of this tile's bf16-rounded outputs for a LayerNorm folded into the consumer (gemm.h): TPR adjacent lanes share a
@@ -727,7 +742,7 @@ int launch_tile(const GemmArgs& a, hipStream_t stream) {
     attr_set = true;
   }
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-  dim3 grid(ntm * ntn, 1, a.ksplit);
+  dim3 grid(ntm * ntn, a.nbatch > 1 ? a.nbatch : 1, a.ksplit);
   hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, LEAN, WEPI>), grid, dim3(WM * WN * 64), lds, stream, a);
   return dfh::check_launch("gemm_bf16_kernel");
 }
@@ -818,6 +833,7 @@ int gemm_pick_split(const GemmArgs& a, int* tile_out) {
 }
 
 size_t gemm_partial_floats(const GemmArgs& a) {
+  if (a.nbatch > 1) return 0;     // batched launches never split K
   int tile;
   const int s = gemm_pick_split(a, &tile);
   return s > 1 ? (size_t)s * a.M * a.N : 0;
@@ -907,7 +923,7 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
   if (rowstat_bn) *rowstat_bn = 0;
   DFH_REQUIRE(a.M > 0 && a.N > 0, "empty GEMM");
   DFH_REQUIRE(a.N % 4 == 0, "N must be a multiple of 4");
-  DFH_REQUIRE(a.ntaps == 0 || a.ntaps == 9, "ntaps must be 0 or 9");
+  DFH_REQUIRE(a.ntaps == 0 || a.ntaps == 9 || (a.ntaps == 4 && a.phase2x), "ntaps must be 0 or 9 (4 for the phase planes of an upsample conv)");
   DFH_REQUIRE(a.ntaps + a.nplain >= 1, "no K segment");
   DFH_REQUIRE(a.ntaps == 0 || a.conv_c % 8 == 0, "conv channels must be a multiple of 8");
   for (int i = 0; i < a.nplain; ++i) DFH_REQUIRE(a.p_c[i] % 8 == 0, "segment length must be a multiple of 8");
@@ -938,6 +954,18 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     a.n_major = (force_order == 2 || (force_order < 0 && a.ntaps && w_bytes > a_bytes && a.N > 160)) ? 1 : 0;   // force_order 2 / 3 pin it (probe)
     if (force_order == 3) a.n_major = 0;
   }
+  if (a.nbatch > 1) {
+    // the split heuristic sees one plane's tiles: a batched launch has nbatch times as many, and its planes are independent problems
+    split = 1;
+    DFH_REQUIRE(((a.ntaps == 0 && a.nplain == 1) || (a.phase2x && a.nplain == 0)) && a.out_mode == OUT_BF16 && a.act != ACT_GEGLU &&
+                !a.resid && !a.rowvec && !a.out2 && !a.rowstat && !a.ln_stat && (a.N & 7) == 0 && (a.ld_out & 7) == 0 && force_split <= 1,
+                "batched launch: one plain segment (or the four phase planes of an upsample conv), plain bf16 row-major output, no split-K");
+    a.gstat = nullptr; a.ksplit = 1;
+    // one plane alone would pick the 256-row tile at the 8x8 level (M <= 1024): the planes together fill the chip with the 128-row tiles
+    if (force_tile == 0 && !force_deep) tile = (a.N % 160 == 0) ? kEightWave : 4;
+  }
+  DFH_REQUIRE(!a.phase2x || (a.nbatch == 4 && a.ntaps == 4 && a.stride == 1 && a.ups == 0 && !a.pad0 && a.Hin == a.Hout && a.Win == a.Wout &&
+                             a.M % (a.Hout * a.Wout) == 0), "phase planes of an upsample conv: four planes over the source image");
   if (split > 1) DFH_REQUIRE(a.partial != nullptr, "split-K needs a partial buffer");
   if (a.ln_stat) {
     DFH_REQUIRE(split == 1 && a.ln_parts > 0 && a.ln_cnt > 0 && a.ln_s != nullptr && !a.rowvec && !a.resid,
@@ -955,8 +983,10 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     for (int i = 0; i < a.nplain; ++i) { kreal += a.p_c[i]; abytes += (double)a.M * a.p_c[i] * 2.0; }
     const double obytes = (double)a.M * (a.act == ACT_GEGLU ? a.N / 2 : a.N) * ((a.out_mode == OUT_F32 || a.out_mode == OUT_F32_T) ? 4.0 : 2.0) +
                           (a.resid ? (double)a.M * a.N * 2.0 : 0.0);      // the residual is an operand too: read once
-    ProfScope ps(a.ntaps ? PC_CONV3 : PC_LINEAR, 2.0 * a.M * a.N * kreal, abytes + (double)a.N * kreal * 2.0 + obytes, stream);
-    const bool wide_ok = split == 1 && a.out2 == nullptr && a.out_mode == OUT_BF16 && (a.act != ACT_GEGLU || a.N % 160 == 0 || a.N % 128 == 0) && (a.N & 7) == 0 &&
+    const double planes = a.nbatch > 1 ? (double)a.nbatch : 1.0;       // a phase launch reads its source image once for all four planes
+    ProfScope ps(a.ntaps ? PC_CONV3 : PC_LINEAR, planes * 2.0 * a.M * a.N * kreal,
+                 (a.phase2x ? abytes : planes * abytes) + planes * ((double)a.N * kreal * 2.0 + obytes), stream);
+    const bool wide_ok = split == 1 && a.out2 == nullptr && a.nbatch <= 1 && a.out_mode == OUT_BF16 && (a.act != ACT_GEGLU || a.N % 160 == 0 || a.N % 128 == 0) && (a.N & 7) == 0 &&
                          (a.ld_out & 7) == 0 && (!a.resid || (a.ld_res & 7) == 0);
     // tile id 21 pins the 256 x 320 tile (launches it cannot take -- fp32 / transposed outputs, GEGLU, N % 8 -- fall back to the
     // heuristic tile, like the forced wide ids); otherwise gemm_big_pick decides

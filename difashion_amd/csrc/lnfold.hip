@@ -59,9 +59,34 @@ __global__ __launch_bounds__(256) void matvec_bias_kernel(const bf16_t* __restri
   if (threadIdx.x == 0) b_out[n] = (b_add ? b_add[n] : 0.f) + ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// Summed weights of the four phase planes of a nearest-2x upsample + 3x3 conv (gemm.h GemmArgs::phase2x):
+//   WP[py * 2 + px][n][(a * 2 + b) * C + c] = sum over the 3x3 taps (ky, kx) that land on source offset (a, b) for phase (py, px) of
+//   W[n][(ky * 3 + kx) * C + c],     rows: py = 0 -> a = 0: {ky = 0}, a = 1: {1, 2};  py = 1 -> a = 0: {0, 1}, a = 1: {2};  columns alike.
+// Sums in fp32 of the packed bf16 taps, rounded once.  One block per output channel.
+__global__ __launch_bounds__(256) void ups_phase_fold_kernel(const bf16_t* __restrict__ W, int ldw, bf16_t* __restrict__ WP, int N, int C) {
+  const int n = blockIdx.x;
+  const bf16_t* w = W + (long)n * ldw;
+  for (int i = threadIdx.x; i < 16 * C; i += 256) {
+    const int c = i % C, sab = (i / C) & 3, ph = i / (4 * C);
+    const int py = ph >> 1, px = ph & 1, a = sab >> 1, b = sab & 1;
+    const int ky0 = a == 0 ? 0 : (py == 0 ? 1 : 2), ky1 = a == 0 ? (py == 0 ? 0 : 1) : 2;
+    const int kx0 = b == 0 ? 0 : (px == 0 ? 1 : 2), kx1 = b == 0 ? (px == 0 ? 0 : 1) : 2;
+    float acc = 0.f;
+    for (int ky = ky0; ky <= ky1; ++ky)
+      for (int kx = kx0; kx <= kx1; ++kx) acc += bf2f(w[(ky * 3 + kx) * C + c]);
+    WP[((long)ph * N + n) * (4 * C) + sab * C + c] = f2bf(acc);
+  }
+}
+
 }  // namespace
 
 namespace dfh {
+
+int ups_phase_fold_launch(const bf16_t* W, int ldw, bf16_t* WP, int N, int C, hipStream_t stream) {
+  DFH_REQUIRE(W && WP && N > 0 && C > 0 && ldw >= 9 * C, "bad argument");
+  hipLaunchKernelGGL(ups_phase_fold_kernel, dim3(N), dim3(256), 0, stream, W, ldw, WP, N, C);
+  return check_launch("ups_phase_fold_kernel");
+}
 
 int matvec_bias_launch(const bf16_t* W, int ldw, const float* v, const float* b_add, float* b_out, int N, int K, hipStream_t stream) {
   DFH_REQUIRE(W && v && b_out && N > 0 && K > 0, "bad argument");

@@ -58,7 +58,11 @@ struct AttL {
   std::string pre; Mat pint, qkvt, o1t, q2t, o2t, ff1t, ff2t, poutt;
   Mat8 qk8, v8, q28, ff18;           // fp8 copies of the LayerNorm-fed projections (gemm_fp8.hip), when enabled
 };
-struct ConvL { Mat w; Vec b; int cin = 0, cout = 0; std::string pre; Mat wt; };
+struct ConvL {
+  Mat w; Vec b; int cin = 0, cout = 0; std::string pre; Mat wt;
+  // upsamplers: summed phase weights [4][cout][4 * cin] in the fold region (gemm.h GemmArgs::phase2x), has_ph when allocated
+  size_t ph = 0; bool has_ph = false;
+};
 
 struct Tensor {
   bf16_t* p = nullptr; int H = 0, W = 0, C = 0;
@@ -324,7 +328,13 @@ struct dfh_unet {
       }
       for (int j = 0; j < L && att; ++j)
         build_attn(b + ".attentions." + std::to_string(j), out_ch, cfg.num_heads[nb - 1 - i], up_att[i][j]);
-      if (i != nb - 1) build_conv(b + ".upsamplers.0.conv", out_ch, out_ch, up_samp[i]);
+      if (i != nb - 1) {
+        build_conv(b + ".upsamplers.0.conv", out_ch, out_ch, up_samp[i]);
+        if (out_ch % 8 == 0) {
+          up_samp[i].ph = fold16; up_samp[i].has_ph = true;
+          fold16 += ((size_t)16 * out_ch * out_ch + 127) & ~(size_t)127;
+        }
+      }
     }
     cnw = vec("conv_norm_out.weight", boc[0]);
     cnb = vec("conv_norm_out.bias", boc[0]);
@@ -424,6 +434,9 @@ struct dfh_unet {
                                          fold_w() + dst[i]->w, fold_v() + dst[i]->s, fold_v() + dst[i]->b, src[i]->N, src[i]->K, s)) return rc;
       }
     }
+    for (ConvL& c : up_samp)
+      if (c.has_ph)
+        if (int rc = dfh::ups_phase_fold_launch(arena16 + c.w.off, c.w.K, fold_w() + c.ph, c.cout, c.cin, s)) return rc;
     // ff.net.2 . proj_out: [pout . ff2 | pout] and its bias.  The product runs on the GEMM kernel itself (A = pout [C][C], the W operand
     // = ff2^T [4C][C], transposed into the activation workspace, which no walk is using while the weights are being derived)
     bf16_t* scratch = (bf16_t*)(ws + fold_bytes());
@@ -561,6 +574,18 @@ struct dfh_unet {
       const int Ho = ups ? x.H * 2 : (stride == 2 ? x.H / 2 : x.H);
       const int Wo = ups ? x.W * 2 : (stride == 2 ? x.W / 2 : x.W);
       Tensor o = to_persist ? palloc(Ho, Wo, c.cout) : talloc(Ho, Wo, c.cout);
+      // nearest-2x upsample + conv: four 2x2 convs over the source image with the summed taps (4/9 of the multiply-adds), one launch
+      // over the four phase planes.  DFH_UPS_PHASE=0 keeps the 3x3 conv over the virtual upsampled image (A/B).
+      static const bool phase_off = [] { const char* e = getenv("DFH_UPS_PHASE"); return e && e[0] == '0'; }();
+      if (ups == 1 && c.has_ph && u->fold_valid && !phase_off && !dry && x.C == c.cin) {
+        GemmArgs g = base(B * x.H * x.W, c.cout);
+        g.conv_src = x.p; g.conv_c = x.C; g.ntaps = 4; g.phase2x = 1; g.nbatch = 4; g.w_bs = (long)c.cout * 4 * x.C;
+        g.Hin = x.H; g.Win = x.W; g.Hout = x.H; g.Wout = x.W; g.stride = 1; g.rows_per_b = x.H * x.W;
+        g.W = u->fold_w() + c.ph; g.ldw = 4 * x.C; g.bias = v32(c.b);
+        g.out = o.p;
+        gemm(g);
+        return o;
+      }
       GemmArgs g = base(B * Ho * Wo, c.cout);
       g.conv_src = x.p; g.conv_c = x.C; g.ntaps = 9;
       g.Hin = x.H; g.Win = x.W; g.Hout = Ho; g.Wout = Wo; g.stride = stride; g.ups = ups;

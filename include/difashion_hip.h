@@ -260,6 +260,17 @@ int dfh_ln_fold(const void* W, int ldw, const float* gamma, const float* beta, c
                 void* stream);
 int dfh_gemm_ln(const dfh_gemm_desc* d, float* rowstat, int* rowstat_bn, const float* ln_stat, int ln_parts, int ln_cnt, float ln_eps,
                 const float* ln_s, void* stream);
+/* ---- nearest-2x upsample + 3x3 conv (diffusers Upsample2D: F.interpolate(scale_factor=2, mode="nearest") then conv, the up-block
+ * upsamplers reached from df.py:518-523) as FOUR 2x2 convs over the source image: output pixel (2y + py, 2x + px) sees source rows
+ * {y - 1 + py, y + py} and columns alike, each with the sum of the 3x3 taps that land on it -- 4/9 of the multiply-adds.
+ *   dfh_ups_phase_fold : packed bf16 W [N][ldw >= 9 C] (tap-major columns) -> WP [4][N][4 C] bf16, the summed taps per phase py * 2 + px
+ *   dfh_conv_up2x      : src [batch][H][W][C] bf16 -> out [batch][2H][2W][N] bf16 = conv3x3(upsample2x(src)) + bias, one launch */
+int dfh_ups_phase_fold(const void* W, int ldw, void* WP, int N, int C, void* stream);
+int dfh_conv_up2x(const void* src, int batch, int H, int W, int C, const void* WP, int N, const float* bias, void* out,
+                  const void* zero_page, void* stream);
+/* dfh_gemm over nbatch independent planes in ONE launch (grid.y): plane z reads d->a0 + z * a_bs, d->W + z * w_bs and writes
+ * d->out + z * o_bs (strides in bf16 elements).  One plain K segment, bias-only epilogue, bf16 row-major output, no split-K. */
+int dfh_gemm_batched(const dfh_gemm_desc* d, int nbatch, long a_bs, long w_bs, long o_bs, void* stream);
 /* ---- fp8 (OCP e4m3fn) linears: BASELINE configs[4].  The reference has no fp8 path (fp16 autocast, run_inf4eval.sh:1); these
  * replace the same diffusers linears as dfh_gemm (BasicTransformerBlock attn1.to_q/k/v, attn2.to_q, ff.net.0.proj reached from
  * df.py:249-253,518-523) when the caller opts in.

@@ -245,6 +245,64 @@ def test_conv3x3(cin, cout, H, stride, ups, glds):
     gu.assert_close_bf16(gu.nchw(out.view(B, Ho, Ho, cout)), ref, f"conv {cin}->{cout}@{H} s{stride} u{ups}")
 
 
+def _phase_weights_ref(wb):
+    """Summed taps per output phase of conv3x3(upsample2x(x)): [4][O][4 * I] from the bf16-rounded OIHW weights, fp32 sums."""
+    O, I = wb.shape[:2]
+    grp = {0: ([0], [1, 2]), 1: ([0, 1], [2])}          # phase -> (taps on source offset 0, taps on source offset 1)
+    out = torch.zeros(4, O, 4, I, device=wb.device)
+    for py in (0, 1):
+        for px in (0, 1):
+            for a in (0, 1):
+                for b in (0, 1):
+                    for ky in grp[py][a]:
+                        for kx in grp[px][b]:
+                            out[py * 2 + px, :, a * 2 + b] += wb[:, :, ky, kx]
+    return out.reshape(4, O, 4 * I)
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 128, 8, 8), (3, 128, 160, 5, 7), (2, 320, 320, 16, 16), (16, 64, 64, 8, 8),
+                                            (1, 72, 40, 4, 4), (2, 64, 96, 1, 1)])
+def test_upsample_conv_as_four_phase_planes(B, cin, cout, H, W):
+    """Upsample2D (nearest 2x, then conv3x3; diffusers, the up-block upsamplers) as four 2x2 convs over the source image with summed taps:
+    the summed weights are the exact fp32 tap sums rounded once, and the launch equals the conv over the upsampled image computed with
+    those same weights (exact up to accumulation order) -- and the reference conv with the original weights to bf16 weight rounding."""
+    x = bf(rnd(B, cin, H, W, seed=26))
+    w = rnd(cout, cin, 3, 3, seed=27, scale=0.05)
+    bias = rnd(cout, seed=28)
+    packed = gu.pack_conv(w)
+    wp = torch.empty(4, cout, 4 * cin, dtype=torch.bfloat16, device=gu.DEV)
+    _lib.call("dfh_ups_phase_fold", _lib.ptr(packed), 9 * cin, _lib.ptr(wp), cout, cin, gu.stream())
+    ref_w = _phase_weights_ref(bf(w).float())
+    assert torch.equal(wp, bf(ref_w)), "phase weights are the fp32 tap sums, rounded once"
+    out = torch.empty(B, 2 * H, 2 * W, cout, dtype=torch.bfloat16, device=gu.DEV)
+    z = gu.zero_page()
+    _lib.call("dfh_conv_up2x", _lib.ptr(gu.nhwc(x)), B, H, W, cin, _lib.ptr(wp), cout, _lib.ptr(bias), _lib.ptr(out), _lib.ptr(z), gu.stream())
+    # the same arithmetic in torch: each phase is a 2x2 conv of the (zero-padded) source with the rounded summed weights
+    xp = F.pad(x.float(), (1, 1, 1, 1))
+    ref = torch.empty(B, cout, 2 * H, 2 * W, device=gu.DEV)
+    for py in (0, 1):
+        for px in (0, 1):
+            k = wp[py * 2 + px].float().view(cout, 2, 2, cin).permute(0, 3, 1, 2).contiguous()
+            ref[:, :, py::2, px::2] = F.conv2d(xp[:, :, py:py + H + 1, px:px + W + 1], k, bias)
+    gu.assert_close_bf16(gu.nchw(out), ref, f"phase conv {cin}->{cout}@{H}x{W}")
+    full = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), bf(w).float(), bias, padding=1)
+    assert gu.rel_err(gu.nchw(out).float(), full) < 6e-3, "against the 3x3 conv over the upsampled image (summed weights rounded once more)"
+
+
+@pytest.mark.parametrize("nb,M,N,K,tile", [(16, 1024, 1280, 1280, 0), (4, 300, 160, 64, 0), (3, 128, 128, 192, 5), (16, 256, 320, 320, 10)])
+def test_gemm_batched_planes_in_one_launch(nb, M, N, K, tile):
+    """grid.y planes of independent GEMMs (dfh_gemm_batched) equal nb separate launches bit for bit."""
+    a = bf(rnd(nb, M, K, seed=29)); w = bf(rnd(nb, N, K, seed=30, scale=0.05)); bias = rnd(N, seed=31)
+    out = torch.empty(nb, M, N, dtype=torch.bfloat16, device=gu.DEV)
+    d = gu.gemm_desc(M=M, N=N, W=w, ldw=K, a0=a, a0_c=K, bias=bias, out=out, ld_out=N, force_tile=tile)
+    _lib.call("dfh_gemm_batched", C.byref(d), nb, M * K, N * K, M * N, gu.stream())
+    for z in range(nb):
+        one = gu.gemm(M=M, N=N, W=w[z], ldw=K, a0=a[z], a0_c=K, bias=bias, force_tile=tile if tile else 10 if N % 160 == 0 else 5, force_split=1)
+        ref = a[z].float() @ w[z].float().t() + bias
+        gu.assert_close_bf16(out[z], ref, f"batched plane {z}")
+        assert torch.equal(out[z], one.view(M, N)), f"plane {z} differs from its own launch"
+
+
 @pytest.mark.parametrize("tile", [0, 1, 6, 10, 21])
 @pytest.mark.parametrize("cin,H,W", [(64, 12, 20), (128, 5, 3), (192, 16, 1)])
 def test_conv3x3_lean_tap_staging_on_non_square_inputs(cin, H, W, tile):

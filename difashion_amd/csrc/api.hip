@@ -31,7 +31,7 @@ static long g_census[CK_COUNT] = {0};
 void census(int id) { if (id >= 0 && id < CK_COUNT) ++g_census[id]; }
 static const char* const kCensusNames[CK_COUNT] = {"gemm_wide", "gemm_8wave", "gemm_lean", "gemm_other", "gemm_row", "splitk_reduce",
     "splitk_fused", "gstat_written", "gn_pre", "gn_stats", "gn_small", "gn_mid", "layernorm", "ln_folded", "attention_x32", "attention_16",
-    "gemm_fp8", "text_cached"};
+    "gemm_fp8", "text_cached", "conv_phase", "conv_wino"};
 
 struct ProfRec { hipEvent_t e0, e1; int cls; double flops, bytes; };
 static std::vector<ProfRec> g_recs;
@@ -360,6 +360,36 @@ int dfh_conv_up2x(const void* src, int batch, int H, int W, int C, const void* W
   g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.stride = 1;
   g.W = (const bf16_t*)WP; g.ldw = 4 * C; g.bias = bias; g.out = out; g.zero = (const bf16_t*)zero_page;
   return dfh::gemm_launch(g, (hipStream_t)stream, 0, 0, -1);
+}
+// Winograd F(2x2, 3x3) conv (winograd.hip): weight transform, and the three-launch conv over caller-provided scratch
+int dfh_wino_weights(const void* W, int ldw, void* U, int N, int C, void* stream) {
+  return dfh::wino_weight_launch((const bf16_t*)W, ldw, (bf16_t*)U, N, C, (hipStream_t)stream);
+}
+size_t dfh_conv3x3_wino_scratch_bytes(int batch, int H, int W, int C, int N) {
+  if (batch <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return 0;
+  const size_t mt = (size_t)batch * (H / 2) * (W / 2);
+  return ((16 * mt * C * 2 + 255) & ~(size_t)255) + ((16 * mt * N * 2 + 255) & ~(size_t)255);
+}
+int dfh_conv3x3_wino(const void* src, int batch, int H, int W, int C, const void* U, int N, const float* bias, const float* rowvec,
+                     int rv_ld, int rv_off, const void* resid, void* out, void* scratch, size_t scratch_bytes, const void* zero_page,
+                     void* stream) {
+  DFH_REQUIRE(src && U && bias && out && scratch && zero_page, "null argument");
+  DFH_REQUIRE(batch > 0 && H > 0 && W > 0 && (H & 1) == 0 && (W & 1) == 0 && C > 0 && C % 8 == 0 && N > 0 && N % 8 == 0,
+              "even image sides, channel counts multiples of 8");
+  DFH_REQUIRE(scratch_bytes >= dfh_conv3x3_wino_scratch_bytes(batch, H, W, C, N) && (uintptr_t)scratch % 256 == 0, "scratch too small or misaligned");
+  const long mt = (long)batch * (H / 2) * (W / 2);
+  bf16_t* V = (bf16_t*)scratch;
+  bf16_t* Mb = (bf16_t*)((char*)scratch + ((16 * (size_t)mt * C * 2 + 255) & ~(size_t)255));
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = dfh::wino_input_launch((const bf16_t*)src, V, batch, H, W, C, s)) return rc;
+  GemmArgs g; std::memset(&g, 0, sizeof(g));
+  g.M = (int)mt; g.N = N; g.rows_per_b = (int)mt; g.out_mode = OUT_BF16; g.ld_out = N;
+  g.p_src[0] = V; g.p_c[0] = C; g.nplain = 1; g.W = (const bf16_t*)U; g.ldw = C;
+  g.nbatch = 16; g.a_bs = mt * C; g.w_bs = (long)N * C; g.o_bs = mt * N;
+  g.out = Mb; g.zero = (const bf16_t*)zero_page;
+  g.prof_flops = 2.0 * batch * H * W * (double)N * 9.0 * C;
+  if (int rc = dfh::gemm_launch(g, s, dfh::wino_gemm_tile(g), 0, -1)) return rc;
+  return dfh::wino_output_launch(Mb, (bf16_t*)out, bias, rowvec, rv_ld, rv_off, (const bf16_t*)resid, batch, H, W, N, s);
 }
 // dfh_gemm over nbatch independent planes in one launch: plane z reads a0 + z * a_bs, W + z * w_bs and writes out + z * o_bs (elements)
 int dfh_gemm_batched(const dfh_gemm_desc* d, int nbatch, long a_bs, long w_bs, long o_bs, void* stream) {

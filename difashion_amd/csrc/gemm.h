@@ -53,6 +53,9 @@ struct GemmArgs {
   // (s & 1) + px of the source), W plane z = the summed weights [N][4 * conv_c] (lnfold.hip ups_phase_fold), Hin = Win = Hout = Wout =
   // source size, M = rows of ONE phase; row m = (b, y, x) is stored at output pixel (b, 2y + py, 2x + px) of the 2H x 2W image.
   int phase2x;
+  // profile accounting override (0 = derive from the shape): a launch that is one stage of a convolution (the batched transform-domain
+  // GEMM of winograd.hip) reports the REFERENCE algorithm's multiply-adds (the direct conv) under the conv3x3 class
+  double prof_flops;
   float* partial;  // [ksplit][M][N] fp32 when ksplit > 1
   // --- optional GroupNorm statistics of the OUTPUT, written by the 256-row epilogue (gemm_wide_epilogue.h) when the launcher finds
   //     the launch eligible: per (image, group, row tile) the sum and the sum of squares of the bf16-rounded outputs, in the layout
@@ -117,6 +120,14 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile = 0, int force_sp
 // lnfold.hip: W' = bf16(W * gamma) [N][K], s[n] = sum_k W'[n][k], b[n] = bias[n] (or 0) + sum_k W[n][k] * beta[k]
 int ln_fold_launch(const bf16_t* W, int ldw, const float* gamma, const float* beta, const float* bias, bf16_t* WF, float* s, float* b,
                    int N, int K, hipStream_t stream);
+// Winograd F(2x2, 3x3) transforms (winograd.hip): U = G g G^T per weight pack, V = B^T d B of the conv's input, out = A^T m A + epilogue
+int wino_weight_launch(const bf16_t* W, int ldw, bf16_t* U, int N, int C, hipStream_t stream);
+int wino_input_launch(const bf16_t* g, bf16_t* V, int B, int H, int W, int C, hipStream_t stream);
+int wino_output_launch(const bf16_t* Mb, bf16_t* out, const float* bias, const float* rowvec, int rv_ld, int rv_off, const bf16_t* resid,
+                       int B, int H, int W, int N, hipStream_t stream);
+// tile id (gemm_launch force_tile) for the batched transform-domain GEMM: the 256-row ring when a plane has at most 256 rows (its
+// weights are then read by ONE row tile), else 0 = the batched default (eight-wave 128 x 160)
+int wino_gemm_tile(const GemmArgs& a);
 // summed phase weights [4][N][4 * C] of a nearest-2x upsample + 3x3 conv from its packed [N][9 * C] matrix (GemmArgs::phase2x)
 int ups_phase_fold_launch(const bf16_t* W, int ldw, bf16_t* WP, int N, int C, hipStream_t stream);
 int matvec_bias_launch(const bf16_t* W, int ldw, const float* v, const float* b_add, float* b_out, int N, int K, hipStream_t stream);

@@ -900,6 +900,22 @@ int gemm_big_geglu_pick(const GemmArgs& a) {
   return (tiles >= 224 && (rem == 0 || rem >= 224 || tiles >= 512)) ? 1 : 0;
 }
 
+int wino_gemm_tile(const GemmArgs& a) {
+  static const int pin = [] { const char* e = getenv("DFH_WINO_TILE"); return e ? atoi(e) : -1; }();      // probe
+  if (pin >= 0) return pin;
+  return 0;
+}
+
+// Batched launches (Winograd planes, phase planes of an upsample conv) for the 256 x 320 eight-wave tile: planes of at least 512 rows whose
+// tiles together make whole rounds of the CUs (16x16 level Winograd: 16 x 16 = 256 tiles, 78.7 -> us with the 128 x 160 tile).
+// DFH_BATCH_BIG=0 turns it off (A/B).
+static bool batched_big_pick(const GemmArgs& a) {
+  static const bool off = [] { const char* e = getenv("DFH_BATCH_BIG"); return e && e[0] == '0'; }();
+  if (off || a.nbatch <= 1 || a.M < 512 || a.N % 320 != 0) return false;
+  const long tiles = (long)((a.M + 255) / 256) * (a.N / 320) * a.nbatch, rem = tiles % 256;
+  return tiles >= 224 && (rem == 0 || rem >= 224 || tiles >= 1024);
+}
+
 bool gemm_out2_ok(GemmArgs a) {
   if (a.rows_per_b <= 0) a.rows_per_b = a.M;
   a.ksteps = gemm_count_ksteps(a);
@@ -984,20 +1000,25 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     const double obytes = (double)a.M * (a.act == ACT_GEGLU ? a.N / 2 : a.N) * ((a.out_mode == OUT_F32 || a.out_mode == OUT_F32_T) ? 4.0 : 2.0) +
                           (a.resid ? (double)a.M * a.N * 2.0 : 0.0);      // the residual is an operand too: read once
     const double planes = a.nbatch > 1 ? (double)a.nbatch : 1.0;       // a phase launch reads its source image once for all four planes
-    ProfScope ps(a.ntaps ? PC_CONV3 : PC_LINEAR, planes * 2.0 * a.M * a.N * kreal,
+    // algorithmic multiply-adds = the reference algorithm's: the four phase planes of an upsample conv stand for the
+    // 3x3 conv over the upsampled image (9 taps per output pixel, of which the planes execute 4)
+    const double flops = a.prof_flops > 0.0 ? a.prof_flops : (a.phase2x ? 9.0 / 4.0 : 1.0) * planes * 2.0 * a.M * a.N * kreal;
+    ProfScope ps((a.ntaps || a.prof_flops > 0.0) ? PC_CONV3 : PC_LINEAR, flops,
                  (a.phase2x ? abytes : planes * abytes) + planes * ((double)a.N * kreal * 2.0 + obytes), stream);
-    const bool wide_ok = split == 1 && a.out2 == nullptr && a.nbatch <= 1 && a.out_mode == OUT_BF16 && (a.act != ACT_GEGLU || a.N % 160 == 0 || a.N % 128 == 0) && (a.N & 7) == 0 &&
+    const bool wide_ok0 = split == 1 && a.out2 == nullptr && a.out_mode == OUT_BF16 && (a.act != ACT_GEGLU || a.N % 160 == 0 || a.N % 128 == 0) && (a.N & 7) == 0 &&
                          (a.ld_out & 7) == 0 && (!a.resid || (a.ld_res & 7) == 0);
+    const bool wide_ok = wide_ok0 && a.nbatch <= 1;       // batched launches: gemm_bf16_kernel tiles only (the 256 x 320 one when pinned)
     // tile id 21 pins the 256 x 320 tile (launches it cannot take -- fp32 / transposed outputs, GEGLU, N % 8 -- fall back to the
     // heuristic tile, like the forced wide ids); otherwise gemm_big_pick decides
-    const bool force_big = force_wide == 16;     // id 21
+    const bool force_big = force_wide == 16 ||     // id 21
+                           (a.nbatch > 1 && force_tile == 0 && force_wide == 0 && !force_deep && batched_big_pick(a));
     if (force_big) force_wide = 0;
     // tile id 23: the 256 x 256 GEGLU tile
     const bool force_bigg = force_wide == 18;
     if (force_bigg) force_wide = 0;
     const bool bigg = wide_ok && !force_deep && a.act == ACT_GEGLU && a.N % 32 == 0 && !a.resid && !a.rowvec &&
                       (force_bigg || (!force_wide && force_tile == 0 && force_split == 0 && gemm_big_geglu_pick(a)));
-    const bool big_ok = wide_ok && !force_deep && a.act != ACT_GEGLU && !a.ln_stat;
+    const bool big_ok = wide_ok0 && !force_deep && a.act != ACT_GEGLU && !a.ln_stat && (a.nbatch <= 1 || force_big);
     const bool big = big_ok && (force_big || (!force_wide && force_tile == 0 && force_split == 0 && gemm_big_pick(a)));
     int wide = (!wide_ok || force_deep || big || force_big || bigg || force_bigg) ? 0 : (force_wide ? force_wide : ((force_tile == 0 && force_split == 0) ? gemm_wide_pick(a) : 0));
     int ws = 0; bool halo = false;
@@ -1048,6 +1069,7 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     else rc = launch_variant(tile, a, stream);
     census((big || bigg) ? CK_GEMM_ROW : wide ? CK_GEMM_WIDE : ((halo || ws) ? CK_GEMM_OTHER : (tile == kEightWave ? (lean_plain(a) ? CK_GEMM_LEAN : CK_GEMM_8WAVE) : CK_GEMM_OTHER)));
     if (a.gstat) census(CK_GSTAT_WRITTEN);
+    if (a.phase2x) census(CK_CONV_PHASE);
   }
   if (rc) return rc;
   if (split > 1) {

@@ -149,7 +149,14 @@ DFH_DEVICE void wide_epilogue(const GemmArgs& a, f32x4_t (&acc)[BM / 2 / 16][BN 
         for (int r = 0; r < 8; ++r) v[r] += f[r];
       }
       const uint4 packed = pack8(v);
-      *(uint4*)((bf16_t*)a.out + (long)m * a.ld_out + n) = packed;
+      long orow = m;
+      if (a.phase2x) {                                 // phase plane of an upsample conv (gemm.h): source pixel -> its pixel of the 2H x 2W image
+        const int hw = a.Hout * a.Wout, pb = m / hw, rem = m - pb * hw;
+        const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+        orow = (long)pb * 4 * hw + (long)(2 * oy + (int)(blockIdx.y >> 1)) * (2 * a.Wout) + 2 * ox + (int)(blockIdx.y & 1);
+      }
+      // batched launch (gemm.h GemmArgs::nbatch): plane blockIdx.y of the output (o_bs = 0 otherwise)
+      *(uint4*)((bf16_t*)a.out + (long)blockIdx.y * a.o_bs + orow * a.ld_out + n) = packed;
       if (gst || rst) {                                // this thread read the slot, nobody else touches it in this pass
         float f[8];
         unpack8(packed, f);

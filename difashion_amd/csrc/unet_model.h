@@ -41,6 +41,8 @@ struct ResL {
   int cin = 0, cout = 0, temb_off = 0; bool shortcut = false;
   Vec n1w, n1b, b1, n2w, n2b, b2; Mat w1, w2;
   std::string pre; Mat w1t, w2t, wst;   // training: transposed packs for the data-gradient GEMMs
+  // Winograd F(2x2, 3x3) weights U [16][cout][cin] of conv1 / conv2 in the fold region (winograd.hip), allocated for the deep levels
+  size_t u1 = 0, u2 = 0; bool has_u = false;
 };
 // A LayerNorm-fed projection with the LayerNorm folded in (lnfold.hip): W' (bf16 elements) / s / b' (floats) offsets inside the fold
 // region at the head of the workspace
@@ -207,8 +209,14 @@ struct dfh_unet {
     packs.push_back(op);
   }
 
-  void build_resnet(const std::string& pre, int cin, int cout, ResL& r) {
+  // res: side of the (square) image this resnet runs on
+  void build_resnet(const std::string& pre, int cin, int cout, ResL& r, int res) {
     const int temb = cfg.block_out_channels[0] * 4;
+    if (res % 2 == 0 && res * res <= 256 && cin % 8 == 0 && cout % 8 == 0) {
+      r.has_u = true;
+      r.u1 = fold16; fold16 += ((size_t)16 * cout * cin + 127) & ~(size_t)127;
+      r.u2 = fold16; fold16 += ((size_t)16 * cout * cout + 127) & ~(size_t)127;
+    }
     r.cin = cin; r.cout = cout; r.shortcut = cin != cout; r.pre = pre;
     r.n1w = vec(pre + ".norm1.weight", cin);
     r.n1b = vec(pre + ".norm1.bias", cin);
@@ -300,7 +308,7 @@ struct dfh_unet {
       if (cfg.down_attn[i]) down_att[i].resize(cfg.layers_per_block);
       for (int j = 0; j < cfg.layers_per_block; ++j) {
         const std::string b = "down_blocks." + std::to_string(i);
-        build_resnet(b + ".resnets." + std::to_string(j), j == 0 ? ch : oc, oc, down_res[i][j]);
+        build_resnet(b + ".resnets." + std::to_string(j), j == 0 ? ch : oc, oc, down_res[i][j], cfg.sample_size >> i);
       }
       for (int j = 0; j < cfg.layers_per_block && cfg.down_attn[i]; ++j)
         build_attn("down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j), oc, cfg.num_heads[i], down_att[i][j]);
@@ -308,9 +316,9 @@ struct dfh_unet {
       ch = oc;
     }
     const int mid = boc[nb - 1];
-    build_resnet("mid_block.resnets.0", mid, mid, mid_res[0]);
+    build_resnet("mid_block.resnets.0", mid, mid, mid_res[0], cfg.sample_size >> (nb - 1));
     build_attn("mid_block.attentions.0", mid, cfg.num_heads[nb - 1], mid_att);
-    build_resnet("mid_block.resnets.1", mid, mid, mid_res[1]);
+    build_resnet("mid_block.resnets.1", mid, mid, mid_res[1], cfg.sample_size >> (nb - 1));
     int out_ch = boc[nb - 1];
     for (int i = 0; i < nb; ++i) {
       const int prev = out_ch;
@@ -324,7 +332,7 @@ struct dfh_unet {
       for (int j = 0; j < L; ++j) {
         const int skip = (j == L - 1) ? in_ch : out_ch;
         const int hid = (j == 0) ? prev : out_ch;
-        build_resnet(b + ".resnets." + std::to_string(j), hid + skip, out_ch, up_res[i][j]);
+        build_resnet(b + ".resnets." + std::to_string(j), hid + skip, out_ch, up_res[i][j], cfg.sample_size >> (nb - 1 - i));
       }
       for (int j = 0; j < L && att; ++j)
         build_attn(b + ".attentions." + std::to_string(j), out_ch, cfg.num_heads[nb - 1 - i], up_att[i][j]);
@@ -432,6 +440,17 @@ struct dfh_unet {
         const float* bias = i == 3 ? arena32 + a->ff1b.off : nullptr;
         if (int rc = dfh::ln_fold_launch(arena16 + src[i]->off, src[i]->K, arena32 + gam[i]->off, arena32 + bet[i]->off, bias,
                                          fold_w() + dst[i]->w, fold_v() + dst[i]->s, fold_v() + dst[i]->b, src[i]->N, src[i]->K, s)) return rc;
+      }
+    }
+    {
+      std::vector<ResL*> rs;
+      for (auto& lv : down_res) for (auto& r : lv) rs.push_back(&r);
+      rs.push_back(&mid_res[0]); rs.push_back(&mid_res[1]);
+      for (auto& lv : up_res) for (auto& r : lv) rs.push_back(&r);
+      for (ResL* r : rs) {
+        if (!r->has_u) continue;
+        if (int rc = dfh::wino_weight_launch(arena16 + r->w1.off, r->w1.K, fold_w() + r->u1, r->cout, r->cin, s)) return rc;
+        if (int rc = dfh::wino_weight_launch(arena16 + r->w2.off, r->w2.K, fold_w() + r->u2, r->cout, r->cout, s)) return rc;
       }
     }
     for (ConvL& c : up_samp)
@@ -595,6 +614,24 @@ struct dfh_unet {
       return o;
     }
 
+    // stride-1 3x3 conv by Winograd F(2x2, 3x3) (winograd.hip): input transform, ONE batched GEMM over the sixteen transform-domain
+    // planes, output transform with the epilogue (bias, time-embedding row, residual).  The scratch is planned by the dry run too.
+    void wino_conv(const Tensor& x, size_t uoff, int cout, const Vec& bias, const float* rowvec, int rv_off, const bf16_t* resid, Tensor& o) {
+      const long mt = (long)B * (x.H / 2) * (x.W / 2);
+      bf16_t* V = (bf16_t*)temp.alloc((size_t)16 * mt * x.C * 2);
+      bf16_t* Mb = (bf16_t*)temp.alloc((size_t)16 * mt * cout * 2);
+      if (rc || dry) return;
+      if ((rc = dfh::wino_input_launch(x.p, V, B, x.H, x.W, x.C, s))) return;
+      GemmArgs g = base((int)mt, cout);
+      g.p_src[0] = V; g.p_c[0] = x.C; g.nplain = 1; g.W = u->fold_w() + uoff; g.ldw = x.C;
+      g.nbatch = 16; g.a_bs = mt * x.C; g.w_bs = (long)cout * x.C; g.o_bs = mt * cout;
+      g.out = Mb; g.zero = zero;
+      g.prof_flops = 2.0 * B * x.H * x.W * (double)cout * 9.0 * x.C;
+      if ((rc = dfh::gemm_launch(g, s, dfh::wino_gemm_tile(g), 0, -1))) return;
+      rc = dfh::wino_output_launch(Mb, o.p, v32(bias), rowvec, temb_ld, rv_off, resid, B, x.H, x.W, cout, s);
+      dfh::census(dfh::CK_CONV_WINO);
+    }
+
     Tensor resnet(const Tensor& x0, const Tensor* x1, const ResL& r, const float* temb_all) {
       const int H = x0.H, W = x0.W;
       Tensor out = palloc(H, W, r.cout);
@@ -602,6 +639,28 @@ struct dfh_unet {
       Tensor g1 = talloc(H, W, r.cin);
       groupnorm(x0, x1, r.n1w, r.n1b, u->cfg.norm_eps, 1, g1);
       Tensor h1 = talloc(H, W, r.cout);
+      // DFH_WINO: 0 = direct implicit GEMM everywhere, 1 = Winograd at H * W <= 64 (the 8x8 level), 2 = also at H * W <= 256 (A/B)
+      static const int wino_mode = [] { const char* e = getenv("DFH_WINO"); return e ? atoi(e) : 2; }();
+      const bool wino = r.has_u && (dry || u->fold_valid) && ((wino_mode >= 1 && H * W <= 64) || (wino_mode >= 2 && H * W <= 256));
+      if (wino) {
+        wino_conv(g1, r.u1, r.cout, r.b1, temb_all, r.temb_off, nullptr, h1);
+        Tensor g2 = talloc(H, W, r.cout);
+        groupnorm(h1, nullptr, r.n2w, r.n2b, u->cfg.norm_eps, 1, g2);
+        const bf16_t* resid = x0.p;
+        if (r.shortcut) {      // the 1x1 shortcut over the (possibly concatenated) block input: its own GEMM, added by the output transform
+          Tensor sc = talloc(H, W, r.cout);
+          GemmArgs g = base(B * H * W, r.cout);
+          g.p_src[0] = x0.p; g.p_c[0] = x0.C; g.nplain = 1;
+          if (x1) { g.p_src[1] = x1->p; g.p_c[1] = x1->C; g.nplain = 2; }
+          g.W = w16(r.w2) + 9 * r.cout; g.ldw = r.w2.K;
+          g.out = sc.p;
+          gemm(g);
+          resid = sc.p;
+        }
+        wino_conv(g2, r.u2, r.cout, r.b2, nullptr, 0, resid, out);
+        temp.off = mark;
+        return out;
+      }
       {
         GemmArgs g = base(B * H * W, r.cout);
         g.conv_src = g1.p; g.conv_c = r.cin; g.ntaps = 9;

@@ -268,6 +268,17 @@ int dfh_gemm_ln(const dfh_gemm_desc* d, float* rowstat, int* rowstat_bn, const f
 int dfh_ups_phase_fold(const void* W, int ldw, void* WP, int N, int C, void* stream);
 int dfh_conv_up2x(const void* src, int batch, int H, int W, int C, const void* WP, int N, const float* bias, void* out,
                   const void* zero_page, void* stream);
+/* ---- Winograd F(2x2, 3x3) for stride-1 3x3 convs (ResnetBlock2D.conv1 / conv2 at the deep levels; df.py:249-253,518-523): sixteen
+ * transform-domain GEMMs over the 2x2 output tiles instead of nine taps per pixel (2.25 x fewer multiply-adds), U / V / M rounded to bf16.
+ *   dfh_wino_weights : packed bf16 W [N][ldw >= 9 C] -> U [16][N][C] bf16 (G g G^T, fp32 arithmetic, rounded once)
+ *   dfh_conv3x3_wino : src [batch][H][W][C] bf16 (H, W even) -> out [batch][H][W][N] bf16 = conv3x3(src) + bias (+ rowvec row of the
+ *                      image: rowvec[b * rv_ld + rv_off + n]) (+ resid [batch][H][W][N] bf16); three launches (input transform, one
+ *                      batched GEMM, output transform) over `scratch` (dfh_conv3x3_wino_scratch_bytes, 256-byte aligned) */
+int dfh_wino_weights(const void* W, int ldw, void* U, int N, int C, void* stream);
+size_t dfh_conv3x3_wino_scratch_bytes(int batch, int H, int W, int C, int N);
+int dfh_conv3x3_wino(const void* src, int batch, int H, int W, int C, const void* U, int N, const float* bias, const float* rowvec,
+                     int rv_ld, int rv_off, const void* resid, void* out, void* scratch, size_t scratch_bytes, const void* zero_page,
+                     void* stream);
 /* dfh_gemm over nbatch independent planes in ONE launch (grid.y): plane z reads d->a0 + z * a_bs, d->W + z * w_bs and writes
  * d->out + z * o_bs (strides in bf16 elements).  One plain K segment, bias-only epilogue, bf16 row-major output, no split-K. */
 int dfh_gemm_batched(const dfh_gemm_desc* d, int nbatch, long a_bs, long w_bs, long o_bs, void* stream);

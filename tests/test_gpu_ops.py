@@ -261,7 +261,8 @@ def _phase_weights_ref(wb):
 
 
 @pytest.mark.parametrize("B,cin,cout,H,W", [(2, 64, 128, 8, 8), (3, 128, 160, 5, 7), (2, 320, 320, 16, 16), (16, 64, 64, 8, 8),
-                                            (1, 72, 40, 4, 4), (2, 64, 96, 1, 1)])
+                                            (1, 72, 40, 4, 4), (2, 64, 96, 1, 1),
+                                            (16, 64, 320, 32, 32)])      # 4 planes x 64 tiles: the 256 x 320 tile
 def test_upsample_conv_as_four_phase_planes(B, cin, cout, H, W):
     """Upsample2D (nearest 2x, then conv3x3; diffusers, the up-block upsamplers) as four 2x2 convs over the source image with summed taps:
     the summed weights are the exact fp32 tap sums rounded once, and the launch equals the conv over the upsampled image computed with
@@ -287,6 +288,40 @@ def test_upsample_conv_as_four_phase_planes(B, cin, cout, H, W):
     gu.assert_close_bf16(gu.nchw(out), ref, f"phase conv {cin}->{cout}@{H}x{W}")
     full = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), bf(w).float(), bias, padding=1)
     assert gu.rel_err(gu.nchw(out).float(), full) < 6e-3, "against the 3x3 conv over the upsampled image (summed weights rounded once more)"
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W,resid,temb", [(2, 64, 128, 8, 8, False, True), (3, 128, 160, 6, 10, True, False), (2, 320, 320, 16, 16, True, True),
+                                                          (16, 64, 64, 8, 8, False, False), (1, 72, 40, 4, 4, True, True), (2, 64, 96, 2, 2, False, True),
+                                                          (4, 256, 320, 8, 8, True, True),
+                                                          (16, 64, 1280, 16, 16, True, True)])     # 16 planes x 16 tiles: the 256 x 320 tile
+def test_conv3x3_winograd(B, cin, cout, H, W, resid, temb):
+    """Winograd F(2x2, 3x3) conv (input transform, batched GEMM over the 16 transform-domain planes, output transform with bias /
+    time-embedding row / residual) against F.conv2d on the same bf16 operands.  U, V and M are rounded to bf16, so the bound is looser than
+    the direct kernel's (whose only error is the output rounding): rel L2 <= 1e-2 (measured 5e-3)."""
+    x = bf(rnd(B, cin, H, W, seed=32))
+    w = rnd(cout, cin, 3, 3, seed=33, scale=0.05)
+    bias = rnd(cout, seed=34)
+    rv = rnd(B, 3 * cout, seed=35) if temb else None
+    res = bf(rnd(B, H, W, cout, seed=36)) if resid else None
+    packed = gu.pack_conv(w)
+    U = torch.empty(16, cout, cin, dtype=torch.bfloat16, device=gu.DEV)
+    _lib.call("dfh_wino_weights", _lib.ptr(packed), 9 * cin, _lib.ptr(U), cout, cin, gu.stream())
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1.]], device=gu.DEV)
+    Uref = torch.einsum("ij,ncjk,lk->ilnc", G, bf(w).float(), G).reshape(16, cout, cin)
+    assert torch.equal(U, bf(Uref)) or gu.rel_err(U.float(), Uref) < 3e-3, "U = G g G^T of the bf16 taps"
+    nbytes = _lib.raw().dfh_conv3x3_wino_scratch_bytes(B, H, W, cin, cout)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=gu.DEV)
+    out = torch.empty(B, H, W, cout, dtype=torch.bfloat16, device=gu.DEV)
+    z = gu.zero_page()
+    _lib.call("dfh_conv3x3_wino", _lib.ptr(gu.nhwc(x)), B, H, W, cin, _lib.ptr(U), cout, _lib.ptr(bias), _lib.ptr(rv) if temb else None,
+              3 * cout if temb else 0, cout if temb else 0, _lib.ptr(res) if resid else None, _lib.ptr(out), _lib.ptr(scratch), nbytes,
+              _lib.ptr(z), gu.stream())
+    ref = F.conv2d(x.float(), bf(w).float(), bias, padding=1)
+    if temb:
+        ref = ref + rv[:, cout:2 * cout, None, None]
+    if resid:
+        ref = ref + gu.nchw(res).float()
+    gu.assert_close_bf16(gu.nchw(out), ref, f"winograd conv {cin}->{cout}@{H}x{W}", rel=1e-2, max_rel=4e-2)
 
 
 @pytest.mark.parametrize("nb,M,N,K,tile", [(16, 1024, 1280, 1280, 0), (4, 300, 160, 64, 0), (3, 128, 128, 192, 5), (16, 256, 320, 320, 10)])

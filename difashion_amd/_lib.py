@@ -159,9 +159,10 @@ SIGNATURES = {
     "dfh_gemm_out2": (_i, [C.POINTER(GemmDesc), _vp, _i, _i, _vp]),
     "dfh_ups_phase_fold": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "dfh_conv_up2x": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
-    "dfh_wino_weights": (_i, [_vp, _i, _vp, _i, _i, _vp]),
+    "dfh_wino_weights": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    "dfh_wino_blocked": (_i, [_i, _i]),
     "dfh_conv3x3_wino_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
-    "dfh_conv3x3_wino": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "dfh_conv3x3_wino": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
     "dfh_gemm_batched": (_i, [C.POINTER(GemmDesc), _i, C.c_long, C.c_long, C.c_long, _vp]),
     "dfh_ln_fold": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "dfh_gemm_ln": (_i, [C.POINTER(GemmDesc), _vp, C.POINTER(C.c_int), _vp, _i, _i, _f, _vp, _vp]),

@@ -362,15 +362,16 @@ int dfh_conv_up2x(const void* src, int batch, int H, int W, int C, const void* W
   return dfh::gemm_launch(g, (hipStream_t)stream, 0, 0, -1);
 }
 // Winograd F(2x2, 3x3) conv (winograd.hip): weight transform, and the three-launch conv over caller-provided scratch
-int dfh_wino_weights(const void* W, int ldw, void* U, int N, int C, void* stream) {
-  return dfh::wino_weight_launch((const bf16_t*)W, ldw, (bf16_t*)U, N, C, (hipStream_t)stream);
+int dfh_wino_weights(const void* W, int ldw, void* U, int N, int C, int blocked, void* stream) {
+  return dfh::wino_weight_launch((const bf16_t*)W, ldw, (bf16_t*)U, N, C, blocked, (hipStream_t)stream);
 }
+int dfh_wino_blocked(int N, int C) { return dfh::wino_blocked(N, C) ? 1 : 0; }
 size_t dfh_conv3x3_wino_scratch_bytes(int batch, int H, int W, int C, int N) {
   if (batch <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return 0;
   const size_t mt = (size_t)batch * (H / 2) * (W / 2);
   return ((16 * mt * C * 2 + 255) & ~(size_t)255) + ((16 * mt * N * 2 + 255) & ~(size_t)255);
 }
-int dfh_conv3x3_wino(const void* src, int batch, int H, int W, int C, const void* U, int N, const float* bias, const float* rowvec,
+int dfh_conv3x3_wino(const void* src, int batch, int H, int W, int C, const void* U, int u_blocked, int N, const float* bias, const float* rowvec,
                      int rv_ld, int rv_off, const void* resid, void* out, void* scratch, size_t scratch_bytes, const void* zero_page,
                      void* stream) {
   DFH_REQUIRE(src && U && bias && out && scratch && zero_page, "null argument");
@@ -385,7 +386,7 @@ int dfh_conv3x3_wino(const void* src, int batch, int H, int W, int C, const void
   GemmArgs g; std::memset(&g, 0, sizeof(g));
   g.M = (int)mt; g.N = N; g.rows_per_b = (int)mt; g.out_mode = OUT_BF16; g.ld_out = N;
   g.p_src[0] = V; g.p_c[0] = C; g.nplain = 1; g.W = (const bf16_t*)U; g.ldw = C;
-  g.nbatch = 16; g.a_bs = mt * C; g.w_bs = (long)N * C; g.o_bs = mt * N;
+  g.nbatch = 16; g.a_bs = mt * C; g.w_bs = (long)N * C; g.o_bs = mt * N; g.w_blocked = u_blocked;
   g.out = Mb; g.zero = (const bf16_t*)zero_page;
   g.prof_flops = 2.0 * batch * H * W * (double)N * 9.0 * C;
   if (int rc = dfh::gemm_launch(g, s, dfh::wino_gemm_tile(g), 0, -1)) return rc;

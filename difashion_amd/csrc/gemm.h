@@ -56,6 +56,11 @@ struct GemmArgs {
   // profile accounting override (0 = derive from the shape): a launch that is one stage of a convolution (the batched transform-domain
   // GEMM of winograd.hip) reports the REFERENCE algorithm's multiply-adds (the direct conv) under the conv3x3 class
   double prof_flops;
+  // W is stored in 16-row x 64-column blocks, [N / 16][ldw / 64][16][64] (2 KB each): a k-step's W tile is then BN / 16 contiguous 2-KB
+  // chunks instead of BN separate 128-byte pieces of rows ldw * 2 bytes apart -- for weight streams that come from HBM (the deep levels:
+  // few pixel rows share a weight tile) every DRAM page opened is used whole.  Derived weights only (Winograd U: winograd.hip); needs the
+  // LEAN k-loop (plain segments of whole 64-channel slices), N % 16 == 0, ldw % 64 == 0.
+  int w_blocked;
   float* partial;  // [ksplit][M][N] fp32 when ksplit > 1
   // --- optional GroupNorm statistics of the OUTPUT, written by the 256-row epilogue (gemm_wide_epilogue.h) when the launcher finds
   //     the launch eligible: per (image, group, row tile) the sum and the sum of squares of the bf16-rounded outputs, in the layout
@@ -121,7 +126,9 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile = 0, int force_sp
 int ln_fold_launch(const bf16_t* W, int ldw, const float* gamma, const float* beta, const float* bias, bf16_t* WF, float* s, float* b,
                    int N, int K, hipStream_t stream);
 // Winograd F(2x2, 3x3) transforms (winograd.hip): U = G g G^T per weight pack, V = B^T d B of the conv's input, out = A^T m A + epilogue
-int wino_weight_launch(const bf16_t* W, int ldw, bf16_t* U, int N, int C, hipStream_t stream);
+int wino_weight_launch(const bf16_t* W, int ldw, bf16_t* U, int N, int C, int blocked, hipStream_t stream);
+// does the batched transform-domain GEMM of an N x C Winograd conv take U in the blocked layout (GemmArgs::w_blocked)?
+bool wino_blocked(int N, int C);
 int wino_input_launch(const bf16_t* g, bf16_t* V, int B, int H, int W, int C, hipStream_t stream);
 int wino_output_launch(const bf16_t* Mb, bf16_t* out, const float* bias, const float* rowvec, int rv_ld, int rv_off, const bf16_t* resid,
                        int B, int H, int W, int N, hipStream_t stream);

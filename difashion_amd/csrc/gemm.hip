@@ -225,6 +225,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
       const bool ok = w_row[i] >= 0;
       lp_w[i] = ok ? Wb + ((size_t)(unsigned)w_row[i] + k0) : a.zero;
       ls_w[i] = ok ? BK : 0;
+      if (a.w_blocked && ok) {                         // [N / 16][ldw / 64][16][64]: the next k-step of a row is 2 KB further on
+        const int n = n0 + (i * NWV + wave) * 8 + srow;
+        lp_w[i] = Wb + (((size_t)(n >> 4) * (unsigned)(a.ldw >> 6) + (unsigned)ks_begin) * 1024u + (unsigned)((n & 15) * 64 + sslot * 8));
+        ls_w[i] = 1024;
+      }
     }
   }
   auto issue_lean = [&](int buf) {
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
   constexpr int RS = BN * 2 + 16;                  // LDS row stride of the staged output tile (bytes)
   constexpr int NRES = FM * FN;                    // residual loads per lane
   static_assert(WEPI || BM * RS <= 2 * STAGE, "staged output tile must fit the pipeline buffers");
-  static_assert(2 * N_HI + NRES <= 63, "vmcnt is a 6-bit counter");
+  static_assert((NSTAGE - 1) * N_HI + NRES <= 63, "vmcnt is a 6-bit counter");
   // ... and the per-batch TRANSPOSED bf16 output (attention's V^T) as well when the tile lies inside one batch element: the tile is
   // staged transposed and leaves as 16-byte pieces of the [channel][pixel] rows (the fragment layout alone writes 2-byte elements:
   // 40 store instructions of 128 bytes per lane set)
@@ -322,10 +327,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
       if (t == 0 && res_pre) {                        // ... and so may the residual loads issued behind the prologue
         if (ahead == 0) wait_vmcnt<NRES>();
         else if (ahead == 1) { if (hi_wave) wait_vmcnt<N_HI + NRES>(); else wait_vmcnt<N_LO + NRES>(); }
-        else { if (hi_wave) wait_vmcnt<2 * N_HI + NRES>(); else wait_vmcnt<2 * N_LO + NRES>(); }
+        else if (ahead == 2 || NSTAGE < 4) { if (hi_wave) wait_vmcnt<2 * N_HI + NRES>(); else wait_vmcnt<2 * N_LO + NRES>(); }
+        else { if (hi_wave) wait_vmcnt<3 * N_HI + NRES>(); else wait_vmcnt<3 * N_LO + NRES>(); }
       } else if (ahead == 0) wait_vmcnt<0>();
       else if (ahead == 1) { if (hi_wave) wait_vmcnt<N_HI>(); else wait_vmcnt<N_LO>(); }
-      else { if (hi_wave) wait_vmcnt<2 * N_HI>(); else wait_vmcnt<2 * N_LO>(); }
+      else if (ahead == 2 || NSTAGE < 4) { if (hi_wave) wait_vmcnt<2 * N_HI>(); else wait_vmcnt<2 * N_LO>(); }
+      else { if (hi_wave) wait_vmcnt<3 * N_HI>(); else wait_vmcnt<3 * N_LO>(); }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();          // stage t visible to all waves; all waves done with k-step t-1
       asm volatile("" ::: "memory");
@@ -788,7 +795,14 @@ int launch_variant(int tile, const GemmArgs& a, hipStream_t s) {
     case 1: return launch_tile<256, 128, 4, 2, 3>(a, s);
     case 2: return launch_tile<128, 64, 2, 2, 3>(a, s);
     case 3: return launch_tile<128, 160, 2, 2, 2>(a, s);
-    case 5: return lean_plain(a) ? launch_tile<128, 160, 4, 2, 2, true>(a, s) : launch_tile<128, 160, 4, 2, 2>(a, s);
+    case 5: {
+      // batched launches of short planes (the 8x8-level Winograd GEMM: 16 planes x 256 rows = 256 workgroups, one per CU, each a chain of
+      // k-steps that wait for lines requested one stage ahead): a 4-stage ring keeps three stages in flight.  DFH_DEEP4=0 turns it off (A/B).
+      static const bool deep4_off = [] { const char* e = getenv("DFH_DEEP4"); return e && e[0] == '0'; }();
+      const long wgs = (long)((a.M + 127) / 128) * ((a.N + 159) / 160) * (a.nbatch > 1 ? a.nbatch : 1);
+      if (!deep4_off && a.nbatch > 1 && wgs <= 320) return lean_plain(a) ? launch_tile<128, 160, 4, 2, 4, true>(a, s) : launch_tile<128, 160, 4, 2, 4>(a, s);
+      return lean_plain(a) ? launch_tile<128, 160, 4, 2, 2, true>(a, s) : launch_tile<128, 160, 4, 2, 2>(a, s);
+    }
     default: return launch_tile<128, 128, 2, 2, 2>(a, s);
   }
 }
@@ -900,6 +914,11 @@ int gemm_big_geglu_pick(const GemmArgs& a) {
   return (tiles >= 224 && (rem == 0 || rem >= 224 || tiles >= 512)) ? 1 : 0;
 }
 
+bool wino_blocked(int N, int C) {
+  static const bool off = [] { const char* e = getenv("DFH_W_BLOCKED"); return e && e[0] == '0'; }();      // A/B
+  return !off && N % 160 == 0 && C % 64 == 0;          // the batched launch then runs on a LEAN instantiation (128 x 160 eight-wave / 256 x 320)
+}
+
 int wino_gemm_tile(const GemmArgs& a) {
   static const int pin = [] { const char* e = getenv("DFH_WINO_TILE"); return e ? atoi(e) : -1; }();      // probe
   if (pin >= 0) return pin;
@@ -988,6 +1007,8 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
                 "folded LayerNorm: single-pass launches without rowvec / residual only (gemm_ln_consumer_ok)");
     DFH_REQUIRE(a.act != ACT_GEGLU || (a.ld_out & 7) == 0, "folded LayerNorm + GEGLU needs 16-byte aligned output rows");
   }
+  if (a.w_blocked) DFH_REQUIRE(lean_plain(a) && a.N % 16 == 0 && a.ldw % 64 == 0 && a.N % 160 == 0 && force_tile == 0 && split == 1,
+                               "blocked W: LEAN launches (plain 64-multiple segments) on the 128 x 160 / 256 x 320 tiles only");
   if (a.out2) DFH_REQUIRE(split == 1 && a.n_split > 0 && a.n_split % kTiles[tile].bn == 0 && a.out_mode == OUT_BF16 && a.act != ACT_GEGLU &&
                           !a.resid && force_tile == 0, "second destination: single pass, n_split a multiple of the column tile (gemm_out2_ok)");
   if (a.resid) DFH_REQUIRE((double)a.M * a.ld_res * 2.0 < 4.0e9, "residual tensor must be smaller than 4 GB (32-bit lane offsets)");

@@ -449,8 +449,8 @@ struct dfh_unet {
       for (auto& lv : up_res) for (auto& r : lv) rs.push_back(&r);
       for (ResL* r : rs) {
         if (!r->has_u) continue;
-        if (int rc = dfh::wino_weight_launch(arena16 + r->w1.off, r->w1.K, fold_w() + r->u1, r->cout, r->cin, s)) return rc;
-        if (int rc = dfh::wino_weight_launch(arena16 + r->w2.off, r->w2.K, fold_w() + r->u2, r->cout, r->cout, s)) return rc;
+        if (int rc = dfh::wino_weight_launch(arena16 + r->w1.off, r->w1.K, fold_w() + r->u1, r->cout, r->cin, dfh::wino_blocked(r->cout, r->cin), s)) return rc;
+        if (int rc = dfh::wino_weight_launch(arena16 + r->w2.off, r->w2.K, fold_w() + r->u2, r->cout, r->cout, dfh::wino_blocked(r->cout, r->cout), s)) return rc;
       }
     }
     for (ConvL& c : up_samp)
@@ -624,7 +624,7 @@ struct dfh_unet {
       if ((rc = dfh::wino_input_launch(x.p, V, B, x.H, x.W, x.C, s))) return;
       GemmArgs g = base((int)mt, cout);
       g.p_src[0] = V; g.p_c[0] = x.C; g.nplain = 1; g.W = u->fold_w() + uoff; g.ldw = x.C;
-      g.nbatch = 16; g.a_bs = mt * x.C; g.w_bs = (long)cout * x.C; g.o_bs = mt * cout;
+      g.nbatch = 16; g.a_bs = mt * x.C; g.w_bs = (long)cout * x.C; g.o_bs = mt * cout; g.w_blocked = dfh::wino_blocked(cout, x.C);
       g.out = Mb; g.zero = zero;
       g.prof_flops = 2.0 * B * x.H * x.W * (double)cout * 9.0 * x.C;
       if ((rc = dfh::gemm_launch(g, s, dfh::wino_gemm_tile(g), 0, -1))) return;

@@ -10,7 +10,7 @@
 // at the 64x64 / 32x32 levels the transforms would move more bytes than the direct conv's whole launch takes.
 //
 //   wino_weight_kernel : packed bf16 W [N][ldw >= 9 C] (tap-major columns) -> U [16][N][C] bf16 = G g G^T in fp32, rounded once
-//                        (per weight pack, into the fold region of the workspace)
+//                        (per weight pack, into the fold region of the workspace); each plane optionally in 16 x 64 blocks (w_blocked)
 //   wino_input_kernel  : g [B][H][W][C] bf16 (the GroupNorm + SiLU output the conv reads) -> V [16][B H W / 4][C] bf16 = B^T d B
 //                        (zero padding = patches that hang over the border read zeros)
 //   wino_output_kernel : M [16][B H W / 4][N] bf16 (the batched GEMM's output) -> out [B][H][W][N] bf16 = A^T m A + bias
@@ -25,7 +25,7 @@ namespace {
 
 DFH_DEVICE void load8(const bf16_t* p, float* f) { unpack8(*(const uint4*)p, f); }
 
-__global__ __launch_bounds__(256) void wino_weight_kernel(const bf16_t* __restrict__ W, int ldw, bf16_t* __restrict__ U, int N, int C) {
+__global__ __launch_bounds__(256) void wino_weight_kernel(const bf16_t* __restrict__ W, int ldw, bf16_t* __restrict__ U, int N, int C, int blocked) {
   const int n = blockIdx.x;
   const bf16_t* w = W + (long)n * ldw;
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -44,7 +44,11 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const bf16_t* __restri
     for (int i = 0; i < 4; ++i) {         // (G g) G^T
       const float u[4] = {t4[i][0], 0.5f * (t4[i][0] + t4[i][1] + t4[i][2]), 0.5f * (t4[i][0] - t4[i][1] + t4[i][2]), t4[i][2]};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) U[((long)(i * 4 + j) * N + n) * C + c] = f2bf(u[j]);
+      for (int j = 0; j < 4; ++j) {
+        // blocked: each plane as [N / 16][C / 64][16][64] (gemm.h GemmArgs::w_blocked)
+        const long off = blocked ? ((long)(n >> 4) * (C >> 6) + (c >> 6)) * 1024 + (n & 15) * 64 + (c & 63) : (long)n * C + c;
+        U[(long)(i * 4 + j) * N * C + off] = f2bf(u[j]);
+      }
     }
   }
 }
@@ -155,9 +159,10 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const bf16_t* __restri
 
 namespace dfh {
 
-int wino_weight_launch(const bf16_t* W, int ldw, bf16_t* U, int N, int C, hipStream_t stream) {
+int wino_weight_launch(const bf16_t* W, int ldw, bf16_t* U, int N, int C, int blocked, hipStream_t stream) {
   DFH_REQUIRE(W && U && N > 0 && C > 0 && ldw >= 9 * C, "bad argument");
-  hipLaunchKernelGGL(wino_weight_kernel, dim3(N), dim3(256), 0, stream, W, ldw, U, N, C);
+  DFH_REQUIRE(!blocked || (N % 16 == 0 && C % 64 == 0), "blocked U needs N % 16 == 0 and C % 64 == 0");
+  hipLaunchKernelGGL(wino_weight_kernel, dim3(N), dim3(256), 0, stream, W, ldw, U, N, C, blocked);
   return check_launch("wino_weight_kernel");
 }
 

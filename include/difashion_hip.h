@@ -274,9 +274,12 @@ int dfh_conv_up2x(const void* src, int batch, int H, int W, int C, const void* W
  *   dfh_conv3x3_wino : src [batch][H][W][C] bf16 (H, W even) -> out [batch][H][W][N] bf16 = conv3x3(src) + bias (+ rowvec row of the
  *                      image: rowvec[b * rv_ld + rv_off + n]) (+ resid [batch][H][W][N] bf16); three launches (input transform, one
  *                      batched GEMM, output transform) over `scratch` (dfh_conv3x3_wino_scratch_bytes, 256-byte aligned) */
-int dfh_wino_weights(const void* W, int ldw, void* U, int N, int C, void* stream);
+int dfh_wino_weights(const void* W, int ldw, void* U, int N, int C, int blocked, void* stream);
+/* 1 when the library stores U of an N x C conv in 16-row x 64-column blocks ([16][N / 16][C / 64][16][64]: every 2-KB DRAM burst of the
+ * weight stream is used whole); pass the same value as `blocked` / `u_blocked` */
+int dfh_wino_blocked(int N, int C);
 size_t dfh_conv3x3_wino_scratch_bytes(int batch, int H, int W, int C, int N);
-int dfh_conv3x3_wino(const void* src, int batch, int H, int W, int C, const void* U, int N, const float* bias, const float* rowvec,
+int dfh_conv3x3_wino(const void* src, int batch, int H, int W, int C, const void* U, int u_blocked, int N, const float* bias, const float* rowvec,
                      int rv_ld, int rv_off, const void* resid, void* out, void* scratch, size_t scratch_bytes, const void* zero_page,
                      void* stream);
 /* dfh_gemm over nbatch independent planes in ONE launch (grid.y): plane z reads d->a0 + z * a_bs, d->W + z * w_bs and writes

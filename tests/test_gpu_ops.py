@@ -305,15 +305,17 @@ def test_conv3x3_winograd(B, cin, cout, H, W, resid, temb):
     res = bf(rnd(B, H, W, cout, seed=36)) if resid else None
     packed = gu.pack_conv(w)
     U = torch.empty(16, cout, cin, dtype=torch.bfloat16, device=gu.DEV)
-    _lib.call("dfh_wino_weights", _lib.ptr(packed), 9 * cin, _lib.ptr(U), cout, cin, gu.stream())
+    blocked = _lib.raw().dfh_wino_blocked(cout, cin)          # 16 x 64 blocks where the batched GEMM reads them (N % 160 == 0, C % 64 == 0)
+    _lib.call("dfh_wino_weights", _lib.ptr(packed), 9 * cin, _lib.ptr(U), cout, cin, blocked, gu.stream())
     G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1.]], device=gu.DEV)
     Uref = torch.einsum("ij,ncjk,lk->ilnc", G, bf(w).float(), G).reshape(16, cout, cin)
-    assert torch.equal(U, bf(Uref)) or gu.rel_err(U.float(), Uref) < 3e-3, "U = G g G^T of the bf16 taps"
+    Urow = U.view(16, cout // 16, cin // 64, 16, 64).permute(0, 1, 3, 2, 4).reshape(16, cout, cin) if blocked else U
+    assert torch.equal(Urow, bf(Uref)) or gu.rel_err(Urow.float(), Uref) < 3e-3, "U = G g G^T of the bf16 taps"
     nbytes = _lib.raw().dfh_conv3x3_wino_scratch_bytes(B, H, W, cin, cout)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=gu.DEV)
     out = torch.empty(B, H, W, cout, dtype=torch.bfloat16, device=gu.DEV)
     z = gu.zero_page()
-    _lib.call("dfh_conv3x3_wino", _lib.ptr(gu.nhwc(x)), B, H, W, cin, _lib.ptr(U), cout, _lib.ptr(bias), _lib.ptr(rv) if temb else None,
+    _lib.call("dfh_conv3x3_wino", _lib.ptr(gu.nhwc(x)), B, H, W, cin, _lib.ptr(U), blocked, cout, _lib.ptr(bias), _lib.ptr(rv) if temb else None,
               3 * cout if temb else 0, cout if temb else 0, _lib.ptr(res) if resid else None, _lib.ptr(out), _lib.ptr(scratch), nbytes,
               _lib.ptr(z), gu.stream())
     ref = F.conv2d(x.float(), bf(w).float(), bias, padding=1)

@@ -212,7 +212,9 @@ struct dfh_unet {
   // res: side of the (square) image this resnet runs on
   void build_resnet(const std::string& pre, int cin, int cout, ResL& r, int res) {
     const int temb = cfg.block_out_channels[0] * 4;
-    if (res % 2 == 0 && res * res <= 256 && cin % 8 == 0 && cout % 8 == 0) {
+    // Winograd (winograd.hip) where it pays and where its bf16 transform-domain roundings are a small part of the layer's error budget:
+    // the wide layers (>= 512 channels both ways) of the levels of at most 16 x 16 pixels
+    if (res % 2 == 0 && res * res <= 256 && cin % 8 == 0 && cout % 8 == 0 && std::min(cin, cout) >= 512) {
       r.has_u = true;
       r.u1 = fold16; fold16 += ((size_t)16 * cout * cin + 127) & ~(size_t)127;
       r.u2 = fold16; fold16 += ((size_t)16 * cout * cout + 127) & ~(size_t)127;

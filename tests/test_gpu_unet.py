@@ -61,6 +61,29 @@ def test_unet_matches_oracle_small(name, cfg):
     assert all(v <= TOL for v in report.values()), report
 
 
+def test_unet_wide_deep_levels_take_winograd_and_phase_convs():
+    """A small U-Net whose two deep levels are wide (512 channels at 8x8 and 4x4): their resnet convs run as Winograd F(2x2, 3x3)
+    (csrc/winograd.hip: 16 transform-domain GEMMs in one batched launch, also with the 1x1 shortcut as its own GEMM and the concatenated
+    skip input), the upsamplers as four phase planes over the source image (csrc/gemm.h phase2x) -- the census shows both ran -- within
+    the same tolerance."""
+    from difashion_amd import _lib
+    cfg = unet_ref.UNetConfig(sample_size=32, block_out_channels=(64, 64, 512, 512), cross_attention_dim=64, num_heads=(2, 2, 8, 8))
+    params = unet_ref.init_params(cfg, seed=5, w_std=0.03, affine_jitter=0.1)
+    m = hip_unet(cfg, params)
+    x, e = inputs(cfg, 3, 13)
+    t = torch.tensor([7, 500, 981])
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(params, cfg, x, t, e)
+        m(x.to(DEV), t.to(DEV), e.to(DEV))
+        _lib.census_reset()
+        out = m(x.to(DEV), t.to(DEV), e.to(DEV)).sample
+    cen = _lib.census()
+    err = rel_err(out.cpu(), ref)
+    print("wide2", f"{err:.2e}", {k: v for k, v in cen.items() if v})
+    assert cen["conv_wino"] == 22 and cen["conv_phase"] == 3, cen      # every resnet of the two wide levels but the 64 -> 512 one
+    assert err <= TOL
+
+
 def test_timestep_forms_and_return_dict():
     cfg = unet_ref.TINY
     params = unet_ref.init_params(cfg, seed=4)
@@ -233,6 +256,7 @@ def test_unet_sd15_full_size_batch16_matches_oracle():
     assert cen["attention_x32"] > 0, cen                               # the 32x32x16 attention kernel
     assert cen["gemm_lean"] + cen["gemm_row"] > 0, cen                 # the short-K token linears
     assert cen["ln_folded"] >= 45 and cen["layernorm"] <= 3, cen       # LayerNorm folded into its consumers (all but the 8x8 block)
+    assert cen["conv_wino"] == 24 and cen["conv_phase"] == 3, cen      # Winograd at the 16x16 / 8x8 levels, phase-plane upsamplers
     m.enable_fp8()
     with torch.no_grad():
         m(xd, td, ed)

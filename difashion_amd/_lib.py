@@ -161,6 +161,9 @@ SIGNATURES = {
     "dfh_conv_up2x": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "dfh_wino_weights": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     "dfh_wino_blocked": (_i, [_i, _i]),
+    "dfh_wino_input": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "dfh_gn_wino_input_ok": (_i, [_i, _i, _i, _i, _i]),
+    "dfh_gn_wino_input": (_i, [_vp, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _i, _i, _i, _vp]),
     "dfh_conv3x3_wino_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "dfh_conv3x3_wino": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
     "dfh_gemm_batched": (_i, [C.POINTER(GemmDesc), _i, C.c_long, C.c_long, C.c_long, _vp]),

@@ -366,6 +366,15 @@ int dfh_wino_weights(const void* W, int ldw, void* U, int N, int C, int blocked,
   return dfh::wino_weight_launch((const bf16_t*)W, ldw, (bf16_t*)U, N, C, blocked, (hipStream_t)stream);
 }
 int dfh_wino_blocked(int N, int C) { return dfh::wino_blocked(N, C) ? 1 : 0; }
+int dfh_wino_input(const void* src, void* V, int batch, int H, int W, int C, void* stream) {
+  return dfh::wino_input_launch((const bf16_t*)src, (bf16_t*)V, batch, H, W, C, (hipStream_t)stream);
+}
+int dfh_gn_wino_input_ok(int c0, int c1, int groups, int H, int W) { return dfh::gn_wino_ok(c0, c1, groups, H, W) ? 1 : 0; }
+int dfh_gn_wino_input(const void* src0, int c0, const void* src1, int c1, const float* gamma, const float* beta, float eps, int groups,
+                      void* V, int batch, int H, int W, void* stream) {
+  return dfh::gn_wino_input_launch((const bf16_t*)src0, c0, (const bf16_t*)src1, c1, gamma, beta, eps, groups, (bf16_t*)V, batch, H, W,
+                                   (hipStream_t)stream);
+}
 size_t dfh_conv3x3_wino_scratch_bytes(int batch, int H, int W, int C, int N) {
   if (batch <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return 0;
   const size_t mt = (size_t)batch * (H / 2) * (W / 2);

@@ -130,6 +130,10 @@ int wino_weight_launch(const bf16_t* W, int ldw, bf16_t* U, int N, int C, int bl
 // does the batched transform-domain GEMM of an N x C Winograd conv take U in the blocked layout (GemmArgs::w_blocked)?
 bool wino_blocked(int N, int C);
 int wino_input_launch(const bf16_t* g, bf16_t* V, int B, int H, int W, int C, hipStream_t stream);
+// GroupNorm(+SiLU) fused with the input transform: V = B^T silu(GN(concat(src0, src1))) B (gn_wino_ok: is the shape supported?)
+bool gn_wino_ok(int C0, int C1, int G, int H, int W);
+int gn_wino_input_launch(const bf16_t* src0, int C0, const bf16_t* src1, int C1, const float* gamma, const float* beta, float eps, int G,
+                         bf16_t* V, int B, int H, int W, hipStream_t stream);
 int wino_output_launch(const bf16_t* Mb, bf16_t* out, const float* bias, const float* rowvec, int rv_ld, int rv_off, const bf16_t* resid,
                        int B, int H, int W, int N, hipStream_t stream);
 // tile id (gemm_launch force_tile) for the batched transform-domain GEMM: the 256-row ring when a plane has at most 256 rows (its

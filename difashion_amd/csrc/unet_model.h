@@ -618,17 +618,24 @@ struct dfh_unet {
 
     // stride-1 3x3 conv by Winograd F(2x2, 3x3) (winograd.hip): input transform, ONE batched GEMM over the sixteen transform-domain
     // planes, output transform with the epilogue (bias, time-embedding row, residual).  The scratch is planned by the dry run too.
-    void wino_conv(const Tensor& x, size_t uoff, int cout, const Vec& bias, const float* rowvec, int rv_off, const bf16_t* resid, Tensor& o) {
+    // nw / nb: the GroupNorm(+SiLU) in front of the conv runs inside the input transform (x, x1 = its raw, possibly concatenated input;
+    // winograd.hip gn_wino_input_kernel); null: x is the already normalised tensor
+    void wino_conv(const Tensor& x, const Tensor* x1, const Vec* nw, const Vec* nb, size_t uoff, int cout, const Vec& bias, const float* rowvec,
+                   int rv_off, const bf16_t* resid, Tensor& o) {
+      const int C = x.C + (x1 ? x1->C : 0);
       const long mt = (long)B * (x.H / 2) * (x.W / 2);
-      bf16_t* V = (bf16_t*)temp.alloc((size_t)16 * mt * x.C * 2);
+      bf16_t* V = (bf16_t*)temp.alloc((size_t)16 * mt * C * 2);
       bf16_t* Mb = (bf16_t*)temp.alloc((size_t)16 * mt * cout * 2);
       if (rc || dry) return;
-      if ((rc = dfh::wino_input_launch(x.p, V, B, x.H, x.W, x.C, s))) return;
+      if (nw) rc = dfh::gn_wino_input_launch(x.p, x.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, v32(*nw), v32(*nb), u->cfg.norm_eps,
+                                             u->cfg.norm_num_groups, V, B, x.H, x.W, s);
+      else rc = dfh::wino_input_launch(x.p, V, B, x.H, x.W, C, s);
+      if (rc) return;
       GemmArgs g = base((int)mt, cout);
-      g.p_src[0] = V; g.p_c[0] = x.C; g.nplain = 1; g.W = u->fold_w() + uoff; g.ldw = x.C;
-      g.nbatch = 16; g.a_bs = mt * x.C; g.w_bs = (long)cout * x.C; g.o_bs = mt * cout; g.w_blocked = dfh::wino_blocked(cout, x.C);
+      g.p_src[0] = V; g.p_c[0] = C; g.nplain = 1; g.W = u->fold_w() + uoff; g.ldw = C;
+      g.nbatch = 16; g.a_bs = mt * C; g.w_bs = (long)cout * C; g.o_bs = mt * cout; g.w_blocked = dfh::wino_blocked(cout, C);
       g.out = Mb; g.zero = zero;
-      g.prof_flops = 2.0 * B * x.H * x.W * (double)cout * 9.0 * x.C;
+      g.prof_flops = 2.0 * B * x.H * x.W * (double)cout * 9.0 * C;
       if ((rc = dfh::gemm_launch(g, s, dfh::wino_gemm_tile(g), 0, -1))) return;
       rc = dfh::wino_output_launch(Mb, o.p, v32(bias), rowvec, temb_ld, rv_off, resid, B, x.H, x.W, cout, s);
       dfh::census(dfh::CK_CONV_WINO);
@@ -639,15 +646,23 @@ struct dfh_unet {
       Tensor out = palloc(H, W, r.cout);
       const size_t mark = temp.off;
       Tensor g1 = talloc(H, W, r.cin);
-      groupnorm(x0, x1, r.n1w, r.n1b, u->cfg.norm_eps, 1, g1);
       Tensor h1 = talloc(H, W, r.cout);
       // DFH_WINO: 0 = direct implicit GEMM everywhere, 1 = Winograd at H * W <= 64 (the 8x8 level), 2 = also at H * W <= 256 (A/B)
       static const int wino_mode = [] { const char* e = getenv("DFH_WINO"); return e ? atoi(e) : 2; }();
       const bool wino = r.has_u && (dry || u->fold_valid) && ((wino_mode >= 1 && H * W <= 64) || (wino_mode >= 2 && H * W <= 256));
       if (wino) {
-        wino_conv(g1, r.u1, r.cout, r.b1, temb_all, r.temb_off, nullptr, h1);
+        // the GroupNorms in front of the two convs run inside the input transforms where the (image, group) slab fits the kernel
+        // (DFH_WINO_GN=0: separate GroupNorm launches, A/B)
+        static const bool gn_off = [] { const char* e = getenv("DFH_WINO_GN"); return e && e[0] == '0'; }();
+        const int G = u->cfg.norm_num_groups;
+        if (!gn_off && dfh::gn_wino_ok(x0.C, x1 ? x1->C : 0, G, H, W)) wino_conv(x0, x1, &r.n1w, &r.n1b, r.u1, r.cout, r.b1, temb_all, r.temb_off, nullptr, h1);
+        else {
+          groupnorm(x0, x1, r.n1w, r.n1b, u->cfg.norm_eps, 1, g1);
+          wino_conv(g1, nullptr, nullptr, nullptr, r.u1, r.cout, r.b1, temb_all, r.temb_off, nullptr, h1);
+        }
         Tensor g2 = talloc(H, W, r.cout);
-        groupnorm(h1, nullptr, r.n2w, r.n2b, u->cfg.norm_eps, 1, g2);
+        const bool gn2 = !gn_off && dfh::gn_wino_ok(r.cout, 0, G, H, W);
+        if (!gn2) groupnorm(h1, nullptr, r.n2w, r.n2b, u->cfg.norm_eps, 1, g2);
         const bf16_t* resid = x0.p;
         if (r.shortcut) {      // the 1x1 shortcut over the (possibly concatenated) block input: its own GEMM, added by the output transform
           Tensor sc = talloc(H, W, r.cout);
@@ -659,10 +674,12 @@ struct dfh_unet {
           gemm(g);
           resid = sc.p;
         }
-        wino_conv(g2, r.u2, r.cout, r.b2, nullptr, 0, resid, out);
+        if (gn2) wino_conv(h1, nullptr, &r.n2w, &r.n2b, r.u2, r.cout, r.b2, nullptr, 0, resid, out);
+        else wino_conv(g2, nullptr, nullptr, nullptr, r.u2, r.cout, r.b2, nullptr, 0, resid, out);
         temp.off = mark;
         return out;
       }
+      groupnorm(x0, x1, r.n1w, r.n1b, u->cfg.norm_eps, 1, g1);
       {
         GemmArgs g = base(B * H * W, r.cout);
         g.conv_src = g1.p; g.conv_c = r.cin; g.ntaps = 9;

@@ -102,6 +102,115 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const bf16_t* __restric
   }
 }
 
+// GroupNorm(+SiLU) and the input transform in ONE launch: a workgroup owns one (image, group) slab -- H W pixels x C / G channels, at most
+// 16 x 16 x 80 here -- keeps it in LDS as bf16, computes the statistics (two passes: mean, centred squares), normalises in place (rounded to
+// bf16 exactly where the unfused GroupNorm kernel rounds its output) and transforms 4x4 patches straight out of LDS.  Saves the normalised
+// tensor's round trip through HBM and one launch per conv.  Channels come from two sources (the up blocks' skip concat), 4-channel units.
+struct GnWinoArgs {
+  const bf16_t* src0; const bf16_t* src1; int C0, C1;   // [B][HW][C0], [B][HW][C1]
+  const float* gamma; const float* beta; float eps;
+  bf16_t* V; int B, H, W, G;
+};
+
+__global__ __launch_bounds__(256) void gn_wino_input_kernel(const GnWinoArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int C = a.C0 + a.C1, cpg = C / a.G, upp = cpg >> 2, HW = a.H * a.W;
+  const int cg = g * cpg, total = HW * upp;
+  const int RS = cpg * 2 + 8;                                  // LDS row stride (bytes): one pixel's slab + 8 (bank spread)
+  __shared__ float red[8];
+  __shared__ __attribute__((aligned(16))) float gam_s[256], bet_s[256];
+  if (tid < cpg) { gam_s[tid] = a.gamma[cg + tid]; bet_s[tid] = a.beta[cg + tid]; }
+  // ---- pass 1: global -> LDS (raw bf16), sum
+  float s = 0.f;
+  for (int idx = tid; idx < total; idx += 256) {
+    const int p = idx / upp, j = idx - p * upp, c = cg + j * 4;
+    const uint2 r = c < a.C0 ? *(const uint2*)(a.src0 + ((long)b * HW + p) * a.C0 + c)
+                             : *(const uint2*)(a.src1 + ((long)b * HW + p) * a.C1 + (c - a.C0));
+    *(uint2*)(smem + p * RS + j * 8) = r;
+    s += (__uint_as_float(r.x << 16) + __uint_as_float(r.x & 0xffff0000u)) + (__uint_as_float(r.y << 16) + __uint_as_float(r.y & 0xffff0000u));
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float n = (float)HW * (float)cpg;
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / n;
+  // ---- pass 2: centred squares (each thread re-reads the units it wrote)
+  float q = 0.f;
+  for (int idx = tid; idx < total; idx += 256) {
+    const int p = idx / upp, j = idx - p * upp;
+    const uint2 r = *(const uint2*)(smem + p * RS + j * 8);
+    const float v[4] = {__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float d = v[k] - mean; q += d * d; }
+  }
+  q = wave_sum(q);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
+  __syncthreads();
+  const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) / n + a.eps);
+  // ---- pass 3: normalise + SiLU in place, rounded to bf16
+  for (int idx = tid; idx < total; idx += 256) {
+    const int p = idx / upp, j = idx - p * upp;
+    uint2* slot = (uint2*)(smem + p * RS + j * 8);
+    const uint2 r = *slot;
+    const float4 gm = *(const float4*)(gam_s + j * 4), bt = *(const float4*)(bet_s + j * 4);
+    const float y0 = silu_f((__uint_as_float(r.x << 16) - mean) * rstd * gm.x + bt.x);
+    const float y1 = silu_f((__uint_as_float(r.x & 0xffff0000u) - mean) * rstd * gm.y + bt.y);
+    const float y2 = silu_f((__uint_as_float(r.y << 16) - mean) * rstd * gm.z + bt.z);
+    const float y3 = silu_f((__uint_as_float(r.y & 0xffff0000u) - mean) * rstd * gm.w + bt.w);
+    uint2 o; o.x = pack2bf(y0, y1); o.y = pack2bf(y2, y3);
+    *slot = o;
+  }
+  __syncthreads();
+  // ---- transform: one item = one 4x4 patch x one 4-channel unit
+  const int TH = a.H >> 1, TW = a.W >> 1, tiles = TH * TW;
+  const long Mt = (long)a.B * tiles;
+  for (int idx = tid; idx < tiles * upp; idx += 256) {
+    const int t = idx / upp, j = idx - t * upp;
+    const int ty = t / TW, tx = t - ty * TW;
+    float d[4][4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int y = 2 * ty - 1 + r;
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const int x = 2 * tx - 1 + c4;
+        uint2 v = uint2{0u, 0u};
+        if ((unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) v = *(const uint2*)(smem + (y * a.W + x) * RS + j * 8);
+        d[r][c4][0] = __uint_as_float(v.x << 16); d[r][c4][1] = __uint_as_float(v.x & 0xffff0000u);
+        d[r][c4][2] = __uint_as_float(v.y << 16); d[r][c4][3] = __uint_as_float(v.y & 0xffff0000u);
+      }
+    }
+    float qv[4][4][4];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        qv[0][c4][e] = d[0][c4][e] - d[2][c4][e];
+        qv[1][c4][e] = d[1][c4][e] + d[2][c4][e];
+        qv[2][c4][e] = d[2][c4][e] - d[1][c4][e];
+        qv[3][c4][e] = d[1][c4][e] - d[3][c4][e];
+      }
+    bf16_t* dst = a.V + ((long)b * tiles + t) * C + cg + j * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v[4][4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[0][e] = qv[i][0][e] - qv[i][2][e];
+        v[1][e] = qv[i][1][e] + qv[i][2][e];
+        v[2][e] = qv[i][2][e] - qv[i][1][e];
+        v[3][e] = qv[i][1][e] - qv[i][3][e];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        uint2 o; o.x = pack2bf(v[jj][0], v[jj][1]); o.y = pack2bf(v[jj][2], v[jj][3]);
+        *(uint2*)(dst + (long)(i * 4 + jj) * Mt * C) = o;
+      }
+    }
+  }
+}
+
 // one thread = one 2x2 output tile x 8 channels
 __global__ __launch_bounds__(256) void wino_output_kernel(const bf16_t* __restrict__ Mb, bf16_t* __restrict__ out, const float* __restrict__ bias,
                                                           const float* __restrict__ rowvec, int rv_ld, int rv_off,
@@ -172,6 +281,31 @@ int wino_input_launch(const bf16_t* g, bf16_t* V, int B, int H, int W, int C, hi
   ProfScope ps(PC_CONV3, 0.0, (double)B * H * W * C * 2.0 * 5.0, stream);
   hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, V, B, H, W, C);
   return check_launch("wino_input_kernel");
+}
+
+bool gn_wino_ok(int C0, int C1, int G, int H, int W) {
+  const int C = C0 + C1;
+  if (G <= 0 || C % G) return false;
+  const int cpg = C / G;
+  return cpg % 4 == 0 && cpg <= 256 && C0 % 4 == 0 && (H & 1) == 0 && (W & 1) == 0 && (size_t)H * W * (cpg * 2 + 8) <= 96 * 1024;
+}
+
+int gn_wino_input_launch(const bf16_t* src0, int C0, const bf16_t* src1, int C1, const float* gamma, const float* beta, float eps, int G,
+                         bf16_t* V, int B, int H, int W, hipStream_t stream) {
+  DFH_REQUIRE(src0 && gamma && beta && V && (C1 == 0 || src1), "null pointer");
+  DFH_REQUIRE(gn_wino_ok(C0, C1, G, H, W), "shape not supported by the fused GroupNorm + input transform (gn_wino_ok)");
+  GnWinoArgs a; a.src0 = src0; a.src1 = src1; a.C0 = C0; a.C1 = C1; a.gamma = gamma; a.beta = beta; a.eps = eps; a.V = V;
+  a.B = B; a.H = H; a.W = W; a.G = G;
+  const int C = C0 + C1;
+  const size_t lds = (size_t)H * W * ((C / G) * 2 + 8);
+  static size_t lds_set = 0;
+  if (lds > 48 * 1024 && lds > lds_set) {
+    (void)hipFuncSetAttribute((const void*)gn_wino_input_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    lds_set = 96 * 1024;
+  }
+  ProfScope ps(PC_GNORM, 0.0, (double)B * H * W * C * 2.0 * 5.0, stream);
+  hipLaunchKernelGGL(gn_wino_input_kernel, dim3(G, B), dim3(256), lds, stream, a);
+  return check_launch("gn_wino_input_kernel");
 }
 
 int wino_output_launch(const bf16_t* Mb, bf16_t* out, const float* bias, const float* rowvec, int rv_ld, int rv_off, const bf16_t* resid,

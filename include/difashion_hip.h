@@ -275,6 +275,13 @@ int dfh_conv_up2x(const void* src, int batch, int H, int W, int C, const void* W
  *                      image: rowvec[b * rv_ld + rv_off + n]) (+ resid [batch][H][W][N] bf16); three launches (input transform, one
  *                      batched GEMM, output transform) over `scratch` (dfh_conv3x3_wino_scratch_bytes, 256-byte aligned) */
 int dfh_wino_weights(const void* W, int ldw, void* U, int N, int C, int blocked, void* stream);
+/* the input transform alone: src [batch][H][W][C] bf16 -> V [16][batch * H/2 * W/2][C] bf16 = B^T d B per 4x4 patch (stride 2, zero padded);
+ * dfh_gn_wino_input: the same over silu(GroupNorm(concat(src0, src1))) (ResnetBlock2D.norm1 / norm2 + nonlinearity in front of the conv),
+ * one launch, the normalised tensor never goes to HBM; dfh_gn_wino_input_ok tells whether the (image, group) slab fits the kernel */
+int dfh_wino_input(const void* src, void* V, int batch, int H, int W, int C, void* stream);
+int dfh_gn_wino_input_ok(int c0, int c1, int groups, int H, int W);
+int dfh_gn_wino_input(const void* src0, int c0, const void* src1, int c1, const float* gamma, const float* beta, float eps, int groups,
+                      void* V, int batch, int H, int W, void* stream);
 /* 1 when the library stores U of an N x C conv in 16-row x 64-column blocks ([16][N / 16][C / 64][16][64]: every 2-KB DRAM burst of the
  * weight stream is used whole); pass the same value as `blocked` / `u_blocked` */
 int dfh_wino_blocked(int N, int C);

@@ -326,6 +326,30 @@ def test_conv3x3_winograd(B, cin, cout, H, W, resid, temb):
     gu.assert_close_bf16(gu.nchw(out), ref, f"winograd conv {cin}->{cout}@{H}x{W}", rel=1e-2, max_rel=4e-2)
 
 
+@pytest.mark.parametrize("B,C0,C1,H,W", [(2, 1280, 0, 16, 16), (3, 1280, 640, 8, 8), (2, 640, 0, 16, 16), (16, 1280, 1280, 8, 8), (2, 128, 128, 4, 6)])
+def test_groupnorm_silu_fused_into_the_winograd_input_transform(B, C0, C1, H, W):
+    """V = B^T silu(GroupNorm(concat(x0, x1))) B from one launch (gn_wino_input_kernel) against the two-launch path (dfh_groupnorm, then
+    dfh_wino_input) and against torch: the statistics are summed in a different order, so single bf16 roundings of the normalised tensor may
+    differ -- rel L2 <= 2e-3 between the two, and the unfused transform is exact on its input."""
+    G, C = 32, C0 + C1
+    assert _lib.raw().dfh_gn_wino_input_ok(C0, C1, G, H, W)
+    x0 = bf(rnd(B, H, W, C0, seed=40)); x1 = bf(rnd(B, H, W, C1, seed=41, scale=2.0)) if C1 else None
+    gamma = 1.0 + 0.1 * rnd(C, seed=42); beta = 0.1 * rnd(C, seed=43)
+    mt = B * (H // 2) * (W // 2)
+    Vf = torch.empty(16, mt, C, dtype=torch.bfloat16, device=gu.DEV)
+    _lib.call("dfh_gn_wino_input", _lib.ptr(x0), C0, _lib.ptr(x1) if C1 else None, C1, _lib.ptr(gamma), _lib.ptr(beta), 1e-5, G, _lib.ptr(Vf),
+              B, H, W, gu.stream())
+    xcat = torch.cat([x0, x1], dim=-1) if C1 else x0
+    gref = bf(F.silu(F.group_norm(gu.nchw(xcat).float(), G, gamma, beta, 1e-5)))           # what the GroupNorm kernel writes
+    Vu = torch.empty_like(Vf)
+    _lib.call("dfh_wino_input", _lib.ptr(gu.nhwc(gref)), _lib.ptr(Vu), B, H, W, C, gu.stream())
+    BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1.]], device=gu.DEV)
+    patches = F.pad(gref.float(), (1, 1, 1, 1)).unfold(2, 4, 2).unfold(3, 4, 2)                 # [B][C][TH][TW][4][4]
+    Vref = torch.einsum("ij,bcyxjk,lk->ilbyxc", BT, patches, BT).reshape(16, mt, C)
+    assert torch.equal(Vu, bf(Vref)), "the input transform is exact in fp32 on bf16 inputs (sums of four)"
+    assert gu.rel_err(Vf.float(), Vref) <= 2e-3
+
+
 @pytest.mark.parametrize("nb,M,N,K,tile", [(16, 1024, 1280, 1280, 0), (4, 300, 160, 64, 0), (3, 128, 128, 192, 5), (16, 256, 320, 320, 10)])
 def test_gemm_batched_planes_in_one_launch(nb, M, N, K, tile):
     """grid.y planes of independent GEMMs (dfh_gemm_batched) equal nb separate launches bit for bit."""

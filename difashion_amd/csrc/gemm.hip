@@ -796,11 +796,13 @@ int launch_variant(int tile, const GemmArgs& a, hipStream_t s) {
     case 2: return launch_tile<128, 64, 2, 2, 3>(a, s);
     case 3: return launch_tile<128, 160, 2, 2, 2>(a, s);
     case 5: {
-      // batched launches of short planes (the 8x8-level Winograd GEMM: 16 planes x 256 rows = 256 workgroups, one per CU, each a chain of
-      // k-steps that wait for lines requested one stage ahead): a 4-stage ring keeps three stages in flight.  DFH_DEEP4=0 turns it off (A/B).
+      // launches of at most ~one workgroup per CU (the 8x8-level Winograd GEMM: 16 planes x 256 rows = 256 workgroups; the 16x16-level token
+      // linears), each a chain of k-steps that wait for lines requested one stage ahead: a 4-stage ring keeps three stages in flight.
+      // DFH_DEEP4=0 turns it off (A/B).
       static const bool deep4_off = [] { const char* e = getenv("DFH_DEEP4"); return e && e[0] == '0'; }();
-      const long wgs = (long)((a.M + 127) / 128) * ((a.N + 159) / 160) * (a.nbatch > 1 ? a.nbatch : 1);
-      if (!deep4_off && a.nbatch > 1 && wgs <= 320) return lean_plain(a) ? launch_tile<128, 160, 4, 2, 4, true>(a, s) : launch_tile<128, 160, 4, 2, 4>(a, s);
+      static const bool deep4_all = [] { const char* e = getenv("DFH_DEEP4"); return !(e && e[0] == '1'); }();     // 1: batched launches only (A/B: 16.32 -> 16.25 ms with single launches too)
+      const long wgs = (long)((a.M + 127) / 128) * ((a.N + 159) / 160) * (a.nbatch > 1 ? a.nbatch : 1) * a.ksplit;
+      if (!deep4_off && (a.nbatch > 1 || deep4_all) && wgs <= 320) return lean_plain(a) ? launch_tile<128, 160, 4, 2, 4, true>(a, s) : launch_tile<128, 160, 4, 2, 4>(a, s);
       return lean_plain(a) ? launch_tile<128, 160, 4, 2, 2, true>(a, s) : launch_tile<128, 160, 4, 2, 2>(a, s);
     }
     default: return launch_tile<128, 128, 2, 2, 2>(a, s);

@@ -161,6 +161,7 @@ SIGNATURES = {
     "dfh_conv_up2x": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "dfh_wino_weights": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     "dfh_wino_blocked": (_i, [_i, _i]),
+    "dfh_prof_saved_flops": (C.c_double, []),
     "dfh_wino_input": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dfh_gn_wino_input_ok": (_i, [_i, _i, _i, _i, _i]),
     "dfh_gn_wino_input": (_i, [_vp, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _i, _i, _i, _vp]),

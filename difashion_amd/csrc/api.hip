@@ -49,6 +49,9 @@ void prof_open(int cls, double flops, double bytes, hipStream_t s) {
   g_recs.push_back(r);
 }
 void prof_close(hipStream_t s) { (void)hipEventRecord(g_recs.back().e1, s); }
+// multiply-adds of the reference algorithm that a rewrite (phase planes, Winograd) did NOT execute, summed over a profiling window
+static double g_prof_saved = 0.0;
+void prof_note_saved(double flops) { if (g_prof) g_prof_saved += flops; }
 }  // namespace dfh
 
 static int fill_gemm(const dfh_gemm_desc* d, GemmArgs* g) {
@@ -81,9 +84,10 @@ extern "C" {
 int dfh_abi_version(void) { return DFH_ABI_VERSION; }
 
 int dfh_prof_begin(void) {
-  dfh::g_recs.clear(); dfh::g_pool_next = 0; dfh::g_prof = true;
+  dfh::g_recs.clear(); dfh::g_pool_next = 0; dfh::g_prof = true; dfh::g_prof_saved = 0.0;
   return 0;
 }
+double dfh_prof_saved_flops(void) { return dfh::g_prof_saved; }
 int dfh_prof_end(dfh_prof_class* out, int max_classes) {
   dfh::g_prof = false;
   DFH_REQUIRE(out != nullptr && max_classes >= dfh::PC_COUNT, "need room for every kernel class");

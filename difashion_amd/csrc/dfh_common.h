@@ -134,6 +134,7 @@ void census(int id);
 bool prof_enabled();
 void prof_open(int cls, double flops, double bytes, hipStream_t s);   // no-ops unless enabled
 void prof_close(hipStream_t s);
+void prof_note_saved(double flops);   // reference-algorithm flops a launch reports but does not execute (phase planes, Winograd)
 struct ProfScope {
   hipStream_t s; bool on;
   ProfScope(int cls, double flops, double bytes, hipStream_t st) : s(st), on(prof_enabled()) { if (on) prof_open(cls, flops, bytes, s); }

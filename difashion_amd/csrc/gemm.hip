@@ -1026,6 +1026,7 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     // algorithmic multiply-adds = the reference algorithm's: the four phase planes of an upsample conv stand for the
     // 3x3 conv over the upsampled image (9 taps per output pixel, of which the planes execute 4)
     const double flops = a.prof_flops > 0.0 ? a.prof_flops : (a.phase2x ? 9.0 / 4.0 : 1.0) * planes * 2.0 * a.M * a.N * kreal;
+    prof_note_saved(flops - planes * 2.0 * a.M * a.N * kreal);
     ProfScope ps((a.ntaps || a.prof_flops > 0.0) ? PC_CONV3 : PC_LINEAR, flops,
                  (a.phase2x ? abytes : planes * abytes) + planes * ((double)a.N * kreal * 2.0 + obytes), stream);
     const bool wide_ok0 = split == 1 && a.out2 == nullptr && a.out_mode == OUT_BF16 && (a.act != ACT_GEGLU || a.N % 160 == 0 || a.N % 128 == 0) && (a.N & 7) == 0 &&

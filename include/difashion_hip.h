@@ -45,6 +45,9 @@ typedef struct dfh_prof_class {
 } dfh_prof_class;
 int dfh_prof_begin(void);
 int dfh_prof_end(dfh_prof_class* out, int max_classes);   /* returns the number of classes written (7) */
+/* flops of the reference algorithm that the launches of the window reported but did not execute: the upsampler convs
+ * run 4 of the 9 taps (phase planes), the Winograd convs 16 multiply-adds per 2x2 outputs and channel instead of 36 */
+double dfh_prof_saved_flops(void);
 
 /* Launch census: how many times each kernel family was launched since the last reset (host-side counters bumped by the launchers).
  * Test infrastructure for "which kernels did this walk take" (tests/test_gpu_unet.py: the batch-16 forward of the bench workload). */

@@ -559,9 +559,19 @@ __global__ __launch_bounds__(256, 2) void attention_xs_kernel(const AttnArgs a, 
     for (int t = 0; t < ntiles; ++t) {
       const unsigned char* Ks = smem + t * G::BUF;
       const unsigned char* Vs = Ks + G::K_BYTES;
+      // second 32-key block of the tile entirely beyond Nk (77 text tokens: keys 96..127): its scores are the mask value, its
+      // probabilities zero -- no MFMA, no exponentials, no P.V for it (a quarter of the launch's matrix and VALU work)
+      const bool kb1 = t * KVT + 32 < a.Nk;                  // workgroup-uniform
       f32x16_t s[2][QB];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
+        if (kb == 1 && !kb1) {
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[1][qb][r] = MASK_Q;
+          continue;
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const bf16x8_t kf = *(const bf16x8_t*)(Ks + kb * 32 * KROW + k_off[ks]);
@@ -618,14 +628,17 @@ __global__ __launch_bounds__(256, 2) void attention_xs_kernel(const AttnArgs a, 
       }
       uint32_t pw[2][QB][8];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb) {
+        if (kb == 1 && !kb1) continue;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
           for (int r = 0; r < 16; r += 2)
             pw[kb][qb][r >> 1] = pack2bf(__builtin_amdgcn_exp2f(s[kb][qb][r]), __builtin_amdgcn_exp2f(s[kb][qb][r + 1]));
+      }
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb) {
+        if (kb == 1 && !kb1) continue;
 #pragma unroll
         for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
@@ -637,6 +650,7 @@ __global__ __launch_bounds__(256, 2) void attention_xs_kernel(const AttnArgs a, 
               o[db][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, __builtin_bit_cast(bf16x8_t, pv), o[db][qb], 0, 0, 0);
             }
           }
+      }
     }
     // ---- normalise and store (layout as in the streaming kernel)
 #pragma unroll

@@ -309,8 +309,10 @@ def per_launch_bound(dump_path, steps):
                 g = table.setdefault((cls, flops, nbytes), [0, 0.0]); g[0] += 1; g[1] += float(ms)
                 t_mfma = float(flops) / (MFMA_BF16_PEAK * 1e12) * 1e3
                 t_hbm = float(nbytes) / (HBM_PEAK * 1e9) * 1e3
-                r = out.setdefault(cls, dict(attainable_ms=0.0, measured_ms=0.0, hbm_bound=0, mfma_bound=0))
+                r = out.setdefault(cls, dict(attainable_ms=0.0, measured_ms=0.0, hbm_bound=0, mfma_bound=0, aux_launches=0, aux_ms=0.0))
                 r["attainable_ms"] += max(t_mfma, t_hbm); r["measured_ms"] += float(ms)
+                if float(flops) == 0.0:       # launches without multiply-adds inside a GEMM class: the Winograd transform kernels
+                    r["aux_launches"] += 1; r["aux_ms"] += float(ms)
                 r["hbm_bound" if t_hbm >= t_mfma else "mfma_bound"] += 1
         os.remove(dump_path)
     except OSError:
@@ -325,6 +327,7 @@ def per_launch_bound(dump_path, steps):
     for r in out.values():
         r["attainable_ms"] /= steps; r["measured_ms"] /= steps
         r["hbm_bound"] //= steps; r["mfma_bound"] //= steps
+        r["aux_launches"] //= steps; r["aux_ms"] /= steps
     return out
 
 
@@ -418,6 +421,8 @@ def main():
         bound = per_launch_bound(dump, K)
         gemm = {k: sum(classes[c][k] for c in ("gemm_conv3x3", "gemm_linear")) for k in ("launches", "ms", "flops", "bytes")}
         achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
+        aux_n = sum(bound.get(c, {}).get("aux_launches", 0) for c in ("gemm_conv3x3", "gemm_linear"))
+        aux_ms = sum(bound.get(c, {}).get("aux_ms", 0.0) for c in ("gemm_conv3x3", "gemm_linear"))
         # flops = the REFERENCE algorithm's; the upsampler convs (phase planes) and the Winograd convs execute fewer
         saved = float(_lib.raw().dfh_prof_saved_flops())
         executed = (gemm["flops"] - saved) / (gemm["ms"] * 1e-3) / 1e12
@@ -428,8 +433,11 @@ def main():
                         traffic=traffic, traffic_unit="HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", traffic_source=traffic_src,
                         algorithmic_bytes_per_launch=round(gemm["bytes"] / max(1, gemm["launches"])),
                         sustained_mfma_only_peak=MFMA_BF16_SUSTAINED, frac_of_sustained=round(achieved / MFMA_BF16_SUSTAINED, 4),
-                        launches_per_step=gemm["launches"] // K,
-                        avg_launch_us=round(gemm["ms"] * 1e3 / max(1, gemm["launches"]), 2),
+                        # the GEMM kernel's own launches (what rocprofv3 lists under gemm_bf16_kernel / gemm_wide_kernel): the conv class also
+                        # holds the Winograd transform launches (no multiply-adds), whose time stays inside `achieved`
+                        launches_per_step=gemm["launches"] // K - aux_n,
+                        avg_launch_us=round((gemm["ms"] * 1e3 / K - aux_ms * 1e3) / max(1, gemm["launches"] // K - aux_n), 2),
+                        transform_launches_per_step=aux_n, transform_ms_per_step=round(aux_ms, 3),
                         algorithmic_tflop_per_step=round(gemm["flops"] / K / 1e12, 3),
                         executed_tflop_per_step=round((gemm["flops"] - saved) / K / 1e12, 3),
                         executed_tflops=round(executed, 1), executed_frac=round(executed / MFMA_BF16_PEAK, 4),

@@ -988,7 +988,10 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     for (int i = 0; i < a.nplain; ++i) kk += a.p_c[i];
     const double w_bytes = (double)a.N * kk, a_bytes = (double)a.M * (a.ntaps ? (double)a.conv_c : kk);
     // measured (scripts/gemm_nmajor_probe.py): +12 % / +6 % on the 16x16-level 3x3 convs, -4 % on the linear shapes -> convs only
-    a.n_major = (force_order == 2 || (force_order < 0 && a.ntaps && w_bytes > a_bytes && a.N > 160)) ? 1 : 0;   // force_order 2 / 3 pin it (probe)
+    // batched planes (Winograd): each plane is its own weight-heavy GEMM -- same rule (DFH_BATCH_NMAJOR=0: m-major, A/B)
+    static const bool bn_off = [] { const char* e = getenv("DFH_BATCH_NMAJOR"); return e && e[0] == '0'; }();
+    const bool conv_like = a.ntaps || (a.nbatch > 1 && !bn_off);
+    a.n_major = (force_order == 2 || (force_order < 0 && conv_like && w_bytes > a_bytes && a.N > 160)) ? 1 : 0;   // force_order 2 / 3 pin it (probe)
     if (force_order == 3) a.n_major = 0;
   }
   if (a.nbatch > 1) {

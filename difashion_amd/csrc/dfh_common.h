@@ -65,7 +65,7 @@ DFH_DEVICE float erf_as_f(float x) {
 // GELU (erf form) as used by every GEGLU epilogue: 84 M gate elements per ff.net.0 launch, all on the VALU while the MFMA pipe
 // idles, so the op count is launch time.  erfc(|x|/sqrt2) = 2^P(|x|) with P a degree-6 polynomial (minimax fit of log2 erfc on
 // [0, 4 sqrt2], the 1/sqrt2 folded into the coefficients; beyond the clamp erfc < 1.6e-8): one v_exp and six FMAs, no
-// reciprocal, and gelu(x) = max(x, 0) - |x/2 * 2^P| covers both signs without a select.  |error| <= 5.5e-7 absolute over all x
+// reciprocal, and gelu(x) = max(x, 0) - |x * 2^(P - 1)| covers both signs without a select.  |error| <= 5.5e-7 absolute over all x
 // (the same as the Abramowitz-Stegun form above at |x| ~ 4, three orders below the bf16 rounding of the product) at ~10 VALU
 // slots against ~19.
 DFH_DEVICE float gelu_erf_f(float x) {
@@ -76,9 +76,67 @@ DFH_DEVICE float gelu_erf_f(float x) {
   p = fmaf(p, ax, -5.296538429e-02f);
   p = fmaf(p, ax, -4.590602584e-01f);
   p = fmaf(p, ax, -1.151122051e+00f);
-  p = fmaf(p, ax, 3.063254510e-07f);
-  const float h = 0.5f * x * __builtin_amdgcn_exp2f(p);
+  p = fmaf(p, ax, 3.063254510e-07f - 1.0f);          // - 1: the 0.5 of x / 2 * erfc rides in the exponent
+  const float h = x * __builtin_amdgcn_exp2f(p);
   return fmaxf(x, 0.0f) - fabsf(h);
+}
+
+// The same GELU on a PAIR of values with packed fp32 arithmetic (v_pk_fma_f32: two fp32 lanes per VALU slot).  The GEGLU epilogues are
+// VALU-bound (in-kernel stamps: ~22 issue slots per output element, profiles/r03/geglu_phases.txt), and left to itself hipcc either keeps
+// the Horner chain scalar (v_fmaak_f32, one slot per element and step) or packs it and re-materialises every constant pair with two
+// v_mov per use.  Here the seven coefficients sit in four register pairs and each v_pk_fma_f32 broadcasts the half it needs with
+// op_sel: three slots per element for the polynomial instead of six.  Every lane computes exactly gelu_erf_f (fma is fma).
+struct GeluK { f32x2_t k65, k43, k21, k0; };
+DFH_DEVICE GeluK gelu_consts() {
+  GeluK k;
+  k.k65 = f32x2_t{1.917432119e-05f, -6.586021110e-04f}; k.k43 = f32x2_t{7.754402186e-03f, -5.296538429e-02f};
+  k.k21 = f32x2_t{-4.590602584e-01f, -1.151122051e+00f}; k.k0 = f32x2_t{3.063254510e-07f - 1.0f, 0.0f};
+  asm volatile("" : "+v"(k.k65), "+v"(k.k43), "+v"(k.k21), "+v"(k.k0));      // live register pairs, not literals to re-materialise
+  return k;
+}
+DFH_DEVICE f32x2_t gelu_erf_f2(f32x2_t x, const GeluK& k) {
+  // min(|x|, 4 sqrt2) and max(x, 0) as ONE instruction each (fminf / fmaxf / fabsf cost a canonicalising v_max apiece through the compiler)
+  const float clampv = 5.65685424949f;
+  f32x2_t ax, rl;
+  asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(ax[0]) : "v"(x[0]), "s"(clampv));
+  asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(ax[1]) : "v"(x[1]), "s"(clampv));
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(rl[0]) : "v"(x[0]));
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(rl[1]) : "v"(x[1]));
+  f32x2_t p;
+  // p = c6 * ax + c5   (src0 = low half of k65 in both lanes, src2 = high half in both lanes)
+  asm("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(p) : "v"(k.k65), "v"(ax));
+  // p = p * ax + c   (src2 = low / high half of the pair in both lanes)
+  asm("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,1,0]" : "+v"(p) : "v"(ax), "v"(k.k43));
+  asm("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,1,1]" : "+v"(p) : "v"(ax), "v"(k.k43));
+  asm("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,1,0]" : "+v"(p) : "v"(ax), "v"(k.k21));
+  asm("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,1,1]" : "+v"(p) : "v"(ax), "v"(k.k21));
+  asm("v_pk_fma_f32 %0, %0, %1, %2 op_sel_hi:[1,1,0]" : "+v"(p) : "v"(ax), "v"(k.k0));
+  const f32x2_t e = f32x2_t{__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};
+  const f32x2_t h = x * e;
+  f32x2_t r;
+  asm("v_sub_f32_e64 %0, %1, |%2|" : "=v"(r[0]) : "v"(rl[0]), "v"(h[0]));
+  asm("v_sub_f32_e64 %0, %1, |%2|" : "=v"(r[1]) : "v"(rl[1]), "v"(h[1]));
+  return r;
+}
+// GEGLU of four (value, gate) accumulator pairs of one lane: (v + bias-or-fix-up) * gelu(g + ...) -> four bf16 in a uint2.
+//   lnf: v' = rstd * v + (ms * s + b),  ms = -mean * rstd  (folded LayerNorm, gemm.h);  else v' = v + b
+DFH_DEVICE uint2 geglu4(const f32x4_t v, const f32x4_t g, const float4 bv, const float4 bg, const float4 sv, const float4 sg, const bool lnf,
+                        const float rstd, const float ms, const GeluK& k) {
+  f32x2_t v0 = f32x2_t{v[0], v[1]}, v1 = f32x2_t{v[2], v[3]}, g0 = f32x2_t{g[0], g[1]}, g1 = f32x2_t{g[2], g[3]};
+  const f32x2_t bv0 = f32x2_t{bv.x, bv.y}, bv1 = f32x2_t{bv.z, bv.w}, bg0 = f32x2_t{bg.x, bg.y}, bg1 = f32x2_t{bg.z, bg.w};
+  if (lnf) {
+    const f32x2_t r2 = f32x2_t{rstd, rstd}, m2 = f32x2_t{ms, ms};
+    v0 = __builtin_elementwise_fma(r2, v0, __builtin_elementwise_fma(m2, f32x2_t{sv.x, sv.y}, bv0));
+    v1 = __builtin_elementwise_fma(r2, v1, __builtin_elementwise_fma(m2, f32x2_t{sv.z, sv.w}, bv1));
+    g0 = __builtin_elementwise_fma(r2, g0, __builtin_elementwise_fma(m2, f32x2_t{sg.x, sg.y}, bg0));
+    g1 = __builtin_elementwise_fma(r2, g1, __builtin_elementwise_fma(m2, f32x2_t{sg.z, sg.w}, bg1));
+  } else {
+    v0 = v0 + bv0; v1 = v1 + bv1; g0 = g0 + bg0; g1 = g1 + bg1;
+  }
+  const f32x2_t o0 = v0 * gelu_erf_f2(g0, k), o1 = v1 * gelu_erf_f2(g1, k);
+  uint2 o;
+  o.x = pack2bf(o0[0], o0[1]); o.y = pack2bf(o1[0], o1[1]);
+  return o;
 }
 
 // Value of lane (l ^ 16) / (l ^ 32): gfx950's v_permlane{16,32}_swap exchange 16- / 32-lane rows between two registers in
@@ -129,7 +187,7 @@ enum ProfClass { PC_CONV3 = 0, PC_LINEAR = 1, PC_ATTN = 2, PC_GNORM = 3, PC_LNOR
 // the batch-16 forward really took the wide tile, the producer-statistics GroupNorm and the split-K path; dfh_census_* in the C ABI)
 enum CensusId { CK_GEMM_WIDE = 0, CK_GEMM_8WAVE, CK_GEMM_LEAN, CK_GEMM_OTHER, CK_GEMM_ROW, CK_SPLITK, CK_SPLITK_FUSED, CK_GSTAT_WRITTEN,
                 CK_GN_PRE, CK_GN_STATS, CK_GN_SMALL, CK_GN_MID, CK_LAYERNORM, CK_LN_FOLDED, CK_ATTN_X32, CK_ATTN_16, CK_GEMM_FP8,
-                CK_TEXT_CACHED, CK_CONV_PHASE, CK_CONV_WINO, CK_COUNT };
+                CK_TEXT_CACHED, CK_CONV_PHASE, CK_CONV_WINO, CK_GEMM_ROWS_GEGLU, CK_COUNT };
 void census(int id);
 bool prof_enabled();
 void prof_open(int cls, double flops, double bytes, hipStream_t s);   // no-ops unless enabled

@@ -386,6 +386,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
           if (tid < BM) *(float2*)(smem + LNROWG + tid * 8) = lnmr;
           __syncthreads();
         }
+        const GeluK gk = gelu_consts();
         float4 bv[FN / 2], bg[FN / 2], sv[FN / 2], sg[FN / 2];
 #pragma unroll
         for (int jj = 0; jj < FN / 2; ++jj) {
@@ -402,20 +403,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
           const float ms = -mr.x * mr.y;                 // rstd * (acc - mean * s) + b' == rstd * acc + (b' - rstd * mean * s)
 #pragma unroll
           for (int jj = 0; jj < FN / 2; ++jj) {
-            const f32x4_t v = acc[i][2 * jj], g = acc[i][2 * jj + 1];
-            float vv[4], gg[4];
-            if (lnf) {
-              vv[0] = fmaf(mr.y, v[0], fmaf(ms, sv[jj].x, bv[jj].x)); vv[1] = fmaf(mr.y, v[1], fmaf(ms, sv[jj].y, bv[jj].y));
-              vv[2] = fmaf(mr.y, v[2], fmaf(ms, sv[jj].z, bv[jj].z)); vv[3] = fmaf(mr.y, v[3], fmaf(ms, sv[jj].w, bv[jj].w));
-              gg[0] = fmaf(mr.y, g[0], fmaf(ms, sg[jj].x, bg[jj].x)); gg[1] = fmaf(mr.y, g[1], fmaf(ms, sg[jj].y, bg[jj].y));
-              gg[2] = fmaf(mr.y, g[2], fmaf(ms, sg[jj].z, bg[jj].z)); gg[3] = fmaf(mr.y, g[3], fmaf(ms, sg[jj].w, bg[jj].w));
-            } else {
-              vv[0] = v[0] + bv[jj].x; vv[1] = v[1] + bv[jj].y; vv[2] = v[2] + bv[jj].z; vv[3] = v[3] + bv[jj].w;
-              gg[0] = g[0] + bg[jj].x; gg[1] = g[1] + bg[jj].y; gg[2] = g[2] + bg[jj].z; gg[3] = g[3] + bg[jj].w;
-            }
-            uint2 o;
-            o.x = pack2bf(vv[0] * gelu_erf_f(gg[0]), vv[1] * gelu_erf_f(gg[1]));
-            o.y = pack2bf(vv[2] * gelu_erf_f(gg[2]), vv[3] * gelu_erf_f(gg[3]));
+            const uint2 o = geglu4(acc[i][2 * jj], acc[i][2 * jj + 1], bv[jj], bg[jj], sv[jj], sg[jj], lnf, mr.y, ms, gk);
             const int ocl = ((wn * TN) >> 1) + jj * 16 + fg * 4;           // output column inside the tile
             *(uint2*)(smem + row * RSG + ocl * 2) = o;
           }
@@ -1090,7 +1078,7 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     else if (ws) rc = gemm_ws_launch(a, stream, ws);
     else
 #endif
-    if (bigg) rc = launch_big_geglu(a, stream);
+    if (bigg) rc = (force_tile == 0 && !force_bigg && gemm_geglu_rows_ok(a)) ? gemm_geglu_rows_launch(a, stream) : launch_big_geglu(a, stream);
     else if (big) rc = launch_big(a, stream);
     else if (wide) rc = gemm_wide_launch(a, stream, wide);
     else rc = launch_variant(tile, a, stream);

@@ -299,6 +299,7 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
         if (tid < BM) *(float2*)(smem + LNROWG + tid * 8) = lnmr;
         __syncthreads();
       }
+      const GeluK gk = gelu_consts();
       float4 bv[FN / 2], bg[FN / 2], sv[FN / 2], sg[FN / 2];
 #pragma unroll
       for (int jj = 0; jj < FN / 2; ++jj) {
@@ -315,22 +316,9 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
         const float ms = -mr.x * mr.y;                 // rstd * (acc - mean * s) + b' == rstd * acc + (b' - rstd * mean * s)
 #pragma unroll
         for (int jj = 0; jj < FN / 2; ++jj) {
-          const f32x4_t v = acc[i][2 * jj], g = acc[i][2 * jj + 1];
-          // value / gate with their additive constants: bias, or (folded LayerNorm) rstd * acc + (b' - rstd * mean * s): two FMAs per
-          // element instead of one add -- this epilogue is VALU-bound (exact-erf GELU), every extra instruction shows in the launch time
-          float vv[4], gg[4];
-          if (lnf) {
-            vv[0] = fmaf(mr.y, v[0], fmaf(ms, sv[jj].x, bv[jj].x)); vv[1] = fmaf(mr.y, v[1], fmaf(ms, sv[jj].y, bv[jj].y));
-            vv[2] = fmaf(mr.y, v[2], fmaf(ms, sv[jj].z, bv[jj].z)); vv[3] = fmaf(mr.y, v[3], fmaf(ms, sv[jj].w, bv[jj].w));
-            gg[0] = fmaf(mr.y, g[0], fmaf(ms, sg[jj].x, bg[jj].x)); gg[1] = fmaf(mr.y, g[1], fmaf(ms, sg[jj].y, bg[jj].y));
-            gg[2] = fmaf(mr.y, g[2], fmaf(ms, sg[jj].z, bg[jj].z)); gg[3] = fmaf(mr.y, g[3], fmaf(ms, sg[jj].w, bg[jj].w));
-          } else {
-            vv[0] = v[0] + bv[jj].x; vv[1] = v[1] + bv[jj].y; vv[2] = v[2] + bv[jj].z; vv[3] = v[3] + bv[jj].w;
-            gg[0] = g[0] + bg[jj].x; gg[1] = g[1] + bg[jj].y; gg[2] = g[2] + bg[jj].z; gg[3] = g[3] + bg[jj].w;
-          }
-          uint2 o;
-          o.x = pack2bf(vv[0] * gelu_erf_f(gg[0]), vv[1] * gelu_erf_f(gg[1]));
-          o.y = pack2bf(vv[2] * gelu_erf_f(gg[2]), vv[3] * gelu_erf_f(gg[3]));
+          // value / gate with their additive constants (bias, or the folded-LayerNorm fix-up: two FMAs per element), GELU and product on
+          // packed fp32 pairs: this epilogue is VALU-bound, every instruction shows in the launch time (dfh_common.h geglu4)
+          const uint2 o = geglu4(acc[i][2 * jj], acc[i][2 * jj + 1], bv[jj], bg[jj], sv[jj], sg[jj], lnf, mr.y, ms, gk);
           const int ocl = ((wn * TN) >> 1) + jj * 16 + fg * 4;           // output column inside the tile
           *(uint2*)(smem + row * RSG + ocl * 2) = o;
         }

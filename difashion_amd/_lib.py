@@ -164,6 +164,7 @@ SIGNATURES = {
     "dfh_prof_saved_flops": (C.c_double, []),
     "dfh_wino_input": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dfh_gn_wino_input_ok": (_i, [_i, _i, _i, _i, _i]),
+    "dfh_gn_wino_input_chain": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _i, _i, _i, _vp]),
     "dfh_gn_wino_input": (_i, [_vp, _i, _vp, _i, _vp, _vp, _f, _i, _vp, _i, _i, _i, _vp]),
     "dfh_conv3x3_wino_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "dfh_conv3x3_wino": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),

@@ -379,6 +379,12 @@ int dfh_gn_wino_input(const void* src0, int c0, const void* src1, int c1, const 
   return dfh::gn_wino_input_launch((const bf16_t*)src0, c0, (const bf16_t*)src1, c1, gamma, beta, eps, groups, (bf16_t*)V, batch, H, W,
                                    (hipStream_t)stream);
 }
+int dfh_gn_wino_input_chain(const void* Mprev, const float* pbias, const float* prowvec, int prv_ld, int prv_off, int C, const float* gamma,
+                            const float* beta, float eps, int groups, void* V, int batch, int H, int W, void* stream) {
+  DFH_REQUIRE(Mprev != nullptr, "null argument");
+  return dfh::gn_wino_input_launch((const bf16_t*)Mprev, C, nullptr, 0, gamma, beta, eps, groups, (bf16_t*)V, batch, H, W, (hipStream_t)stream,
+                                   (const bf16_t*)Mprev, pbias, prowvec, prv_ld, prv_off);
+}
 size_t dfh_conv3x3_wino_scratch_bytes(int batch, int H, int W, int C, int N) {
   if (batch <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return 0;
   const size_t mt = (size_t)batch * (H / 2) * (W / 2);

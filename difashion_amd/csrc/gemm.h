@@ -132,8 +132,11 @@ bool wino_blocked(int N, int C);
 int wino_input_launch(const bf16_t* g, bf16_t* V, int B, int H, int W, int C, hipStream_t stream);
 // GroupNorm(+SiLU) fused with the input transform: V = B^T silu(GN(concat(src0, src1))) B (gn_wino_ok: is the shape supported?)
 bool gn_wino_ok(int C0, int C1, int G, int H, int W);
+// Mprev != null (conv1 -> conv2 of a resnet): the normalised tensor is the output transform of the previous conv's transform-domain planes
+// Mprev [16][B H W / 4][C0] (+ pbias + the image's row of prowvec), rebuilt inside the kernel: src0 is not read
 int gn_wino_input_launch(const bf16_t* src0, int C0, const bf16_t* src1, int C1, const float* gamma, const float* beta, float eps, int G,
-                         bf16_t* V, int B, int H, int W, hipStream_t stream);
+                         bf16_t* V, int B, int H, int W, hipStream_t stream, const bf16_t* Mprev = nullptr, const float* pbias = nullptr,
+                         const float* prowvec = nullptr, int prv_ld = 0, int prv_off = 0);
 int wino_output_launch(const bf16_t* Mb, bf16_t* out, const float* bias, const float* rowvec, int rv_ld, int rv_off, const bf16_t* resid,
                        int B, int H, int W, int N, hipStream_t stream);
 // persistent GEGLU projection kernel (gemm_geglu.hip): one workgroup per CU walks 256 x 256 tiles and fetches the next tile's first stage

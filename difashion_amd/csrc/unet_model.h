@@ -618,27 +618,39 @@ struct dfh_unet {
 
     // stride-1 3x3 conv by Winograd F(2x2, 3x3) (winograd.hip): input transform, ONE batched GEMM over the sixteen transform-domain
     // planes, output transform with the epilogue (bias, time-embedding row, residual).  The scratch is planned by the dry run too.
-    // nw / nb: the GroupNorm(+SiLU) in front of the conv runs inside the input transform (x, x1 = its raw, possibly concatenated input;
-    // winograd.hip gn_wino_input_kernel); null: x is the already normalised tensor
-    void wino_conv(const Tensor& x, const Tensor* x1, const Vec* nw, const Vec* nb, size_t uoff, int cout, const Vec& bias, const float* rowvec,
-                   int rv_off, const bf16_t* resid, Tensor& o) {
+    // Winograd F(2x2, 3x3) conv in three stages (winograd.hip); the scratch (V, M) is planned by the dry run too.
+    //   wino_in   : V = B^T d B of the conv's input.  nw / nb: the GroupNorm(+SiLU) in front of the conv runs inside the transform (x, x1 = its
+    //               raw, possibly concatenated input); Mprev: that input is the output transform of the PREVIOUS conv's planes (+ pbias + temb row),
+    //               rebuilt inside the kernel (conv1 -> conv2 of a resnet); neither: x is the already normalised tensor
+    //   wino_gemm : ONE batched GEMM over the sixteen transform-domain planes
+    //   wino_out  : A^T m A + bias (+ time-embedding row) (+ residual)
+    bf16_t* wino_in(const Tensor& x, const Tensor* x1, const Vec* nw, const Vec* nb, const bf16_t* Mprev = nullptr, const Vec* pbias = nullptr,
+                    const float* prowvec = nullptr, int prv_off = 0) {
       const int C = x.C + (x1 ? x1->C : 0);
       const long mt = (long)B * (x.H / 2) * (x.W / 2);
       bf16_t* V = (bf16_t*)temp.alloc((size_t)16 * mt * C * 2);
-      bf16_t* Mb = (bf16_t*)temp.alloc((size_t)16 * mt * cout * 2);
-      if (rc || dry) return;
+      if (rc || dry) return V;
       if (nw) rc = dfh::gn_wino_input_launch(x.p, x.C, x1 ? x1->p : nullptr, x1 ? x1->C : 0, v32(*nw), v32(*nb), u->cfg.norm_eps,
-                                             u->cfg.norm_num_groups, V, B, x.H, x.W, s);
+                                             u->cfg.norm_num_groups, V, B, x.H, x.W, s, Mprev, pbias ? v32(*pbias) : nullptr, prowvec, temb_ld, prv_off);
       else rc = dfh::wino_input_launch(x.p, V, B, x.H, x.W, C, s);
-      if (rc) return;
+      return V;
+    }
+    bf16_t* wino_gemm(const bf16_t* V, int H, int W, int C, size_t uoff, int cout) {
+      const long mt = (long)B * (H / 2) * (W / 2);
+      bf16_t* Mb = (bf16_t*)temp.alloc((size_t)16 * mt * cout * 2);
+      if (rc || dry) return Mb;
       GemmArgs g = base((int)mt, cout);
       g.p_src[0] = V; g.p_c[0] = C; g.nplain = 1; g.W = u->fold_w() + uoff; g.ldw = C;
       g.nbatch = 16; g.a_bs = mt * C; g.w_bs = (long)cout * C; g.o_bs = mt * cout; g.w_blocked = dfh::wino_blocked(cout, C);
       g.out = Mb; g.zero = zero;
-      g.prof_flops = 2.0 * B * x.H * x.W * (double)cout * 9.0 * C;
-      if ((rc = dfh::gemm_launch(g, s, dfh::wino_gemm_tile(g), 0, -1))) return;
-      rc = dfh::wino_output_launch(Mb, o.p, v32(bias), rowvec, temb_ld, rv_off, resid, B, x.H, x.W, cout, s);
+      g.prof_flops = 2.0 * B * H * W * (double)cout * 9.0 * C;
+      rc = dfh::gemm_launch(g, s, dfh::wino_gemm_tile(g), 0, -1);
       dfh::census(dfh::CK_CONV_WINO);
+      return Mb;
+    }
+    void wino_out(const bf16_t* Mb, const Vec& bias, const float* rowvec, int rv_off, const bf16_t* resid, Tensor& o) {
+      if (rc || dry) return;
+      rc = dfh::wino_output_launch(Mb, o.p, v32(bias), rowvec, temb_ld, rv_off, resid, B, o.H, o.W, o.C, s);
     }
 
     Tensor resnet(const Tensor& x0, const Tensor* x1, const ResL& r, const float* temb_all) {
@@ -655,14 +667,29 @@ struct dfh_unet {
         // (DFH_WINO_GN=0: separate GroupNorm launches, A/B)
         static const bool gn_off = [] { const char* e = getenv("DFH_WINO_GN"); return e && e[0] == '0'; }();
         const int G = u->cfg.norm_num_groups;
-        if (!gn_off && dfh::gn_wino_ok(x0.C, x1 ? x1->C : 0, G, H, W)) wino_conv(x0, x1, &r.n1w, &r.n1b, r.u1, r.cout, r.b1, temb_all, r.temb_off, nullptr, h1);
+        // conv1 -> conv2: the tensor between them (conv1's output, GroupNorm 2's input) is rebuilt from conv1's transform-domain planes
+        // inside conv2's input transform -- no output-transform launch, no round trip (DFH_WINO_CHAIN=0: materialise it, A/B)
+        static const bool chain_off = [] { const char* e = getenv("DFH_WINO_CHAIN"); return e && e[0] == '0'; }();
+        const bf16_t* V1;
+        if (!gn_off && dfh::gn_wino_ok(x0.C, x1 ? x1->C : 0, G, H, W)) V1 = wino_in(x0, x1, &r.n1w, &r.n1b);
         else {
           groupnorm(x0, x1, r.n1w, r.n1b, u->cfg.norm_eps, 1, g1);
-          wino_conv(g1, nullptr, nullptr, nullptr, r.u1, r.cout, r.b1, temb_all, r.temb_off, nullptr, h1);
+          V1 = wino_in(g1, nullptr, nullptr, nullptr);
         }
-        Tensor g2 = talloc(H, W, r.cout);
+        const bf16_t* M1 = wino_gemm(V1, H, W, r.cin, r.u1, r.cout);
         const bool gn2 = !gn_off && dfh::gn_wino_ok(r.cout, 0, G, H, W);
-        if (!gn2) groupnorm(h1, nullptr, r.n2w, r.n2b, u->cfg.norm_eps, 1, g2);
+        const bool chain = gn2 && !chain_off;
+        Tensor g2 = talloc(H, W, r.cout);
+        const bf16_t* V2;
+        if (chain) V2 = wino_in(h1, nullptr, &r.n2w, &r.n2b, M1, &r.b1, temb_all, r.temb_off);     // h1 only names the shape: it is never written
+        else {
+          wino_out(M1, r.b1, temb_all, r.temb_off, nullptr, h1);
+          if (gn2) V2 = wino_in(h1, nullptr, &r.n2w, &r.n2b);
+          else {
+            groupnorm(h1, nullptr, r.n2w, r.n2b, u->cfg.norm_eps, 1, g2);
+            V2 = wino_in(g2, nullptr, nullptr, nullptr);
+          }
+        }
         const bf16_t* resid = x0.p;
         if (r.shortcut) {      // the 1x1 shortcut over the (possibly concatenated) block input: its own GEMM, added by the output transform
           Tensor sc = talloc(H, W, r.cout);
@@ -674,8 +701,8 @@ struct dfh_unet {
           gemm(g);
           resid = sc.p;
         }
-        if (gn2) wino_conv(h1, nullptr, &r.n2w, &r.n2b, r.u2, r.cout, r.b2, nullptr, 0, resid, out);
-        else wino_conv(g2, nullptr, nullptr, nullptr, r.u2, r.cout, r.b2, nullptr, 0, resid, out);
+        const bf16_t* M2 = wino_gemm(V2, H, W, r.cout, r.u2, r.cout);
+        wino_out(M2, r.b2, nullptr, 0, resid, out);
         temp.off = mark;
         return out;
       }

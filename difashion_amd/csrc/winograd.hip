@@ -110,6 +110,10 @@ struct GnWinoArgs {
   const bf16_t* src0; const bf16_t* src1; int C0, C1;   // [B][HW][C0], [B][HW][C1]
   const float* gamma; const float* beta; float eps;
   bf16_t* V; int B, H, W, G;
+  // conv1 -> conv2 inside a resnet: the slab is not read from a tensor but rebuilt from the PREVIOUS conv's transform-domain output
+  // Mprev [16][B H W / 4][C0] (its output transform A^T m A + bias + time-embedding row, rounded to bf16 as the stored tensor would be):
+  // no output-transform launch, no round trip of the tensor between the two convs
+  const bf16_t* Mprev; const float* pbias; const float* prowvec; int prv_ld, prv_off;
 };
 
 __global__ __launch_bounds__(256) void gn_wino_input_kernel(const GnWinoArgs a) {
@@ -123,6 +127,50 @@ __global__ __launch_bounds__(256) void gn_wino_input_kernel(const GnWinoArgs a) 
   if (tid < cpg) { gam_s[tid] = a.gamma[cg + tid]; bet_s[tid] = a.beta[cg + tid]; }
   // ---- pass 1: global -> LDS (raw bf16), sum
   float s = 0.f;
+  if (a.Mprev) {
+    // one item = one 2x2 output tile x one 4-channel unit of the previous conv: A^T m A + bias (+ time-embedding row), as wino_output_kernel
+    const int TWp = a.W >> 1, tilesp = (a.H >> 1) * TWp;
+    const long Mtp = (long)a.B * tilesp;
+    for (int idx = tid; idx < tilesp * upp; idx += 256) {
+      const int t = idx / upp, j = idx - t * upp, c = cg + j * 4;
+      const int ty = t / TWp, tx = t - ty * TWp;
+      float sm[2][4][4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        float m[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint2 r = *(const uint2*)(a.Mprev + ((long)(i * 4 + jj) * Mtp + (long)b * tilesp + t) * a.C0 + c);
+          m[i][0] = __uint_as_float(r.x << 16); m[i][1] = __uint_as_float(r.x & 0xffff0000u);
+          m[i][2] = __uint_as_float(r.y << 16); m[i][3] = __uint_as_float(r.y & 0xffff0000u);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sm[0][jj][e] = m[0][e] + m[1][e] + m[2][e];
+          sm[1][jj][e] = m[1][e] - m[2][e] - m[3][e];
+        }
+      }
+      float4 add = *(const float4*)(a.pbias + c);
+      if (a.prowvec) {
+        const float4 rv = *(const float4*)(a.prowvec + (long)b * a.prv_ld + a.prv_off + c);
+        add.x += rv.x; add.y += rv.y; add.z += rv.z; add.w += rv.w;
+      }
+      const float ad[4] = {add.x, add.y, add.z, add.w};
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          float y[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            y[e] = (jj == 0 ? sm[i][0][e] + sm[i][1][e] + sm[i][2][e] : sm[i][1][e] - sm[i][2][e] - sm[i][3][e]) + ad[e];
+          uint2 r; r.x = pack2bf(y[0], y[1]); r.y = pack2bf(y[2], y[3]);
+          const int p = (2 * ty + i) * a.W + 2 * tx + jj;
+          *(uint2*)(smem + p * RS + j * 8) = r;
+          s += (__uint_as_float(r.x << 16) + __uint_as_float(r.x & 0xffff0000u)) + (__uint_as_float(r.y << 16) + __uint_as_float(r.y & 0xffff0000u));
+        }
+    }
+  } else
   for (int idx = tid; idx < total; idx += 256) {
     const int p = idx / upp, j = idx - p * upp, c = cg + j * 4;
     const uint2 r = c < a.C0 ? *(const uint2*)(a.src0 + ((long)b * HW + p) * a.C0 + c)
@@ -291,11 +339,14 @@ bool gn_wino_ok(int C0, int C1, int G, int H, int W) {
 }
 
 int gn_wino_input_launch(const bf16_t* src0, int C0, const bf16_t* src1, int C1, const float* gamma, const float* beta, float eps, int G,
-                         bf16_t* V, int B, int H, int W, hipStream_t stream) {
-  DFH_REQUIRE(src0 && gamma && beta && V && (C1 == 0 || src1), "null pointer");
+                         bf16_t* V, int B, int H, int W, hipStream_t stream, const bf16_t* Mprev, const float* pbias, const float* prowvec,
+                         int prv_ld, int prv_off) {
+  DFH_REQUIRE((src0 || Mprev) && gamma && beta && V && (C1 == 0 || src1), "null pointer");
+  DFH_REQUIRE(!Mprev || (pbias && C1 == 0), "chained form: the previous conv's bias, one source");
   DFH_REQUIRE(gn_wino_ok(C0, C1, G, H, W), "shape not supported by the fused GroupNorm + input transform (gn_wino_ok)");
   GnWinoArgs a; a.src0 = src0; a.src1 = src1; a.C0 = C0; a.C1 = C1; a.gamma = gamma; a.beta = beta; a.eps = eps; a.V = V;
   a.B = B; a.H = H; a.W = W; a.G = G;
+  a.Mprev = Mprev; a.pbias = pbias; a.prowvec = prowvec; a.prv_ld = prv_ld; a.prv_off = prv_off;
   const int C = C0 + C1;
   const size_t lds = (size_t)H * W * ((C / G) * 2 + 8);
   static size_t lds_set = 0;

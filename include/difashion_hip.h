@@ -285,6 +285,11 @@ int dfh_wino_input(const void* src, void* V, int batch, int H, int W, int C, voi
 int dfh_gn_wino_input_ok(int c0, int c1, int groups, int H, int W);
 int dfh_gn_wino_input(const void* src0, int c0, const void* src1, int c1, const float* gamma, const float* beta, float eps, int groups,
                       void* V, int batch, int H, int W, void* stream);
+/* conv1 -> conv2 of a ResnetBlock2D: the tensor between the two convs is rebuilt from conv1's transform-domain planes Mprev [16][batch H W / 4][C]
+ * (A^T m A + pbias + the image's row prowvec[b * prv_ld + prv_off + c], rounded to bf16 as the stored tensor would be) inside conv2's
+ * GroupNorm + input transform: no output-transform launch, no round trip of that tensor */
+int dfh_gn_wino_input_chain(const void* Mprev, const float* pbias, const float* prowvec, int prv_ld, int prv_off, int C, const float* gamma,
+                            const float* beta, float eps, int groups, void* V, int batch, int H, int W, void* stream);
 /* 1 when the library stores U of an N x C conv in 16-row x 64-column blocks ([16][N / 16][C / 64][16][64]: every 2-KB DRAM burst of the
  * weight stream is used whole); pass the same value as `blocked` / `u_blocked` */
 int dfh_wino_blocked(int N, int C);

@@ -395,6 +395,30 @@ def test_groupnorm_silu_fused_into_the_winograd_input_transform(B, C0, C1, H, W)
     assert gu.rel_err(Vf.float(), Vref) <= 2e-3
 
 
+@pytest.mark.parametrize("B,C,H,W,temb", [(2, 1280, 16, 16, True), (16, 1280, 8, 8, True), (3, 640, 8, 8, False), (2, 128, 4, 6, True)])
+def test_winograd_chain_rebuilds_the_tensor_between_two_convs(B, C, H, W, temb):
+    """dfh_gn_wino_input_chain: V2 from conv1's transform-domain planes (output transform + bias + time-embedding row, GroupNorm + SiLU,
+    input transform in one launch) against the materialised path (torch output transform rounded to bf16 -> dfh_gn_wino_input)."""
+    G = 32
+    mt = B * (H // 2) * (W // 2)
+    Mp = bf(rnd(16, mt, C, seed=70))
+    bias = rnd(C, seed=71)
+    rv = rnd(B, 2 * C, seed=72) if temb else None
+    gamma = 1.0 + 0.1 * rnd(C, seed=73); beta = 0.1 * rnd(C, seed=74)
+    Vc = torch.empty(16, mt, C, dtype=torch.bfloat16, device=gu.DEV)
+    _lib.call("dfh_gn_wino_input_chain", _lib.ptr(Mp), _lib.ptr(bias), _lib.ptr(rv) if temb else None, 2 * C if temb else 0, C if temb else 0, C,
+              _lib.ptr(gamma), _lib.ptr(beta), 1e-5, G, _lib.ptr(Vc), B, H, W, gu.stream())
+    AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1.]], device=gu.DEV)
+    m = Mp.float().view(4, 4, B, H // 2, W // 2, C)
+    y = torch.einsum("ij,jkbyxc,lk->byixlc", AT, m, AT).reshape(B, H, W, C) + bias          # [b][2 ty + i][2 tx + l][c]
+    if temb:
+        y = y + rv[:, C:2 * C][:, None, None, :]
+    h1 = bf(y)
+    Vm = torch.empty_like(Vc)
+    _lib.call("dfh_gn_wino_input", _lib.ptr(h1), C, None, 0, _lib.ptr(gamma), _lib.ptr(beta), 1e-5, G, _lib.ptr(Vm), B, H, W, gu.stream())
+    assert gu.rel_err(Vc.float(), Vm.float()) <= 2e-3
+
+
 @pytest.mark.parametrize("nb,M,N,K,tile", [(16, 1024, 1280, 1280, 0), (4, 300, 160, 64, 0), (3, 128, 128, 192, 5), (16, 256, 320, 320, 10)])
 def test_gemm_batched_planes_in_one_launch(nb, M, N, K, tile):
     """grid.y planes of independent GEMMs (dfh_gemm_batched) equal nb separate launches bit for bit."""

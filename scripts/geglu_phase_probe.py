@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a tile of the GEGLU projection spends its time: DFH_GEGLU_PROF=1 makes the persistent kernel (csrc/gemm_geglu.hip) stamp
 s_memtime at its phase boundaries (workgroup 0, thread 0) and print per-phase cycle averages.  GPU only.
-    DFH_GEGLU_PROF=1 python scripts/geglu_phase_probe.py"""
+    DFH_GEGLU_ROWS=1 DFH_GEGLU_PROF=1 python scripts/geglu_phase_probe.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scripts.gemm_microbench import run

@@ -974,7 +974,7 @@ int wino_gemm_tile(const GemmArgs& a) {
 }
 
 // Batched launches (Winograd planes, phase planes of an upsample conv) for the 256 x 320 eight-wave tile: planes of at least 512 rows whose
-// tiles together make whole rounds of the CUs (16x16 level Winograd: 16 x 16 = 256 tiles, 78.7 -> us with the 128 x 160 tile).
+// tiles together make whole rounds of the CUs (16x16-level Winograd: 16 planes x 16 tiles = 256 workgroups, 78.7 us on the 128 x 160 tile -> 67.1 us).
 // DFH_BATCH_BIG=0 turns it off (A/B).
 static bool batched_big_pick(const GemmArgs& a) {
   static const bool off = [] { const char* e = getenv("DFH_BATCH_BIG"); return e && e[0] == '0'; }();

@@ -2,7 +2,9 @@
 """Headline benchmark (BASELINE.json): U-Net denoise steps/sec for a 4-item outfit at 64x64x4 latents.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1: either under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...: RANK /
+  WORLD_SIZE come from the environment) or plainly as `python bench.py --gpus N`: the process then starts N ranks of itself
+  (launch_ranks), one per GPU, and relays rank 0's line.
 
 One "step" = everything one iteration of DiFashion.fashion_generation's loop does for one outfit
 (DiFashion/models/difashion.py:456-577) at BASELINE.json configs[1]: sibling reduce + MutualEncoder MLP
@@ -180,7 +182,8 @@ def run_train(args, da, _lib, ddist, rank, world, dev):
            "loss": round(float(loss), 5), "hbm_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
            # time per step the compute stream waited for the side-stream gradient exchange = the part of the exchange the backward
            # walk did not hide (max over ranks; null on one GPU: no exchange)
-           "comm_exposed_ms": None if comm_exposed_ms is None else round(comm_exposed_ms, 3), "grad_wire": args.wire}
+           "comm_exposed_ms": None if comm_exposed_ms is None else round(comm_exposed_ms, 3), "grad_wire": args.wire,
+           "rccl_ranks": args.ranks_seen if args.backend in (None, "nccl") else None, "collective_backend": args.backend}
     if classes is not None:
         tot_f = sum(v["flops"] for v in classes.values())
         out["kernel_classes"] = {c: dict(launches_per_step=v["launches"] // K, ms_per_step=round(v["ms"] / K, 3),
@@ -341,6 +344,48 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher environment: start N child processes of this same script, one rank per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set the way `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` sets them),
+    relay rank 0's single JSON line on stdout and return non-zero when any rank fails.  The parent itself never initialises the GPU
+    (children are fresh processes: no exec of a process that has touched HIP)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                      # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile("w+") as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # a rank that dies leaves the others waiting in a collective: the first non-zero exit ends the whole job
+        bad = []
+        while not bad and any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad:
+            log(f"[bench] ranks failed (rank, exit code): {bad}")
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for p in procs:
+                p.wait()
+            return 1
+        out0.seek(0)
+        text = out0.read()
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    if len(lines) != 1:
+        log(f"[bench] rank 0 printed {len(lines)} JSON lines, expected exactly one")
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -359,6 +404,11 @@ def main():
                     help="fp8: BASELINE configs[4] -- the LayerNorm-fed transformer projections in e4m3 on the block-scaled MFMA")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  Nothing here has touched the GPU yet (no HIP call, no
+        # torch.cuda.is_available()), and it never will: it starts N fresh ranks and relays rank 0's line.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import difashion_amd as da
     from difashion_amd import _lib, dist as ddist
 
@@ -375,6 +425,12 @@ def main():
         local = local_dev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # one all-reduce of ones over the job's process group before anything is timed: the number of ranks the collective backend really
+    # connected (RCCL over xGMI under "nccl"); it goes into the line as rccl_ranks
+    args.ranks_seen = int(round(ddist.sum_over_ranks(1.0))) if world > 1 else 1
+    args.backend = backend if world > 1 else None
+    if args.ranks_seen != world:
+        raise SystemExit(f"bench.py: the all-reduce saw {args.ranks_seen} ranks, WORLD_SIZE is {world}")
 
     if args.mode == "train":
         return run_train(args, da, _lib, ddist, rank, world, dev)
@@ -488,6 +544,8 @@ def main():
                                f"{args.config} shape in_channels=8, 64x64x4 latents, 77 text tokens; one outfit per GPU",
                    "unet_batch": 16, "latent": "64x64x4", "parallelism": f"outfit-replicas x{world} (no data-path collective)"},
         "roofline": roofline,
+        # ranks counted by an all-reduce of ones on the job's process group (RCCL when the backend is "nccl"; null under the gloo test backend)
+        "rccl_ranks": args.ranks_seen if args.backend in (None, "nccl") else None, "collective_backend": args.backend,
     }
     if classes is not None:
         def rate(c, key, scale):

@@ -194,6 +194,7 @@ _NO_STATUS = {"dfh_abi_version", "dfh_census_count", "dfh_unet_num_params", "dfh
               "dfh_vae_param_ndim", "dfh_vae_param_dim"}
 
 _lib = None
+ABI_VERSION = 4          # == DFH_ABI_VERSION of include/difashion_hip.h (checked when the library is loaded)
 
 
 def build(force: bool = False) -> str:
@@ -219,6 +220,10 @@ def raw():
             fn = getattr(lib, name)       # AttributeError here = header/library drift
             fn.restype = res
             fn.argtypes = args
+        got = lib.dfh_abi_version()
+        if got != ABI_VERSION:
+            raise DfhError(f"{LIB_PATH} reports ABI {got}, this Python side binds ABI {ABI_VERSION} (include/difashion_hip.h "
+                           "DFH_ABI_VERSION): rebuild the library (`python -c 'import __graft_entry__ as g; g.build()'`)")
         _lib = lib
     return _lib
 

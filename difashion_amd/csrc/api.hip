@@ -116,7 +116,9 @@ int dfh_census_count(void) { return dfh::CK_COUNT; }
 const char* dfh_census_name(int i) { return (i >= 0 && i < dfh::CK_COUNT) ? dfh::kCensusNames[i] : ""; }
 long dfh_census_get(int i) { return (i >= 0 && i < dfh::CK_COUNT) ? dfh::g_census[i] : -1; }
 const char* dfh_last_error(void) { return dfh::g_err.c_str(); }
-const char* dfh_build_info(void) { return "libdifashion_hip gfx950 (CDNA4) bf16-MFMA abi=1"; }
+#define DFH_STR2(x) #x
+#define DFH_STR(x) DFH_STR2(x)
+const char* dfh_build_info(void) { return "libdifashion_hip gfx950 (CDNA4) bf16/fp8-MFMA abi=" DFH_STR(DFH_ABI_VERSION); }
 
 size_t dfh_gemm_partial_floats(const dfh_gemm_desc* d) {
   GemmArgs g;

@@ -139,10 +139,6 @@ int gn_wino_input_launch(const bf16_t* src0, int C0, const bf16_t* src1, int C1,
                          const float* prowvec = nullptr, int prv_ld = 0, int prv_off = 0);
 int wino_output_launch(const bf16_t* Mb, bf16_t* out, const float* bias, const float* rowvec, int rv_ld, int rv_off, const bf16_t* resid,
                        int B, int H, int W, int N, hipStream_t stream);
-// persistent GEGLU projection kernel (gemm_geglu.hip): one workgroup per CU walks 256 x 256 tiles and fetches the next tile's first stage
-// during the current tile's epilogue; same arithmetic as gemm_bf16_kernel<256,256,2,4,2,LEAN,WEPI> (bit-identical)
-bool gemm_geglu_rows_ok(const GemmArgs& a);
-int gemm_geglu_rows_launch(const GemmArgs& a, hipStream_t stream);
 // tile id (gemm_launch force_tile) for the batched transform-domain GEMM: the 256-row ring when a plane has at most 256 rows (its
 // weights are then read by ONE row tile), else 0 = the batched default (eight-wave 128 x 160)
 int wino_gemm_tile(const GemmArgs& a);
@@ -166,5 +162,10 @@ bool gemm_halo_eligible(const GemmArgs& a);                  // gemm_halo.hip: 3
 int gemm_halo_launch(GemmArgs a, hipStream_t stream);
 int gemm_ws_pick(const GemmArgs& a, int min_tiles);           // 0 = not eligible, else the column tile (160 / 128)
 int gemm_ws_launch(GemmArgs a, hipStream_t stream, int bn);
+// persistent GEGLU projection kernel (scripts/probes/kernels/gemm_geglu.hip): one workgroup per CU walks 256 x 256 tiles and fetches the
+// next tile's first stage during the current tile's epilogue; bit-identical to gemm_bf16_kernel<256,256,2,4,2,LEAN,WEPI>, measured equal
+// inside the step (profiles/r03/geglu_phases.txt)
+bool gemm_geglu_rows_ok(const GemmArgs& a);
+int gemm_geglu_rows_launch(const GemmArgs& a, hipStream_t stream);
 #endif
 }  // namespace dfh

@@ -232,63 +232,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
       }
     }
   }
-#ifdef DFH_LEAN_BUF
-  // Probe (-DDFH_LEAN_BUF): the LEAN staging through buffer_load_dwordx4 ... lds -- one resource descriptor per operand in SGPRs, a 32-bit
-  // byte offset per piece fixed for the kernel (rows beyond M / N: an offset beyond num_records, the hardware returns zeros) and the
-  // k-step's byte offset in ONE SGPR: no 64-bit pointer bump per piece and k-step.
-  unsigned bo_a[IA], bo_w[IB];
-  unsigned bso_a = 0, bso_w = 0;                     // soffset (bytes) of the next k-step to issue
-  const unsigned a_bytes0 = (unsigned)((size_t)a.M * (unsigned)a.p_c[0] * 2u), a_bytes1 = a.nplain == 2 ? (unsigned)((size_t)a.M * (unsigned)a.p_c[1] * 2u) : 0u;
-  const auto rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)psrc0, 0, (int)a_bytes0, 0x00020000);
-  const auto rs_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)psrc1, 0, (int)a_bytes1, 0x00020000);
-  const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, (int)((size_t)a.N * (unsigned)a.ldw * 2u), 0x00020000);
-  bool buf_seg1 = false;
-  if (LEAN) {
-    const int steps0 = a.p_c[0] / BK;
-    const bool in0 = ks_begin < steps0 || a.nplain < 2;
-    buf_seg1 = !in0;
-    bso_a = (unsigned)(in0 ? ks_begin : ks_begin - steps0) * (BK * 2);
-    bso_w = a.w_blocked ? (unsigned)ks_begin * 2048u : (unsigned)ks_begin * (BK * 2);
-#pragma unroll
-    for (int i = 0; i < IA; ++i)
-      bo_a[i] = a_pix[i] >= 0 ? (unsigned)a_pix[i] * (unsigned)(in0 ? a.p_c[0] : a.p_c[1]) * 2u + (unsigned)sslot * 16u : 0xfffffff0u;
-#pragma unroll
-    for (int i = 0; i < IB; ++i) {
-      const int n = n0 + (i * NWV + wave) * 8 + srow;
-      bo_w[i] = w_row[i] < 0 ? 0xfffffff0u
-              : (a.w_blocked ? ((unsigned)(n >> 4) * (unsigned)(a.ldw >> 6)) * 2048u + (unsigned)((n & 15) * 128 + sslot * 16)
-                             : (unsigned)w_row[i] * 2u + (unsigned)sslot * 16u);
-    }
-  }
-  auto bglds = [&](decltype(rs_w) rs, unsigned voff, unsigned soff, unsigned char* dst) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff,
-                                             __builtin_amdgcn_readfirstlane(soff), 0, 0);
-  };
-  auto issue_lean = [&](int buf) {
-    unsigned char* As = smem + buf * STAGE + wave * 1024;
-    unsigned char* Bs = As + A_BYTES;
-    if (lean_left == 0) {                            // block-uniform: the second segment starts here
-#pragma unroll
-      for (int i = 0; i < IA; ++i) bo_a[i] = a_pix[i] >= 0 ? (unsigned)a_pix[i] * (unsigned)a.p_c[1] * 2u + (unsigned)sslot * 16u : 0xfffffff0u;
-      bso_a = 0; buf_seg1 = true;
-      lean_left = 0x7fffffff;
-    }
-    --lean_left;
-    if (buf_seg1) {
-#pragma unroll
-      for (int i = 0; i < IA; ++i) bglds(rs_a1, bo_a[i], bso_a, As + i * NWV * 1024);
-    } else {
-#pragma unroll
-      for (int i = 0; i < IA; ++i) bglds(rs_a0, bo_a[i], bso_a, As + i * NWV * 1024);
-    }
-#pragma unroll
-    for (int i = 0; i < IB; ++i) {
-      if (i * NWV + wave >= PB) continue;             // wave-uniform
-      bglds(rs_w, bo_w[i], bso_w, Bs + i * NWV * 1024);
-    }
-    bso_a += BK * 2; bso_w += a.w_blocked ? 2048u : (unsigned)(BK * 2);
-  };
-#else
   auto issue_lean = [&](int buf) {
     unsigned char* As = smem + buf * STAGE + wave * 1024;
     unsigned char* Bs = As + A_BYTES;
@@ -307,7 +250,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
       glds(lp_w[i], Bs + i * NWV * 1024); lp_w[i] += ls_w[i];
     }
   };
-#endif
 
   f32x4_t acc[FM][FN];
 #pragma unroll
@@ -1135,8 +1077,10 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     if (halo) rc = gemm_halo_launch(a, stream);
     else if (ws) rc = gemm_ws_launch(a, stream, ws);
     else
+    if (bigg && force_tile == 0 && !force_bigg && gemm_geglu_rows_ok(a)) rc = gemm_geglu_rows_launch(a, stream);   // opt-in DFH_GEGLU_ROWS=1
+    else
 #endif
-    if (bigg) rc = (force_tile == 0 && !force_bigg && gemm_geglu_rows_ok(a)) ? gemm_geglu_rows_launch(a, stream) : launch_big_geglu(a, stream);
+    if (bigg) rc = launch_big_geglu(a, stream);
     else if (big) rc = launch_big(a, stream);
     else if (wide) rc = gemm_wide_launch(a, stream, wide);
     else rc = launch_variant(tile, a, stream);

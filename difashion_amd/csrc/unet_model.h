@@ -432,8 +432,10 @@ struct dfh_unet {
   int fold_layernorms(hipStream_t s) {
     fold_valid = false;
     if (!ws || !arena16 || !arena32) return 0;
+    // a transformer width the 16-byte kernels cannot take (C % 8 != 0) has no folded weights: the walk must not read its (unwritten)
+    // fold slots, so the whole inference walk then stays on the unfolded path (fold_valid stays false)
+    for (AttL* a : all_att()) if (a->C % 8) return 0;
     for (AttL* a : all_att()) {
-      if (a->C % 8) continue;
       const Mat* src[4] = {&a->qk, &a->v, &a->q2, &a->ff1};
       const Fold* dst[4] = {&a->fqk, &a->fv, &a->fq2, &a->fff1};
       const Vec* gam[4] = {&a->l1w, &a->l1w, &a->l2w, &a->l3w};

@@ -100,13 +100,30 @@ class Bf16Exchange:
 
     @classmethod
     def for_range(cls, n: int, device, world: int, capacity: int = 0) -> "Bf16Exchange":
-        key = (str(device), world)
+        # one set of buffers per (device, world, STREAM): the exchange inside the backward runs on a side stream, the flat exchange of
+        # the non-overlapped path on the compute stream -- buffers shared across streams could be replaced (and handed back to the
+        # allocating stream's pool) while the other stream still reads them
+        key = (str(device), world, torch.cuda.current_stream(device).cuda_stream)
         ex = cls._cache.get(key)
         need = max(n, capacity)
         if ex is None or ex.per_max * world < ((need + world - 1) // world + 7) // 8 * 8 * world:
+            if ex is not None:
+                torch.cuda.current_stream(device).synchronize()      # the old buffers may still be in flight on this stream
             ex = cls(need, device, world)
             cls._cache[key] = ex
         return ex
+
+    @classmethod
+    def release(cls) -> None:
+        """Drop every cached buffer set (after training, or before a phase that needs the memory)."""
+        if cls._cache and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        cls._cache.clear()
+
+
+# largest range (floats) one pass of the bf16 exchange handles: longer ranges (the flat gradient buffer of the non-overlapped path:
+# 870 M floats) go through the same persistent buffers chunk by chunk instead of pinning 2 x n bf16 for the life of the process
+BF16_EXCHANGE_MAX = 64 << 20
 
 
 def exchange_bf16(t: torch.Tensor, capacity: int = 0) -> torch.Tensor:
@@ -127,6 +144,10 @@ def exchange_bf16(t: torch.Tensor, capacity: int = 0) -> torch.Tensor:
     world, rank = dist.get_world_size(), dist.get_rank()
     n = t.numel()
     flat = t.reshape(-1)
+    if t.is_cuda and n > BF16_EXCHANGE_MAX:
+        for lo in range(0, n, BF16_EXCHANGE_MAX):
+            exchange_bf16(flat[lo:lo + BF16_EXCHANGE_MAX], capacity=BF16_EXCHANGE_MAX)
+        return t
     if not t.is_cuda:                       # CPU tensors (gloo unit tests): the same arithmetic in torch ops
         per = (n + world - 1) // world
         wire = torch.zeros(world * per, dtype=torch.bfloat16)

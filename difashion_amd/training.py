@@ -29,10 +29,15 @@ class FusedAdamW(torch.optim.Optimizer):
     ``param_groups`` keep working for LR schedulers; every group is a contiguous slice of the flat buffers."""
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 max_grad_norm: Optional[float] = None):
+                 max_grad_norm: Optional[float] = None, ddp_group="default"):
+        """``ddp_group``: the process group whose ranks hold replicas of these parameters.  "default" = the default group when one is
+        initialised (the data-parallel training of train.py:611); a ``ProcessGroup`` = that group; ``None`` = this optimizer is NOT
+        data-parallel (per-rank independent models): ``step()`` then performs no collective.  With a group, ``step()`` IS a
+        collective call (one small all-reduce, see ``_sync_freshness``): every rank of the group must call it the same number of times."""
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.max_grad_norm = max_grad_norm
+        self.ddp_group = ddp_group
         plist = [p for g in self.param_groups for p in g["params"]]
         if not plist:
             raise ValueError("no parameters")
@@ -92,13 +97,16 @@ class FusedAdamW(torch.optim.Optimizer):
         (a few hundred bytes) per step.  No-op without an initialised process group."""
         import torch.distributed as tdist
         self._collective_fresh = None
-        if not (tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1):
+        if self.ddp_group is None or not (tdist.is_available() and tdist.is_initialized()):
+            return
+        group = None if isinstance(self.ddp_group, str) else self.ddp_group
+        if tdist.get_world_size(group) <= 1:
             return
         plist = [p for g in self.param_groups for p in g["params"]]
         local = [1 if self._fresh(p) else 0 for p in plist]
-        dev = self.flat_param.device if tdist.get_backend() == "nccl" else torch.device("cpu")
+        dev = self.flat_param.device if tdist.get_backend(group) == "nccl" else torch.device("cpu")
         mask = torch.tensor(local, dtype=torch.int32, device=dev)
-        tdist.all_reduce(mask, op=tdist.ReduceOp.MAX)
+        tdist.all_reduce(mask, op=tdist.ReduceOp.MAX, group=group)
         union = mask.cpu().tolist()
         self._collective_fresh = {id(p) for p, f in zip(plist, union) if f and p.requires_grad}
 

@@ -340,7 +340,7 @@ class UNet2DConditionModel(nn.Module):
         normal path.  ``end_run()`` (or a weight update / another prepare_run) drops the cache.  Inference only."""
         ehs = encoder_hidden_states.contiguous()
         B = ehs.shape[0]
-        self._ensure_ctx(min(B, self.max_batch))
+        self._ensure_ctx(B)                 # grows the context like forward() does: the cache is filled with launches of batch B
         self.pack()
         ts = [float(t) for t in timesteps]
         tdev = torch.tensor(ts, dtype=torch.float32, device=ehs.device)
@@ -461,7 +461,9 @@ class UNet2DConditionModel(nn.Module):
     sync_grads_in_backward = True
     grads_synced = False
     grad_bucket_bytes = 256 << 20         # few, large buckets: xGMI rings are per-link bound, not latency bound
-    grad_wire_dtype = "fp32"              # "bf16": half the bytes per link, fp32 accumulation (dist.exchange_bf16)
+    # wire format of the gradient exchange: "bf16" (default: half the bytes per xGMI link, fp32 accumulation in rank order,
+    # dist.exchange_bf16) or "fp32" (one RCCL all-reduce per range).  Nothing is exchanged in a single-process run.
+    grad_wire_dtype = "bf16"
     measure_comm = False                  # record how long the compute stream waits for the gradient exchange (bench.py --mode train)
     _comm_events = None
 

@@ -26,7 +26,10 @@
 extern "C" {
 #endif
 
-#define DFH_ABI_VERSION 1
+/* Bumped whenever an entry point, a struct layout or the meaning of an argument changes (round 4: 4).  The Python host side
+ * (difashion_amd/_lib.py ABI_VERSION) refuses a library that reports another number: a stale .so next to new Python, or the reverse,
+ * fails at load time instead of at a symbol lookup or silently. */
+#define DFH_ABI_VERSION 4
 #define DFH_MAX_BLOCKS 4
 
 /* ------------------------------------------------------------------ library */

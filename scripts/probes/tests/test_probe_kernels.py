@@ -9,8 +9,10 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+from difashion_amd import _lib  # noqa: E402
 from tests import gpu_util as gu  # noqa: E402
-from tests.gpu_util import bf, rnd  # noqa: E402
+from tests.gpu_util import DEV, bf, rnd  # noqa: E402
+
 
 pytestmark = pytest.mark.skipif("probes" not in os.environ.get("DFH_LIB", ""), reason="needs DFH_LIB=<probe library>")
 
@@ -49,3 +51,48 @@ def test_probe_gemm_tiles(tile, M, N, K):
     res = bf(rnd(M, N, seed=4))
     out = gu.gemm(M=M, N=N, W=w, ldw=K, a0=a, a0_c=K, bias=bias, resid=res, force_tile=tile)
     gu.assert_close_bf16(out, a.float() @ w.float().T + bias + res.float(), f"probe tile {tile}")
+
+
+@pytest.mark.parametrize("M,C,fold", [(8192, 512, False), (16384, 320, True), (4096, 1280, True), (8192, 512, True)])
+def test_geglu_persistent_rows_kernel_is_bit_identical(M, C, fold, monkeypatch):
+    """gemm_geglu_rows_kernel (csrc/gemm_geglu.hip: one workgroup per CU walking 256 x 256 tiles, the next tile's first stage fetched
+    during the current tile's epilogue) against the one-tile-per-workgroup kernel it specialises (tile id 23): same staging, MFMA order
+    and epilogue arithmetic -> bit-identical, with plain bias and with the folded-LayerNorm fix-up; and against torch."""
+    import ctypes
+    monkeypatch.setenv("DFH_GEGLU_ROWS", "1")            # opt-in kernel (measured equal inside the step: csrc/gemm_geglu.hip)
+    x = bf(rnd(M, C, seed=61) + (2.0 if fold else 0.0))
+    w = rnd(8 * C, C, seed=62, scale=0.05)
+    b = rnd(8 * C, seed=63, scale=0.5)
+    wp = torch.empty((8 * C, C), dtype=torch.bfloat16, device=DEV)
+    bp = torch.empty(8 * C, dtype=torch.float32, device=DEV)
+    _lib.call("dfh_pack_matrix", _lib.ptr(w), _lib.ptr(wp), 8 * C, C, C, 0, 0, 1, gu.stream())
+    _lib.call("dfh_pack_vector", _lib.ptr(b), _lib.ptr(bp), 8 * C, 0, 1, 0, gu.stream())
+    assert (M // 256) * (8 * C // 256) >= 512            # enough tiles for the persistent kernel to take the launch
+    if not fold:
+        _lib.census_reset()
+        out = gu.gemm(M=M, N=8 * C, W=wp, ldw=C, a0=x, a0_c=C, bias=bp, act=4)
+        assert _lib.census()["gemm_rows_geglu"] == 1
+        one = gu.gemm(M=M, N=8 * C, W=wp, ldw=C, a0=x, a0_c=C, bias=bp, act=4, force_tile=23)
+        h = x.float() @ bf(w).float().T + b
+    else:
+        gamma, beta = 1.0 + 0.2 * rnd(C, seed=64), 0.3 * rnd(C, seed=65)
+        wf = torch.empty_like(wp)
+        sv, bv = torch.empty(8 * C, device=DEV), torch.empty(8 * C, device=DEV)
+        _lib.call("dfh_ln_fold", _lib.ptr(wp), C, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bp), _lib.ptr(wf), _lib.ptr(sv), _lib.ptr(bv), 8 * C, C,
+                  gu.stream())
+        xf = x.float()
+        mean = xf.mean(-1)
+        st = torch.stack([mean, ((xf - mean[:, None]) ** 2).sum(-1)], -1).contiguous()       # one column tile of C columns: [1][M][2]
+        outs = []
+        for tile in (0, 23):
+            d = gu.gemm_desc(M=M, N=8 * C, W=wf, ldw=C, a0=x, a0_c=C, bias=bv, act=4, force_tile=tile)
+            _lib.census_reset()
+            _lib.call("dfh_gemm_ln", ctypes.byref(d), None, None, _lib.ptr(st), 1, C, 1e-5, _lib.ptr(sv), gu.stream())
+            torch.cuda.synchronize()
+            assert _lib.census()["gemm_rows_geglu"] == (1 if tile == 0 else 0)
+            outs.append(d.keep_out)
+        out, one = outs
+        h = F.layer_norm(xf, (C,), gamma, beta, 1e-5) @ bf(w).float().T + b
+    assert torch.equal(out, one), "persistent kernel differs from the one-tile-per-workgroup kernel"
+    a, gate = h.chunk(2, -1)
+    gu.assert_close_bf16(out, a * F.gelu(gate), "geglu rows", rel=8e-3 if fold else 6e-3)

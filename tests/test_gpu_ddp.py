@@ -49,3 +49,21 @@ def test_bench_multi_rank_flow_on_one_device():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["value"] > 0 and rec["scaling"] == "weak"
     assert rec["roofline"]["bound"] == "mfma" and rec["cpu_baseline"] is None
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher environment: the parent starts two fresh ranks itself (bench.launch_ranks), relays
+    rank 0's one JSON line and exits 0.  Two GPUs: one device per rank over RCCL; one GPU: both ranks on it over gloo."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DFH_DIST_BACKEND="nccl" if TWO_GPUS else "gloo", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-profile"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    print(out.stdout[-2000:], out.stderr[-2000:])
+    assert out.returncode == 0
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0
+    assert rec["collective_backend"] == ("nccl" if TWO_GPUS else "gloo")
+    assert rec["rccl_ranks"] == (2 if TWO_GPUS else None)

@@ -12,6 +12,8 @@ import torch.multiprocessing as mp
 
 import difashion_amd as da
 from difashion_amd import dist as ddist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from difashion_amd import pipeline
 from oracle import glue_ref, sched_ref
 
@@ -404,3 +406,19 @@ def test_profiles_readme_numbers_are_generated_from_the_artefacts():
     for tag in tags:
         r = subprocess.run([sys.executable, os.path.join(root, "scripts", "profiles_readme.py"), tag, "--check"], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_bench_gpus_n_launches_its_own_ranks_and_fails_with_them():
+    """`python bench.py --gpus 2` without a launcher environment becomes the launcher (bench.launch_ranks): it starts the ranks as fresh
+    child processes and must exit non-zero -- promptly, without leaving ranks behind -- when they fail.  Here (no GPU) every rank
+    refuses to start, which is exactly the failure path; the success path runs on the GPU box (tests/test_gpu_ddp.py)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present: the success path is covered by tests/test_gpu_ddp.py")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 1
+    assert "ranks failed" in r.stderr and "needs an MI355X" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -56,6 +56,19 @@ class GemmDesc(C.Structure):
     ]
 
 
+class Fp8GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int),
+        ("sA", C.c_void_p), ("sa_div", C.c_int), ("sa_mul", C.c_float),
+        ("sx", C.c_void_p),
+        ("W", C.c_void_p), ("sW", C.c_void_p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("bias", C.c_void_p), ("resid", C.c_void_p), ("ld_res", C.c_int), ("act", C.c_int),
+        ("out", C.c_void_p), ("ld_out", C.c_int), ("out_mode", C.c_int), ("out_sx", C.c_void_p), ("rows_per_b", C.c_int), ("amax", C.c_void_p),
+        ("zero_page", C.c_void_p),
+    ]
+
+
 class StepCoef(C.Structure):
     _fields_ = [("kind", C.c_int), ("vpred", C.c_int), ("sqrt_a_t", C.c_float), ("sqrt_b_t", C.c_float),
                 ("sqrt_a_prev", C.c_float), ("dir_coef", C.c_float), ("std_dev", C.c_float)]
@@ -173,7 +186,10 @@ SIGNATURES = {
     "dfh_gemm_ln": (_i, [C.POINTER(GemmDesc), _vp, C.POINTER(C.c_int), _vp, _i, _i, _f, _vp, _vp]),
     "dfh_quantize_rows_fp8": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
     "dfh_layernorm_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
-    "dfh_gemm_fp8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "dfh_gemm_fp8": (_i, [C.POINTER(Fp8GemmDesc), _vp]),
+    "dfh_groupnorm_fp8": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "dfh_attention_fp8out": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "dfh_amax_slabs": (_i, [_vp, C.c_long, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "dfh_unet_enable_fp8": (_i, [_vp]),
     "dfh_unet_arena8_bytes": (_sz, [_vp]),
     "dfh_unet_bind_fp8": (_i, [_vp, _vp]),

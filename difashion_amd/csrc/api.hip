@@ -422,14 +422,32 @@ int dfh_gemm_batched(const dfh_gemm_desc* d, int nbatch, long a_bs, long w_bs, l
   return dfh::gemm_launch(g, (hipStream_t)stream, d->force_tile, 0, d->force_order);
 }
 
-int dfh_gemm_fp8(const void* A, const float* sA, const void* W, const float* sW, int M, int N, int K, const float* bias,
-                 const void* resid, int ld_res, int act, void* out, int ld_out, int out_mode, int rows_per_b, const void* zero_page,
-                 void* stream) {
+int dfh_gemm_fp8(const dfh_gemm_fp8_desc* d, void* stream) {
+  DFH_REQUIRE(d != nullptr, "null descriptor");
   Fp8GemmArgs g; std::memset(&g, 0, sizeof(g));
-  g.A = (const uint8_t*)A; g.sA = sA; g.W = (const uint8_t*)W; g.sW = sW; g.M = M; g.N = N; g.K = K; g.bias = bias;
-  g.resid = (const bf16_t*)resid; g.ld_res = ld_res; g.act = act; g.out = out; g.ld_out = ld_out; g.out_mode = out_mode;
-  g.rows_per_b = rows_per_b; g.zero = (const uint8_t*)zero_page;
+  g.A = (const uint8_t*)d->A; g.lda = d->lda; g.sA = d->sA; g.sa_div = d->sa_div; g.sa_mul = d->sa_mul; g.sx = (const uint8_t*)d->sx;
+  g.W = (const uint8_t*)d->W; g.sW = d->sW; g.M = d->M; g.N = d->N; g.K = d->K; g.bias = d->bias;
+  g.resid = (const bf16_t*)d->resid; g.ld_res = d->ld_res; g.act = d->act; g.out = d->out; g.ld_out = d->ld_out; g.out_mode = d->out_mode;
+  g.out_sx = (uint8_t*)d->out_sx; g.rows_per_b = d->rows_per_b; g.amax = d->amax; g.zero = (const uint8_t*)d->zero_page;
   return dfh::gemm_fp8_launch(g, (hipStream_t)stream);
+}
+int dfh_groupnorm_fp8(const void* src, int batch, int HW, int C, int groups, float eps, float q_mul, void* q, float* partial, void* stream) {
+  GnArgs a; std::memset(&a, 0, sizeof(a));
+  a.src0 = (const bf16_t*)src; a.C0 = C; a.B = batch; a.HW = HW; a.G = groups; a.eps = eps; a.out8 = (uint8_t*)q; a.q_mul = q_mul;
+  a.partial = partial;
+  return dfh::groupnorm_launch(a, (hipStream_t)stream);
+}
+int dfh_attention_fp8out(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O8, int ldo, const float* v_amax,
+                         int batch, int heads, int head_dim, int Nq, int Nk, float scale, void* stream) {
+  AttnArgs a; std::memset(&a, 0, sizeof(a));
+  a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.Vt = (const bf16_t*)Vt; a.ldvt = ldvt;
+  a.O8 = (uint8_t*)O8; a.ldo = ldo; a.o_amax = v_amax; a.B = batch; a.H = heads; a.D = head_dim; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+  DFH_REQUIRE(O8 && v_amax, "fp8 attention output needs O8 and the per-batch maxima of V");
+  return dfh::attention_launch(a, (hipStream_t)stream);
+}
+int dfh_amax_slabs(const void* x, long bstride, int ld, int cols, const int* row0, const int* nrows, float* out, int nslab, int batch,
+                   void* stream) {
+  return dfh::amax_slabs_launch((const bf16_t*)x, bstride, ld, cols, row0, nrows, out, nslab, batch, (hipStream_t)stream);
 }
 int dfh_quantize_rows_fp8(const void* x, int ldx, void* q, float* scale, int R, int K, void* stream) {
   return dfh::quant_rows_fp8_launch((const bf16_t*)x, ldx, (uint8_t*)q, scale, R, K, (hipStream_t)stream);

@@ -7,6 +7,10 @@ struct AttnArgs {
   const bf16_t* Vt; int ldvt;   // [B][H*D][ldvt]  V transposed (key index contiguous), ldvt >= roundup8(Nk)
   long vt_bstride;              // elements between batches of Vt (0 = H*D*ldvt): lets a layer read a slice of a batched V^T
   bf16_t* O; int ldo;           // [B][Nq][ldo]
+  // fp8 to_out (BASELINE configs[4]): O8 != null -> the output leaves as e4m3 [B][Nq][ldo] (bytes) instead of bf16, scaled by
+  // 448 / o_amax[b]: the attention output is a convex combination of the rows of V, so |O| <= max |V| of the batch element, which
+  // the V projection's epilogue tracked (gemm.h Fp8GemmArgs::amax).  The consumer multiplies o_amax[b] / 448 back in.
+  uint8_t* O8; const float* o_amax;
   int B, H, D, Nq, Nk;
   float scale;                  // D^-0.5
   float* lse;                   // optional [B][H][Nq] fp32: log2-domain log-sum-exp (m + log2 l) of the scaled scores, for backward
@@ -27,6 +31,27 @@ struct AttnBwdArgs {
   int B, H, D, Nq, Nk;
   float scale;
 };
+
+#ifdef __HIPCC__
+// four consecutive channels d0 .. d0 + 3 of output row `row` (elements from the start of O), already normalised (and, for O8, scaled)
+DFH_DEVICE void attn_store4(const AttnArgs& a, long row, int d0, float v0, float v1, float v2, float v3) {
+  if (a.O8) {
+    const int lo = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v0, -448.f, 448.f), __builtin_amdgcn_fmed3f(v1, -448.f, 448.f), 0, false);
+    *(unsigned*)(a.O8 + row + d0) =
+        (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v2, -448.f, 448.f), __builtin_amdgcn_fmed3f(v3, -448.f, 448.f), lo, true);
+  } else {
+    uint2 w;
+    w.x = pack2bf(v0, v1); w.y = pack2bf(v2, v3);
+    *(uint2*)(a.O + row + d0) = w;
+  }
+}
+// multiplier that takes a normalised output of batch element b to its stored form
+DFH_DEVICE float attn_qmul(const AttnArgs& a, int b) {
+  if (!a.O8) return 1.0f;
+  const float am = a.o_amax[b];
+  return am > 0.f ? 448.0f / am : 0.f;
+}
+#endif
 
 namespace dfh {
 int attention_launch(const AttnArgs& a, hipStream_t stream);

@@ -264,20 +264,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs a) {
       l = l_run[qt];
       l = rows_sum(l);
     }
-    const float inv = 1.0f / l;
+    const float inv = attn_qmul(a, b) / l;
     const int q = q0 + qt * 16 + fr;
     if (q >= a.Nq) continue;
     if (a.lse && fg == 0) a.lse[((long)b * a.H + h) * a.Nq + q] = m_run[qt] + __builtin_amdgcn_logf(l);   // v_log_f32 = log2
-    bf16_t* orow = a.O + ((long)b * a.Nq + q) * a.ldo + h * D;
+    const long orow = ((long)b * a.Nq + q) * a.ldo + h * D;
 #pragma unroll
     for (int f = 0; f < DF; ++f) {
       const int d0 = f * 16 + fg * 4;
-      if (d0 < D) {
-        uint2 o;
-        o.x = pack2bf(oacc[qt][f][0] * inv, oacc[qt][f][1] * inv);
-        o.y = pack2bf(oacc[qt][f][2] * inv, oacc[qt][f][3] * inv);
-        *(uint2*)(orow + d0) = o;
-      }
+      if (d0 < D) attn_store4(a, orow, d0, oacc[qt][f][0] * inv, oacc[qt][f][1] * inv, oacc[qt][f][2] * inv, oacc[qt][f][3] * inv);
     }
   }
 }
@@ -309,6 +304,7 @@ int attention_launch(const AttnArgs& a, hipStream_t stream) {
   DFH_REQUIRE(a.Nq > 0 && a.Nk > 0 && a.B > 0 && a.H > 0, "empty attention");
   DFH_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 4 == 0, "leading dims must be 16-byte aligned");
   DFH_REQUIRE(a.ldvt >= ((a.Nk + 7) / 8) * 8, "V^T rows must be padded to a multiple of 8 keys");
+  DFH_REQUIRE(a.O8 ? a.o_amax != nullptr : a.O != nullptr, "attention: no output (bf16 O, or e4m3 O8 with the per-batch maxima of V)");
   static const bool x32_off = [] { const char* e = getenv("DFH_ATTN_X32"); return e && e[0] == '0'; }();   // A/B switch for the microbenchmarks
   if (!x32_off && attention_x32_eligible(a)) return attention_x32_launch(a, stream);
   census(CK_ATTN_16);

@@ -415,27 +415,23 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
   }
 
   // ---- normalise and store: lane (query ql, half hi) holds O[q][d = 32 db + 8 (r >> 2) + 4 hi + (r & 3)]
+  const float qmul = attn_qmul(a, b);
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const float lv = o[D / 32][qb][G::L_REG];
     const float lo = lane_xor32(lv);
     const float l = hi == G::L_HI ? lv : lo;
-    const float inv = 1.0f / l;
+    const float inv = qmul / l;
     const int q = q0 + qb * 32 + ql;
     if (q >= a.Nq) continue;
     if (a.lse && hi == 0) a.lse[((long)b * a.H + h) * a.Nq + q] = m_run[qb] + __builtin_amdgcn_logf(l);   // v_log_f32 = log2
-    bf16_t* orow = a.O + ((long)b * a.Nq + q) * a.ldo + h * D;
+    const long orow = ((long)b * a.Nq + q) * a.ldo + h * D;
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d0 = db * 32 + g * 8 + hi * 4;
-        if (d0 < D) {
-          uint2 w;
-          w.x = pack2bf(o[db][qb][4 * g] * inv, o[db][qb][4 * g + 1] * inv);
-          w.y = pack2bf(o[db][qb][4 * g + 2] * inv, o[db][qb][4 * g + 3] * inv);
-          *(uint2*)(orow + d0) = w;
-        }
+        if (d0 < D) attn_store4(a, orow, d0, o[db][qb][4 * g] * inv, o[db][qb][4 * g + 1] * inv, o[db][qb][4 * g + 2] * inv, o[db][qb][4 * g + 3] * inv);
       }
   }
 }
@@ -658,21 +654,16 @@ __global__ __launch_bounds__(256, 2) void attention_xs_kernel(const AttnArgs a, 
       const float lv = o[D / 32][qb][G::L_REG];
       const float lo = lane_xor32(lv);
       const float l = hi == G::L_HI ? lv : lo;
-      const float inv = 1.0f / l;
+      const float inv = attn_qmul(a, b) / l;
       const int q = q0 + qb * 32 + ql;
       if (q >= a.Nq) continue;
-      bf16_t* orow = a.O + ((long)b * a.Nq + q) * a.ldo + h * D;
+      const long orow = ((long)b * a.Nq + q) * a.ldo + h * D;
 #pragma unroll
       for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int d0 = db * 32 + g * 8 + hi * 4;
-          if (d0 < D) {
-            uint2 w;
-            w.x = pack2bf(o[db][qb][4 * g] * inv, o[db][qb][4 * g + 1] * inv);
-            w.y = pack2bf(o[db][qb][4 * g + 2] * inv, o[db][qb][4 * g + 3] * inv);
-            *(uint2*)(orow + d0) = w;
-          }
+          if (d0 < D) attn_store4(a, orow, d0, o[db][qb][4 * g] * inv, o[db][qb][4 * g + 1] * inv, o[db][qb][4 * g + 2] * inv, o[db][qb][4 * g + 3] * inv);
         }
     }
   }

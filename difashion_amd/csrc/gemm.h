@@ -17,6 +17,7 @@ enum GemmOut {
   OUT_BF16_T = 1,  // bf16 transposed per batch: out[b][n][ld_out], m = b*rows_per_b + mm (attention V^T)
   OUT_F32 = 2,     // fp32 [M][ld_out]
   OUT_F32_T = 3,   // fp32 transposed per batch (conv_out -> NCHW noise prediction)
+  OUT_FP8_MX = 4,  // gemm_fp8.hip only: e4m3 [M][ld_out bytes] + one E8M0 block scale per row and 32 output columns (out_sx [N / 32][M])
 };
 
 struct GemmArgs {
@@ -77,16 +78,24 @@ struct GemmArgs {
   const float* ln_stat; int ln_parts, ln_cnt; float ln_eps; const float* ln_s;
 };
 
-// fp8 (OCP e4m3fn) linear: out[m][n] = epilogue(sA[m] * sW[n] * sum_k A8[m][k] * W8[n][k]); gemm_fp8.hip
+// fp8 (OCP e4m3fn) linear on v_mfma_scale_f32_32x32x64_f8f6f4 (gemm_fp8.hip):
+//   out[m][n] = epilogue(sa(m) * sW[n] * sum_k 2^(sx[k / 32][m] - 127) * A8[m][k] * W8[n][k])
+// Activation scaling, any combination: a float per row or per group of sa_div rows (sA: the per-token scale of a LayerNorm output, or one
+// value per image), a constant (sa_mul) and E8M0 block scales per row and 32 contraction elements (sx: what the hardware's scale operand
+// takes; written by the producers that cannot see a whole row -- the GEGLU epilogue, a column tile of another fp8 GEMM).
 struct Fp8GemmArgs {
-  const uint8_t* A; const float* sA;   // [M][K] e4m3 activations, one scale per row (token)
+  const uint8_t* A; int lda;            // [M][lda] e4m3 activations (lda bytes per row; 0 = K)
+  const float* sA; int sa_div; float sa_mul;   // sa(m) = (sA ? sA[m / sa_div] : 1) * sa_mul   (sa_div 0 = 1, sa_mul 0 = 1)
+  const uint8_t* sx;                    // optional E8M0 block scales [K / 32][M]; null = 2^0
   const uint8_t* W; const float* sW;   // [N][K] e4m3 weights, one scale per row (output channel)
   int M, N, K;                          // K a multiple of 64
   const float* bias;                    // [N] or null
-  const bf16_t* resid; int ld_res;      // optional residual (OUT_BF16 only)
+  const bf16_t* resid; int ld_res;      // optional residual (row-major outputs)
   int act;                              // ACT_NONE / ACT_GEGLU (packed rows interleaved in 16-row value / gate blocks)
-  void* out; int ld_out; int out_mode;  // OUT_BF16 / OUT_BF16_T
+  void* out; int ld_out; int out_mode;  // OUT_BF16 / OUT_BF16_T / OUT_FP8_MX (ld_out in elements of the output type)
+  uint8_t* out_sx;                      // OUT_FP8_MX: E8M0 scales of the output, [N_out / 32][M]
   int rows_per_b;                       // OUT_BF16_T: rows per batch element
+  float* amax;                          // OUT_BF16_T, optional: amax[b] = max(amax[b], max |out| of batch element b) (atomic; caller zeroes)
   const uint8_t* zero;                  // >= 16 bytes of zeros in device memory
 };
 
@@ -111,7 +120,10 @@ DFH_DEVICE float2 ln_row_stats(const GemmArgs& a, int m) {
 #endif
 
 namespace dfh {
-int gemm_fp8_launch(const Fp8GemmArgs& a, hipStream_t stream);
+int gemm_fp8_launch(Fp8GemmArgs a, hipStream_t stream);
+// out[sl][b] = max |x| over rows row0[sl] .. row0[sl] + nrows[sl] - 1 (cols columns each) of batch element b of a bf16 [B][.][ld] tensor
+int amax_slabs_launch(const bf16_t* x, long bstride, int ld, int cols, const int* row0, const int* nrows, float* out, int nslab, int B,
+                      hipStream_t stream);
 // bf16 [R][K] (row stride ldx) -> e4m3 [R][K] + one scale per row (amax / 448)
 int quant_rows_fp8_launch(const bf16_t* x, int ldx, uint8_t* q, float* scale, int R, int K, hipStream_t stream);
 // LayerNorm whose output is quantised per token: q [M][C] e4m3, scale [M]

@@ -11,6 +11,11 @@ struct GnArgs {
   const float* gamma; const float* beta;    // [C0+C1]
   float eps; int silu;
   bf16_t* out;                               // [B][HW][C0+C1]
+  // fp8 proj_in (BASELINE configs[4]): when out8 is set the kernels write e4m3(clamp((x - mean) * rstd * q_mul, +-448)) [B][HW][C]
+  // INSTEAD of the bf16 tensor -- the normalised value WITHOUT gamma / beta (the consumer's weights carry gamma, its bias W . beta:
+  // unet_model.h), under a static scale: |z| <= 448 / q_mul is representable, typical |z| ~ 1 sits 4-5 binades inside the e4m3 range.
+  // One source, no SiLU.
+  uint8_t* out8; float q_mul;
   float* partial;                            // >= B * GN_MAX_CHUNKS * G * 2 floats
   float* stats_out;                          // optional [B][G][2] (mean, rstd), kept for the backward pass
   const float* pre; int pre_chunks;          // optional: statistics partials written by the producing GEMM's epilogue

@@ -114,7 +114,7 @@ __global__ void gn_apply_kernel(const GnArgs a) {
     if (live && p < p_end) pre[u] = *gn_src(a, b, p, o);
   }
   float gmr[8], btr[8];
-  if (live) {
+  if (live && !a.out8) {
     const float4 g0 = *(const float4*)(a.gamma + o * 8), g1 = *(const float4*)(a.gamma + o * 8 + 4);
     const float4 b0 = *(const float4*)(a.beta + o * 8), b1 = *(const float4*)(a.beta + o * 8 + 4);
     gmr[0] = g0.x; gmr[1] = g0.y; gmr[2] = g0.z; gmr[3] = g0.w; gmr[4] = g1.x; gmr[5] = g1.y; gmr[6] = g1.z; gmr[7] = g1.w;
@@ -162,13 +162,22 @@ __global__ void gn_apply_kernel(const GnArgs a) {
   for (int k = 0; k < 8; ++k) {
     const int c = o * 8 + k;
     const int g = c / cpg;
-    const float w = gmr[k] * rstd_s[g];
+    const float w = (a.out8 ? a.q_mul : gmr[k]) * rstd_s[g];
     sc[k] = w;
-    sh[k] = btr[k] - mean_s[g] * w;
+    sh[k] = (a.out8 ? 0.f : btr[k]) - mean_s[g] * w;
   }
   auto emit = [&](const uint4& raw, int p) {
     float f[8];
     unpack8(raw, f);
+    if (a.out8) {                                    // e4m3 of the normalised value under the static scale (GnArgs::out8)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = __builtin_amdgcn_fmed3f(f[k] * sc[k] + sh[k], -448.f, 448.f);
+      uint2 w;
+      w.x = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false), true);
+      w.y = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false), true);
+      *(uint2*)(a.out8 + ((long)(b * a.HW + p) * a.C + o * 8)) = w;
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       float y = f[k] * sc[k] + sh[k];
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GnArgs a) {
   // the group's gamma / beta go to LDS once: read per unit from global they were two more loads for every 8-byte data load
   __shared__ __attribute__((aligned(16))) float gam_s[256], bet_s[256];
   const bool gb_lds = cpg <= 256;
-  if (gb_lds && tid < cpg) { gam_s[tid] = a.gamma[cg + tid]; bet_s[tid] = a.beta[cg + tid]; }
+  if (gb_lds && tid < cpg && !a.out8) { gam_s[tid] = a.gamma[cg + tid]; bet_s[tid] = a.beta[cg + tid]; }
   float v[UNITS][4];
   int pix[UNITS], ch[UNITS];
   float s = 0.f;
@@ -312,6 +321,20 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GnArgs a) {
   __syncthreads();
   const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) / n + a.eps);
   if (a.stats_out && tid == 0) { a.stats_out[((long)b * a.G + g) * 2] = mean; a.stats_out[((long)b * a.G + g) * 2 + 1] = rstd; }
+  if (a.out8) {                                      // e4m3 of the normalised value under the static scale (GnArgs::out8)
+    uint8_t* dst8 = a.out8 + (long)b * a.HW * a.C + cg;
+    const float w = rstd * a.q_mul;
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u)
+      if (pix[u] >= 0) {
+        float y[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = __builtin_amdgcn_fmed3f((v[u][k] - mean) * w, -448.f, 448.f);
+        *(unsigned*)(dst8 + (long)pix[u] * a.C + ch[u]) =
+            (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], 0, false), true);
+      }
+    return;
+  }
   bf16_t* dst = a.out + (long)b * a.HW * a.C + cg;
 #pragma unroll
   for (int u = 0; u < UNITS; ++u)
@@ -438,7 +461,8 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
   DFH_REQUIRE(a.C % 8 == 0 && a.C0 % 8 == 0 && a.C1 % 8 == 0, "channels must be multiples of 8");
   DFH_REQUIRE(a.G > 0 && a.G <= 64 && a.C % a.G == 0, "bad group count");
   DFH_REQUIRE(a.C / 8 <= 1024, "too many channels");
-  DFH_REQUIRE((a.partial != nullptr || a.pre != nullptr) && a.out != nullptr && a.src0 != nullptr, "null pointer");
+  DFH_REQUIRE((a.partial != nullptr || a.pre != nullptr) && (a.out != nullptr || a.out8 != nullptr) && a.src0 != nullptr, "null pointer");
+  if (a.out8) DFH_REQUIRE(a.C1 == 0 && !a.silu && a.q_mul > 0.f && !a.stats_out, "e4m3 GroupNorm output: one source, no SiLU, a positive scale");
   DFH_REQUIRE(a.C1 == 0 || a.src1 != nullptr, "second source missing");
   if (a.pre) {
     // the producer's epilogue already summed the tensor (one source, its own group structure): normalise only
@@ -447,7 +471,7 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
     gn_geometry(a, &block, &achunks);
     DFH_REQUIRE(block <= 1024, "block too large");
     a.partial = const_cast<float*>(a.pre); a.chunks = a.pre_chunks;
-    ProfScope ps(PC_GNORM, 0.0, 4.0 * a.B * (double)a.HW * a.C, stream);
+    ProfScope ps(PC_GNORM, 0.0, (a.out8 ? 3.0 : 4.0) * a.B * (double)a.HW * a.C, stream);
     census(CK_GN_PRE);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(achunks, a.B), dim3(block), 0, stream, a);
     return check_launch("gn_apply_kernel");
@@ -458,7 +482,7 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
     const bool one_source_per_group = a.C1 == 0 || a.C0 % cpg == 0;
     static const int small_max = [] { const char* e = getenv("DFH_GN_SMALL_MAX"); return e ? atoi(e) : 16; }();   // probe knob; > 16 units per thread (32x32 x 640) the two-kernel path is faster since its prologue fix: 25.6 -> 21.3 us
     if ((cpg & 3) == 0 && units <= 256 * small_max && one_source_per_group && (long)a.B * a.G >= 64) {
-      ProfScope ps(PC_GNORM, 0.0, 4.0 * a.B * (double)a.HW * a.C, stream);
+      ProfScope ps(PC_GNORM, 0.0, (a.out8 ? 3.0 : 4.0) * a.B * (double)a.HW * a.C, stream);
       const dim3 grid(a.G, a.B);
       census(CK_GN_SMALL);
       if (units <= 256 * 8) hipLaunchKernelGGL(gn_small_kernel<8>, grid, dim3(256), 0, stream, a);
@@ -474,7 +498,7 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
     // run across up to sixteen), and at 32x32 the two-kernel path is, so this is the fallback between them.
     static const bool mid_off = [] { const char* e = getenv("DFH_GN_MID"); return e && e[0] == '0'; }();
     const int cpg = a.C / a.G, upp = cpg >> 2;
-    if (!mid_off && (cpg & 3) == 0 && a.HW <= 256 && a.G % 2 == 0) {
+    if (!mid_off && !a.out8 && (cpg & 3) == 0 && a.HW <= 256 && a.G % 2 == 0) {
       for (int gq = 4; gq >= 2; gq >>= 1) {
         if (a.G % gq || (long)a.B * (a.G / gq) < 128 || gq * upp > 256) continue;
         const int uppb = gq * upp;
@@ -501,7 +525,7 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
   DFH_REQUIRE(block <= 1024, "block too large");
   const size_t lds = (size_t)a.PL * a.C * 2 * sizeof(float);
   DFH_REQUIRE(lds <= 64 * 1024, "GroupNorm LDS reduction too large");
-  ProfScope ps(PC_GNORM, 0.0, 4.0 * a.B * (double)a.HW * a.C, stream);   // algorithmic: one read + one write (bf16)
+  ProfScope ps(PC_GNORM, 0.0, (a.out8 ? 3.0 : 4.0) * a.B * (double)a.HW * a.C, stream);   // algorithmic: one read + one write (bf16)
   census(CK_GN_STATS);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(a.chunks, a.B), dim3(block), lds, stream, a);
   if (int rc = check_launch("gn_stats_kernel")) return rc;

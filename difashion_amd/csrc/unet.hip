@@ -121,6 +121,9 @@ int dfh_unet_forward_cached(dfh_unet* u, const void* sample, int sample_bf16, co
   rc.vxt = (const bf16_t*)((const char*)cache + dfh_unet::cache_kx_bytes(*u, batch));
   rc.temb_row = (const float*)((const char*)cache + dfh_unet::cache_kx_bytes(*u, batch) + dfh_unet::cache_vxt_bytes(*u, batch)) +
                 (size_t)t_index * u->temb_total;
+  if (u->fp8)
+    rc.xamax = (const float*)((const char*)cache + dfh_unet::cache_kx_bytes(*u, batch) + dfh_unet::cache_vxt_bytes(*u, batch) +
+                              (((size_t)n_timesteps * u->temb_total * 4 + 255) & ~(size_t)255));
   return u->run(sample, sample_bf16, nullptr, nullptr, 0, out, batch, (hipStream_t)stream, false, &rc);
 }
 

@@ -35,7 +35,9 @@ struct ParamDesc { std::string name; std::vector<int> shape; };
 // transposed pack (training): master weight -> arena16t, see bwd_elementwise.hip pack_*_t kernels
 struct TPackOp { int param, conv; size_t dst; int N, K, ldt, t_row_off, t_col_off, geglu, o_pad; };
 
-struct Mat8 { size_t off = 0, soff = 0; int N = 0, K = 0; bool on = false; };   // fp8 [N][K] at arena8 + off, scales (floats) at arena8 + soff
+// fp8 [N][K] at arena8 + off, per-row scales (floats) at arena8 + soff; boff: a derived bias (floats) for the matrices that fold a norm's
+// affine into themselves (proj_in), else unused
+struct Mat8 { size_t off = 0, soff = 0, boff = 0; int N = 0, K = 0; bool on = false; };
 
 struct ResL {
   int cin = 0, cout = 0, temb_off = 0; bool shortcut = false;
@@ -50,6 +52,7 @@ struct Fold { size_t w = 0, s = 0, b = 0; int N = 0, K = 0; };
 
 struct AttL {
   int C = 0, heads = 0, x_off = 0;   // x_off: this layer's row offset in the batched cross K / V matrices
+  int idx = 0;                       // position in all_att() order (the per-layer slots of the fp8 path's V maxima)
   Fold fqkv, fqk, fv, fq2, fff1;
   // ff.net.2 and proj_out folded into ONE linear over [GEGLU output | h2] (inference walk): W = [pout . ff2 | pout] ([C][5C]), bias =
   // pout . ff2b + poutb -- proj_out(ff2(f) + ff2b + h2) + poutb as written, minus one launch, one bf16 rounding and one round trip
@@ -59,6 +62,9 @@ struct AttL {
   Mat pin, qk, v, o1, q2, o2, ff1, ff2, pout;
   std::string pre; Mat pint, qkvt, o1t, q2t, o2t, ff1t, ff2t, poutt;
   Mat8 qk8, v8, q28, ff18;           // fp8 copies of the LayerNorm-fed projections (gemm_fp8.hip), when enabled
+  // round 4 (BASELINE configs[4] as named: "attention + 1x1-conv path"): to_out of both attentions, ff.net.2, proj_out, and proj_in with
+  // the GroupNorm affine folded in (W . diag(gamma), bias + W . beta: the GroupNorm kernel then emits the normalised value as e4m3)
+  Mat8 o18, o28, ff28, pout8, pin8;
 };
 struct ConvL {
   Mat w; Vec b; int cin = 0, cout = 0; std::string pre; Mat wt;
@@ -399,30 +405,60 @@ struct dfh_unet {
     return v;
   }
   // fp8 copies exist for the transformer layers whose width the 64-deep contraction divides
+  static constexpr float GN_Z = 32.0f;   // |normalised GroupNorm value| representable in the e4m3 proj_in operand (static scale 448 / GN_Z)
+  size_t a8_slab_off = 0; int n_att = 0; std::vector<int> slab_host;
   int enable_fp8() {
     if (fp8) return 0;
     a8 = 0;
-    auto take = [&](const Mat& m, Mat8& q) {
+    auto take = [&](const Mat& m, Mat8& q, bool with_bias = false) {
       q.N = m.N; q.K = m.K; q.on = true;
       q.off = a8; a8 += ((size_t)m.N * m.K + 255) & ~(size_t)255;
       q.soff = a8; a8 += ((size_t)m.N * sizeof(float) + 255) & ~(size_t)255;
+      if (with_bias) { q.boff = a8; a8 += ((size_t)m.N * sizeof(float) + 255) & ~(size_t)255; }
     };
+    // DFH_FP8_EXT=0: only the round-2 set (the LayerNorm-fed projections) -- A/B switch
+    static const bool ext_off = [] { const char* e = getenv("DFH_FP8_EXT"); return e && e[0] == '0'; }();
+    int idx = 0;
     for (AttL* a : all_att()) {
+      a->idx = idx++;
       if (a->C % 64) continue;
       take(a->qk, a->qk8); take(a->v, a->v8); take(a->q2, a->q28); take(a->ff1, a->ff18);
+      if (ext_off) continue;
+      take(a->o1, a->o18); take(a->o2, a->o28); take(a->ff2, a->ff28); take(a->pout, a->pout8); take(a->pin, a->pin8, true);
     }
+    n_att = idx;
+    // (row offset, row count) of every layer's slice of the batched cross-attention V^T: the slabs of amax_slabs_kernel
+    a8_slab_off = a8; a8 += ((size_t)2 * n_att * sizeof(int) + 255) & ~(size_t)255;
+    slab_host.assign(2 * n_att, 0);
+    for (AttL* a : all_att()) { slab_host[a->idx] = a->x_off; slab_host[n_att + a->idx] = a->C; }
     fp8 = true;
     return 0;
   }
+  const int* slab_row0() const { return (const int*)(arena8 + a8_slab_off); }
+  const int* slab_rows() const { return slab_row0() + n_att; }
   int quantize_fp8(hipStream_t s) {
     if (!fp8 || !arena8) return 0;
+    if (hipMemcpyAsync(arena8 + a8_slab_off, slab_host.data(), slab_host.size() * sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) {
+      dfh::set_error("uploading the V^T slab table failed"); return -2;
+    }
     for (AttL* a : all_att()) {
-      const Mat* src[4] = {&a->qk, &a->v, &a->q2, &a->ff1};
-      const Mat8* dst[4] = {&a->qk8, &a->v8, &a->q28, &a->ff18};
-      for (int i = 0; i < 4; ++i) {
+      const Mat* src[8] = {&a->qk, &a->v, &a->q2, &a->ff1, &a->o1, &a->o2, &a->ff2, &a->pout};
+      const Mat8* dst[8] = {&a->qk8, &a->v8, &a->q28, &a->ff18, &a->o18, &a->o28, &a->ff28, &a->pout8};
+      for (int i = 0; i < 8; ++i) {
         if (!dst[i]->on) continue;
         if (int rc = dfh::quant_rows_fp8_launch(arena16 + src[i]->off, src[i]->K, arena8 + dst[i]->off, (float*)(arena8 + dst[i]->soff),
                                                 src[i]->N, src[i]->K, s)) return rc;
+      }
+      if (a->pin8.on) {
+        // proj_in behind the GroupNorm whose kernel emits the un-affined normalised value: W' = W . diag(gamma) (bf16, in the activation
+        // workspace, which no walk is using while weights are derived), b' = bias + W . beta, then the per-channel quantisation of W'
+        const int C = a->C;
+        DFH_REQUIRE(ws && fold_bytes() + (size_t)C * C * 2 + (size_t)C * 4 + 512 <= ws_bytes, "workspace too small for the fp8 proj_in fold");
+        bf16_t* wf = (bf16_t*)(ws + fold_bytes());
+        float* sv = (float*)(ws + fold_bytes() + (((size_t)C * C * 2 + 255) & ~(size_t)255));
+        if (int rc = dfh::ln_fold_launch(arena16 + a->pin.off, a->pin.K, arena32 + a->nw.off, arena32 + a->nb.off, arena32 + a->pinb.off, wf, sv,
+                                         (float*)(arena8 + a->pin8.boff), C, C, s)) return rc;
+        if (int rc = dfh::quant_rows_fp8_launch(wf, C, arena8 + a->pin8.off, (float*)(arena8 + a->pin8.soff), C, C, s)) return rc;
       }
     }
     return 0;
@@ -494,6 +530,9 @@ struct dfh_unet {
     float* gn_partial = nullptr; bf16_t* zero = nullptr;
     int temb_ld = 0;                 // row stride of the time-embedding rows: temb_total, or 0 when the whole batch shares one cached row
     int rc = 0;
+    // fp8 walk: per transformer layer and batch element the largest |V| of the self-attention (tracked by the V projection's epilogue,
+    // zeroed at the start of the walk) and of the cross-attention (amax_slabs over the text V^T, once per forward or per run): [n_att][B]
+    float* amax_self = nullptr; const float* amax_cross = nullptr;
 
     bf16_t* w16(const Mat& m) const { return u->arena16 + m.off; }
     float* v32(const Vec& v) const { return u->arena32 + v.off; }
@@ -568,14 +607,45 @@ struct dfh_unet {
       rc = dfh::layernorm_fp8_launch(x, v32(w), v32(b), q, sc, M, C, 1e-5f, s);
     }
     void linear8(const uint8_t* q, const float* sc, int M, const Mat8& W, const Vec* bias, int act, void* out, int out_mode = OUT_BF16,
-                 int ld_out = -1, int rows_per_b = 0) {
+                 int ld_out = -1, int rows_per_b = 0, float* amax = nullptr) {
       if (rc || dry) return;
       Fp8GemmArgs g; std::memset(&g, 0, sizeof(g));
       g.A = q; g.sA = sc; g.W = u->arena8 + W.off; g.sW = (const float*)(u->arena8 + W.soff);
       g.M = M; g.N = W.N; g.K = W.K; g.bias = bias ? v32(*bias) : nullptr; g.act = act;
       g.out = out; g.out_mode = out_mode; g.ld_out = ld_out < 0 ? (act == ACT_GEGLU ? W.N / 2 : W.N) : ld_out;
-      g.rows_per_b = rows_per_b; g.zero = (const uint8_t*)zero;
+      g.rows_per_b = rows_per_b; g.zero = (const uint8_t*)zero; g.amax = amax;
       rc = dfh::gemm_fp8_launch(g, s);
+    }
+    // ---- fp8 walk (round 4): every operand of these launches is e4m3
+    Fp8GemmArgs args8(const uint8_t* A, int M, const Mat8& W, const Vec* bias, void* out) const {
+      Fp8GemmArgs g; std::memset(&g, 0, sizeof(g));
+      g.A = A; g.W = u->arena8 + W.off; g.sW = (const float*)(u->arena8 + W.soff);
+      g.M = M; g.N = W.N; g.K = W.K; g.bias = bias ? v32(*bias) : nullptr;
+      g.out = out; g.out_mode = OUT_BF16; g.ld_out = W.N; g.zero = (const uint8_t*)zero;
+      return g;
+    }
+    void gemm8(const Fp8GemmArgs& g) {
+      if (rc || dry) return;
+      rc = dfh::gemm_fp8_launch(g, s);
+    }
+    // GroupNorm without its affine, as e4m3 under the static scale 448 / GN_Z (the consumer's weights carry gamma)
+    void groupnorm8(const Tensor& x, float eps, uint8_t* q) {
+      if (rc || dry) return;
+      GnArgs a; std::memset(&a, 0, sizeof(a));
+      a.src0 = x.p; a.C0 = x.C; a.B = B; a.HW = x.H * x.W; a.G = u->cfg.norm_num_groups; a.eps = eps; a.partial = gn_partial;
+      a.out8 = q; a.q_mul = 448.0f / dfh_unet::GN_Z;
+      if (x.gst && x.gst_cpg == x.C / a.G) { a.pre = x.gst; a.pre_chunks = x.gst_chunks; }
+      rc = dfh::groupnorm_launch(a, s);
+    }
+    void attention8(const bf16_t* Q, int ldq, const bf16_t* K, int ldk, const bf16_t* Vt, int ldvt, uint8_t* O8, const float* amax, int C,
+                    int heads, int Nq, int Nk, long vt_bstride = 0) {
+      if (rc || dry) return;
+      AttnArgs a; std::memset(&a, 0, sizeof(a));
+      a.vt_bstride = vt_bstride;
+      a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.Vt = Vt; a.ldvt = ldvt; a.O8 = O8; a.o_amax = amax; a.ldo = C;
+      a.B = B; a.H = heads; a.D = C / heads; a.Nq = Nq; a.Nk = Nk;
+      a.scale = 1.0f / sqrtf((float)a.D);
+      rc = dfh::attention_launch(a, s);
     }
     void layernorm(const bf16_t* x, const Vec& w, const Vec& b, bf16_t* y, int M, int C) {
       if (rc || dry) return;
@@ -742,14 +812,14 @@ struct dfh_unet {
       const int H = x.H, W = x.W, C = a.C, N = H * W, M = B * N;
       Tensor out = palloc(H, W, C);
       const size_t mark = temp.off;
-      Tensor gn = talloc(H, W, C);
-      groupnorm(x, nullptr, a.nw, a.nb, 1e-6f, 0, gn);
       // LayerNorm folding (gemm.h, lnfold.hip): the GEMM that produces a LayerNorm's input leaves per-row statistics of its output, the
       // projections behind the LayerNorm run on the raw rows with gamma folded into their weights and fix the rows up in their
       // epilogue -- no layernorm_kernel launch, no normalised copy of the tensor.  Falls back to the LayerNorm kernel + plain weights
       // whenever the producer ran on a kernel that writes no statistics or a consumer would split K.  DFH_LN_FOLD=0 turns it off (A/B).
       static const bool fold_off = [] { const char* e = getenv("DFH_LN_FOLD"); return e && e[0] == '0'; }();
       const bool f8 = use8(a.qk8);                    // fp8 path: LayerNorm -> e4m3 + token scales -> block-scaled MFMA GEMM
+      // round 4: proj_in, both to_out, ff.net.2 and proj_out in e4m3 as well, every operand quantised by the kernel that produces it
+      const bool f8x = f8 && a.pin8.on;
       const bool fold = u->fold_valid && !fold_off && !f8 && !dry;
       float* st = (float*)temp.alloc((size_t)M * ((C + 63) / 64) * 2 * sizeof(float));       // [C / bn][M][2], bn >= 64
       int bn = 0;
@@ -761,7 +831,19 @@ struct dfh_unet {
         return true;
       };
       Tensor h0 = talloc(H, W, C);
-      linear(gn.p, M, C, a.pin, &a.pinb, ACT_NONE, nullptr, h0.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
+      uint8_t* a8 = f8x ? (uint8_t*)temp.alloc((size_t)M * C) : nullptr;          // e4m3 operand of proj_in, then of the two to_out
+      float* am_self = f8x ? amax_self + (size_t)a.idx * B : nullptr;
+      const float* am_cross = f8x ? amax_cross + (size_t)a.idx * B : nullptr;
+      if (f8x) {
+        groupnorm8(x, 1e-6f, a8);
+        Fp8GemmArgs g = args8(a8, M, a.pin8, nullptr, h0.p);
+        g.bias = (const float*)(u->arena8 + a.pin8.boff); g.sa_mul = dfh_unet::GN_Z / 448.0f;
+        gemm8(g);
+      } else {
+        Tensor gn = talloc(H, W, C);
+        groupnorm(x, nullptr, a.nw, a.nb, 1e-6f, 0, gn);
+        linear(gn.p, M, C, a.pin, &a.pinb, ACT_NONE, nullptr, h0.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
+      }
       // --- self attention
       Tensor n1 = talloc(H, W, C);
       uint8_t* n8 = f8 ? (uint8_t*)temp.alloc((size_t)M * C) : nullptr;
@@ -797,14 +879,21 @@ struct dfh_unet {
         if (!merged) {
           if (f8) linear8(n8, s8, M, a.qk8, nullptr, ACT_NONE, qk.p);
           else linear(n1.p, M, C, a.qk, nullptr, ACT_NONE, nullptr, qk.p, 2 * C);
-          if (f8) linear8(n8, s8, M, a.v8, nullptr, ACT_NONE, vt, OUT_BF16_T, Np, N);
+          if (f8) linear8(n8, s8, M, a.v8, nullptr, ACT_NONE, vt, OUT_BF16_T, Np, N, am_self);
           else linear(n1.p, M, C, a.v, nullptr, ACT_NONE, nullptr, vt, C, OUT_BF16_T, Np, N);
         }
       }
       Tensor at = talloc(H, W, C);
-      attention(qk.p, 2 * C, qk.p + C, 2 * C, vt, Np, at.p, C, a.heads, N, N);
       Tensor h1 = talloc(H, W, C);
-      linear(at.p, M, C, a.o1, &a.o1b, ACT_NONE, h0.p, h1.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
+      if (f8x) {
+        attention8(qk.p, 2 * C, qk.p + C, 2 * C, vt, Np, a8, am_self, C, a.heads, N, N);
+        Fp8GemmArgs g = args8(a8, M, a.o18, &a.o1b, h1.p);
+        g.sA = am_self; g.sa_div = N; g.sa_mul = 1.0f / 448.0f; g.resid = h0.p; g.ld_res = C;
+        gemm8(g);
+      } else {
+        attention(qk.p, 2 * C, qk.p + C, 2 * C, vt, Np, at.p, C, a.heads, N, N);
+        linear(at.p, M, C, a.o1, &a.o1b, ACT_NONE, h0.p, h1.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
+      }
       // --- cross attention over the T text tokens
       const int Tp = (T + 7) & ~7;
       if (!try_folded({folded(h1.p, M, a.fq2, st, bn, ACT_NONE, qk.p, OUT_BF16, -1, 0)})) {
@@ -816,10 +905,37 @@ struct dfh_unet {
       }
       // text K / V^T of this layer live inside the batched projections computed once per forward
       const int XT = u->x_total;
-      attention(qk.p, C, kx + a.x_off, XT, vxt + (size_t)a.x_off * Tp, Tp, at.p, C, a.heads, N, T, (long)XT * Tp);
       Tensor h2 = talloc(H, W, C);
-      linear(at.p, M, C, a.o2, &a.o2b, ACT_NONE, h1.p, h2.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
+      if (f8x) {
+        attention8(qk.p, C, kx + a.x_off, XT, vxt + (size_t)a.x_off * Tp, Tp, a8, am_cross, C, a.heads, N, T, (long)XT * Tp);
+        Fp8GemmArgs g = args8(a8, M, a.o28, &a.o2b, h2.p);
+        g.sA = am_cross; g.sa_div = N; g.sa_mul = 1.0f / 448.0f; g.resid = h1.p; g.ld_res = C;
+        gemm8(g);
+      } else {
+        attention(qk.p, C, kx + a.x_off, XT, vxt + (size_t)a.x_off * Tp, Tp, at.p, C, a.heads, N, T, (long)XT * Tp);
+        linear(at.p, M, C, a.o2, &a.o2b, ACT_NONE, h1.p, h2.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
+      }
       // --- GEGLU feed-forward
+      if (f8x) {
+        // hidden tensor in e4m3 with one E8M0 scale per token and 32 hidden units, written by the GEGLU epilogue and consumed by ff.net.2
+        // through the MFMA's scale operand; ff.net.2's output (+ bias + h2) likewise, consumed by proj_out (+ the block's residual)
+        uint8_t* ff8 = (uint8_t*)temp.alloc((size_t)M * 4 * C);
+        uint8_t* ffsx = (uint8_t*)temp.alloc((size_t)(4 * C / 32) * M + 256);
+        uint8_t* t8 = (uint8_t*)temp.alloc((size_t)M * C);
+        uint8_t* tsx = (uint8_t*)temp.alloc((size_t)(C / 32) * M + 256);
+        layernorm8(h2.p, a.l3w, a.l3b, n8, s8, M, C);
+        Fp8GemmArgs g1 = args8(n8, M, a.ff18, &a.ff1b, ff8);
+        g1.sA = s8; g1.act = ACT_GEGLU; g1.out_mode = OUT_FP8_MX; g1.ld_out = 4 * C; g1.out_sx = ffsx;
+        gemm8(g1);
+        Fp8GemmArgs g2 = args8(ff8, M, a.ff28, &a.ff2b, t8);
+        g2.sx = ffsx; g2.resid = h2.p; g2.ld_res = C; g2.out_mode = OUT_FP8_MX; g2.ld_out = C; g2.out_sx = tsx;
+        gemm8(g2);
+        Fp8GemmArgs g3 = args8(t8, M, a.pout8, &a.poutb, out.p);
+        g3.sx = tsx; g3.resid = x.p; g3.ld_res = C;
+        gemm8(g3);
+        temp.off = mark;
+        return out;
+      }
       Tensor ff = talloc(H, W, 4 * C);
       if (!try_folded({folded(h2.p, M, a.fff1, st, bn, ACT_GEGLU, ff.p, OUT_BF16, -1, 0)})) {
         if (f8) { layernorm8(h2.p, a.l3w, a.l3b, n8, s8, M, C); linear8(n8, s8, M, a.ff18, &a.ff1b, ACT_GEGLU, ff.p); }
@@ -849,11 +965,19 @@ struct dfh_unet {
   // Per-run constants of a sampling loop (reference DiFashion/models/difashion.py:340-357: the prompt states are fixed for the run;
   // :456: the timesteps are the schedule's): the cross-attention K / V^T of every transformer block and the time-embedding rows
   // (all time_emb_proj outputs) per schedule entry, computed once by run_cache() into a caller-owned buffer.
-  struct RunCache { const bf16_t* kx = nullptr; const bf16_t* vxt = nullptr; const float* temb_row = nullptr; };
+  struct RunCache { const bf16_t* kx = nullptr; const bf16_t* vxt = nullptr; const float* temb_row = nullptr; const float* xamax = nullptr; };
+  // fp8 walk: the largest |V| of every layer's cross-attention per batch element, [n_att][B] floats behind the time-embedding table
+  size_t cache_xamax_bytes(int B) const { return fp8 ? (((size_t)n_att * B * 4 + 255) & ~(size_t)255) : 0; }
   static size_t cache_kx_bytes(const dfh_unet& u, int B) { return ((size_t)B * u.cfg.text_len * u.x_total * 2 + 255) & ~(size_t)255; }
   static size_t cache_vxt_bytes(const dfh_unet& u, int B) { return ((size_t)B * u.x_total * ((u.cfg.text_len + 7) & ~7) * 2 + 255) & ~(size_t)255; }
   size_t run_cache_bytes(int B, int n_t) const {
-    return cache_kx_bytes(*this, B) + cache_vxt_bytes(*this, B) + (((size_t)n_t * temb_total * 4 + 255) & ~(size_t)255);
+    return cache_kx_bytes(*this, B) + cache_vxt_bytes(*this, B) + (((size_t)n_t * temb_total * 4 + 255) & ~(size_t)255) + cache_xamax_bytes(B);
+  }
+  // amax_cross[layer][b] = max |V^T| of the layer's slice of the batched text V^T
+  int cross_amax(const bf16_t* vxt, int B, float* out, hipStream_t s) {
+    const int Tp = (cfg.text_len + 7) & ~7;
+    // the pad columns T .. Tp - 1 of V^T are never written: only the T real keys count
+    return dfh::amax_slabs_launch(vxt, (long)x_total * Tp, Tp, cfg.text_len, slab_row0(), slab_rows(), out, n_att, B, s);
   }
 
   int run(const void* sample, int sample_bf16, const float* timestep, const void* ehs, int ehs_bf16, float* out, int B,
@@ -913,6 +1037,16 @@ struct dfh_unet {
     } else {
       kx = const_cast<bf16_t*>(rcache->kx); vxt = const_cast<bf16_t*>(rcache->vxt);
       dfh::census(dfh::CK_TEXT_CACHED);
+    }
+    if (fp8) {
+      r.amax_self = (float*)r.persist.alloc((size_t)n_att * B * 4);
+      float* xam = (float*)r.persist.alloc((size_t)n_att * B * 4);
+      r.amax_cross = xam;
+      if (!dry && !r.rc) {
+        if (hipMemsetAsync(r.amax_self, 0, (size_t)n_att * B * 4, s) != hipSuccess) { dfh::set_error("hipMemsetAsync failed"); return -2; }
+        if (x_cached && rcache->xamax) r.amax_cross = rcache->xamax;
+        else r.rc = cross_amax(vxt, B, xam, s);
+      }
     }
     Tensor x = r.palloc(S, S, conv_in.cin);   // in_channels padded to a multiple of 8
     if (!dry && !r.rc) r.rc = dfh::nchw_to_nhwc_launch(sample, sample_bf16, x.p, B, cfg.in_channels, S * S, s);
@@ -984,11 +1118,13 @@ struct dfh_unet {
     bf16_t* kx = (bf16_t*)cache;
     bf16_t* vxt = (bf16_t*)((char*)cache + cache_kx_bytes(*this, B));
     float* table = (float*)((char*)cache + cache_kx_bytes(*this, B) + cache_vxt_bytes(*this, B));
+    float* xamax = (float*)((char*)table + (((size_t)n_t * temb_total * 4 + 255) & ~(size_t)255));
     bf16_t* ehs16 = (bf16_t*)tmp.alloc((size_t)B * T * X * 2);
     if (ehs_bf16) (void)hipMemcpyAsync(ehs16, ehs, (size_t)B * T * X * 2, hipMemcpyDeviceToDevice, s);
     else r.rc = dfh::cast_f32_to_bf16_launch((const float*)ehs, ehs16, (long)B * T * X, s);
     r.linear(ehs16, B * T, X, kx_all, nullptr, ACT_NONE, nullptr, kx, x_total);
     r.linear(ehs16, B * T, X, vx_all, nullptr, ACT_NONE, nullptr, vxt, x_total, OUT_BF16_T, Tp, T);
+    if (fp8 && !r.rc) r.rc = cross_amax(vxt, B, xamax, s);
     bf16_t* tsin = (bf16_t*)tmp.alloc((size_t)B * c0 * 2);
     bf16_t* e1 = (bf16_t*)tmp.alloc((size_t)B * temb * 2);
     bf16_t* e2 = (bf16_t*)tmp.alloc((size_t)B * temb * 2);

@@ -189,9 +189,13 @@ class UNet2DConditionModel(nn.Module):
         return None
 
     def enable_fp8(self, on: bool = True):
-        """Run the LayerNorm-fed projections of every transformer block (attn1 q|k, v, attn2 q, GEGLU input) in OCP e4m3 on the
-        block-scaled MFMA: per-token activation scales, per-output-channel weight scales, fp32 accumulation (csrc/gemm_fp8.hip).
-        Sampling path only -- the training forward keeps bf16.  Takes effect at the next forward (the context is rebuilt)."""
+        """BASELINE configs[4]: run every linear / 1x1 convolution of every transformer block -- proj_in, attn1 q|k and v, both
+        to_out, attn2 q, the GEGLU pair ff.net.0 / ff.net.2 and proj_out -- in OCP e4m3 on the block-scaled MFMA
+        (csrc/gemm_fp8.hip), fp32 accumulation, per-output-channel weight scales.  Every activation operand is quantised by the
+        kernel that produces it: LayerNorm (a scale per token), GroupNorm (the normalised value under a static scale, its affine
+        folded into proj_in), the attention epilogues (per image, against the maximum of V), the GEGLU / ff.net.2 epilogues (E8M0
+        block scales per 32 channels, consumed by the MFMA's scale operand).  The 3x3 convolutions and the attention products stay
+        bf16.  Sampling path only -- the training forward keeps bf16.  Takes effect at the next forward (the context is rebuilt)."""
         self.fp8 = bool(on)
         return self
 

@@ -308,13 +308,35 @@ int dfh_gemm_batched(const dfh_gemm_desc* d, int nbatch, long a_bs, long w_bs, l
  * df.py:249-253,518-523) when the caller opts in.
  *   dfh_quantize_rows_fp8 : bf16 [R][K] (row stride ldx) -> e4m3 [R][K] + scale[R] = amax / 448 (weights: one scale per output channel)
  *   dfh_layernorm_fp8     : dfh_layernorm whose output is quantised per token: q [M][C] e4m3, scale [M]
- *   dfh_gemm_fp8          : out = epilogue(sA[m] * sW[n] * sum_k A[m][k] W[n][k]); K % 64 == 0; act 0 or 4 (GEGLU, packed rows);
- *                           out_mode 0 (bf16 [M][ld_out]) or 1 (bf16 transposed per batch of rows_per_b rows) */
+ *   dfh_gemm_fp8          : out = epilogue(sa(m) * sW[n] * sum_k 2^(sx[k / 32][m] - 127) A[m][k] W[n][k]); K % 64 == 0; act 0 or 4
+ *                           (GEGLU, packed rows).  Activation scales, any combination: sA (a float per group of sa_div rows: per token,
+ *                           or per image), sa_mul (a constant), sx (E8M0 block scales per row and 32 contraction elements, the
+ *                           hardware's scale operand; layout [K / 32][M] bytes).  out_mode 0 (bf16 [M][ld_out]), 1 (bf16 transposed per
+ *                           batch of rows_per_b rows; amax != NULL: amax[b] = max(amax[b], max |out| of batch element b), the
+ *                           caller zeroes it) or 4 (e4m3 [M][ld_out] + E8M0 block scales of the OUTPUT in out_sx [N_out / 32][M]:
+ *                           the operand of the next fp8 GEMM, e.g. the GEGLU hidden tensor for ff.net.2).  Zero-initialise the descriptor.
+ *   dfh_groupnorm_fp8     : GroupNorm WITHOUT its affine, as e4m3: q = e4m3(clamp((x - mean) * rstd * q_mul)) -- the operand of an fp8
+ *                           proj_in whose weights carry gamma (and whose bias carries W . beta): a static scale, no statistics of q needed
+ *   dfh_attention_fp8out  : dfh_attention whose output leaves as e4m3 scaled by 448 / v_amax[b] (|O| <= max |V| of the batch element)
+ *   dfh_amax_slabs        : out[s][b] = max |x| over rows row0[s] .. + nrows[s] of batch element b of a bf16 [B][.][ld] tensor */
+typedef struct dfh_gemm_fp8_desc {
+  const void* A; int lda;                    /* e4m3 [M][lda]; lda 0 = K */
+  const float* sA; int sa_div; float sa_mul;
+  const void* sx;
+  const void* W; const float* sW;            /* e4m3 [N][K], one scale per output channel */
+  int M, N, K;
+  const float* bias; const void* resid; int ld_res; int act;
+  void* out; int ld_out; int out_mode; void* out_sx; int rows_per_b; float* amax;
+  const void* zero_page;
+} dfh_gemm_fp8_desc;
 int dfh_quantize_rows_fp8(const void* x, int ldx, void* q, float* scale, int R, int K, void* stream);
 int dfh_layernorm_fp8(const void* x, const float* gamma, const float* beta, void* q, float* scale, int M, int C, float eps, void* stream);
-int dfh_gemm_fp8(const void* A, const float* sA, const void* W, const float* sW, int M, int N, int K, const float* bias,
-                 const void* resid, int ld_res, int act, void* out, int ld_out, int out_mode, int rows_per_b, const void* zero_page,
-                 void* stream);
+int dfh_gemm_fp8(const dfh_gemm_fp8_desc* d, void* stream);
+int dfh_groupnorm_fp8(const void* src, int batch, int HW, int C, int groups, float eps, float q_mul, void* q, float* partial, void* stream);
+int dfh_attention_fp8out(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O8, int ldo, const float* v_amax,
+                         int batch, int heads, int head_dim, int Nq, int Nk, float scale, void* stream);
+int dfh_amax_slabs(const void* x, long bstride, int ld, int cols, const int* row0, const int* nrows, float* out, int nslab, int batch,
+                   void* stream);
 /* softmax(Q K^T * scale) V; Q [B][Nq][ldq], K [B][Nk][ldk], Vt [B][H*D][ldvt] (V transposed), O [B][Nq][ldo]; bf16 */
 int dfh_attention(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
                   int batch, int heads, int head_dim, int Nq, int Nk, float scale, void* stream);

@@ -35,14 +35,15 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header_field_order():
     src = open(os.path.join(ROOT, "include", "difashion_hip.h")).read()
-    body = re.search(r"typedef struct dfh_gemm_desc \{(.*?)\} dfh_gemm_desc;", src, flags=re.S).group(1)
-    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    fields = []
-    for decl in body.split(";"):
-        decl = decl.strip()
-        if decl:
-            fields += [f.strip().lstrip("*") for f in re.sub(r"^(const\s+)?[a-z_0-9]+\*?\s+", "", decl).split(",")]
-    assert fields == [f[0] for f in _lib.GemmDesc._fields_]
+    for name, mirror in (("dfh_gemm_desc", _lib.GemmDesc), ("dfh_gemm_fp8_desc", _lib.Fp8GemmDesc)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), src, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                fields += [f.strip().lstrip("*") for f in re.sub(r"^(const\s+)?[a-z_0-9]+\*?\s+", "", decl).split(",")]
+        assert fields == [f[0] for f in mirror._fields_], name
     assert C.sizeof(_lib.StepCoef) == 28 and C.sizeof(_lib.ProfClass) == 64
 
 

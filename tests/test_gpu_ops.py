@@ -807,7 +807,22 @@ def test_layernorm_fp8_matches_layernorm_then_quantise(M, C):
     torch.testing.assert_close(sc, bf(ref).float().abs().amax(dim=1) / 448.0, rtol=2e-2, atol=1e-6)
 
 
-def _fp8_gemm(x, w, bias=None, resid=None, act=0, out_mode=0, rows_per_b=0):
+def _fp8_desc(**kw):
+    """Zero-initialised dfh_gemm_fp8_desc with the given fields; tensors are kept alive on the returned object."""
+    d = _lib.Fp8GemmDesc()
+    d.keep = []
+    for k, v in kw.items():
+        if torch.is_tensor(v):
+            d.keep.append(v)
+            v = v.data_ptr()
+        setattr(d, k, v)
+    z = gu.zero_page()
+    d.keep.append(z)
+    d.zero_page = z.data_ptr()
+    return d
+
+
+def _fp8_gemm(x, w, bias=None, resid=None, act=0, out_mode=0, rows_per_b=0, amax=None):
     """x [M][K], w [N][K] bf16 -> quantised by the library -> dfh_gemm_fp8; returns (out, dequantised x, dequantised w)."""
     M, K = x.shape
     N = w.shape[0]
@@ -823,11 +838,171 @@ def _fp8_gemm(x, w, bias=None, resid=None, act=0, out_mode=0, rows_per_b=0):
     else:
         out = torch.full((M, n_out), float("nan"), dtype=torch.bfloat16, device=DEV)
         ld = n_out
-    z = gu.zero_page()
-    _lib.call("dfh_gemm_fp8", _lib.ptr(xq), _lib.ptr(xs), _lib.ptr(wq), _lib.ptr(ws), M, N, K, _lib.ptr(bias), _lib.ptr(resid), N,
-              act, _lib.ptr(out), ld, out_mode, rows_per_b, _lib.ptr(z), gu.stream())
+    kw = dict(A=xq, sA=xs, W=wq, sW=ws, M=M, N=N, K=K, ld_res=N, act=act, out=out, ld_out=ld, out_mode=out_mode, rows_per_b=rows_per_b)
+    if bias is not None:
+        kw["bias"] = bias
+    if resid is not None:
+        kw["resid"] = resid
+    if amax is not None:
+        kw["amax"] = amax
+    d = _fp8_desc(**kw)
+    _lib.call("dfh_gemm_fp8", C.byref(d), gu.stream())
     torch.cuda.synchronize()
     return out, _fp8_dequant(xq, xs), _fp8_dequant(wq, ws)
+
+
+def _e4m3_random(shape, seed):
+    """Random e4m3 bytes (finite: no NaN pattern 0x7f / 0xff) and their float values."""
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randint(0, 256, shape, generator=g, dtype=torch.int32)
+    q = torch.where((q & 0x7f) == 0x7f, q - 9, q).to(torch.uint8).to(DEV)
+    return q, q.view(torch.float8_e4m3fn).float()
+
+
+def _mx_dequant(q, sx):
+    """q [M][K] e4m3 bytes, sx [K / 32][M] E8M0 bytes -> fp32 values."""
+    M, K = q.shape
+    scale = torch.exp2(sx.float() - 127.0).t().contiguous()              # [M][K / 32]
+    return q.view(torch.float8_e4m3fn).float() * scale.repeat_interleave(32, dim=1)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 160, 64), (384, 320, 320), (1000, 128, 256), (16384, 320, 1280), (4096, 1280, 5120), (68, 64, 128)])
+def test_gemm_fp8_block_scaled_operand(M, N, K):
+    """The E8M0 block scales of the activations go through the MFMA's own scale operand (one byte per lane = per row and 32 contraction
+    elements, staged per k-step by LDS-DMA from the [K / 32][M] layout).  Random e4m3 bytes and random scales 2^-6 .. 2^6 that differ
+    for every (row, block): a scale applied to the wrong row, the wrong k-half or the wrong k-step cannot pass.  Exact arithmetic apart
+    from accumulation order and the bf16 output rounding."""
+    xq, xf = _e4m3_random((M, K), 101)
+    wq, wf = _e4m3_random((N, K), 102)
+    xf, wf = xf * 2.0 ** -4, wf * 2.0 ** -6
+    sx = torch.randint(121, 134, (K // 32, M), generator=torch.Generator().manual_seed(103), dtype=torch.int32).to(torch.uint8).to(DEV)
+    ws = torch.rand(N, generator=torch.Generator().manual_seed(104)).to(DEV) * 2.0 ** -6 + 2.0 ** -7
+    bias, resid = rnd(N, seed=105), bf(rnd(M, N, seed=106))
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    d = _fp8_desc(A=xq, sx=sx, sa_mul=2.0 ** -4, W=wq, sW=ws, M=M, N=N, K=K, bias=bias, resid=resid, ld_res=N, out=out, ld_out=N)
+    _lib.call("dfh_gemm_fp8", C.byref(d), gu.stream())
+    torch.cuda.synchronize()
+    xd = _mx_dequant(xq, sx) * 2.0 ** -4
+    ref = (xd.double() @ (wq.view(torch.float8_e4m3fn).double() * ws.double()[:, None]).t()).float() + bias + resid.float()
+    gu.assert_close_bf16(out, ref, f"fp8 MX gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,C", [(512, 64), (4096, 320), (1040, 640)])
+def test_gemm_fp8_geglu_writes_the_block_scaled_hidden_tensor_and_ff2_reads_it(M, C):
+    """ff.net.0 -> GEGLU with the hidden tensor leaving as e4m3 + one E8M0 scale per token and 32 hidden units (OUT_FP8_MX), then
+    ff.net.2 consuming exactly that pair.  The dequantised hidden tensor must sit within the e4m3 rounding of the fp32 GEGLU of the same
+    (dequantised) operands, every scale must be the smallest power of two that keeps its block inside +-448, and the second GEMM must be
+    exact on what the first one wrote."""
+    x = bf(rnd(M, C, seed=88))
+    w = rnd(8 * C, C, seed=89, scale=0.1)
+    b = rnd(8 * C, seed=90, scale=0.5)
+    wp = torch.empty((8 * C, C), dtype=torch.bfloat16, device=DEV)
+    bp = torch.empty(8 * C, dtype=torch.float32, device=DEV)
+    _lib.call("dfh_pack_matrix", _lib.ptr(w), _lib.ptr(wp), 8 * C, C, C, 0, 0, 1, gu.stream())       # value / gate rows interleaved
+    _lib.call("dfh_pack_vector", _lib.ptr(b), _lib.ptr(bp), 8 * C, 0, 1, 0, gu.stream())
+    xq, wq = torch.empty((M, C), dtype=torch.uint8, device=DEV), torch.empty((8 * C, C), dtype=torch.uint8, device=DEV)
+    xs, ws = torch.empty(M, device=DEV), torch.empty(8 * C, device=DEV)
+    _lib.call("dfh_quantize_rows_fp8", _lib.ptr(x), C, _lib.ptr(xq), _lib.ptr(xs), M, C, gu.stream())
+    _lib.call("dfh_quantize_rows_fp8", _lib.ptr(wp), C, _lib.ptr(wq), _lib.ptr(ws), 8 * C, C, gu.stream())
+    import ctypes
+    hid = torch.full((M, 4 * C), 0x7f, dtype=torch.uint8, device=DEV)
+    hsx = torch.zeros((4 * C // 32, M), dtype=torch.uint8, device=DEV)
+    d = _fp8_desc(A=xq, sA=xs, W=wq, sW=ws, M=M, N=8 * C, K=C, bias=bp, act=4, out=hid, ld_out=4 * C, out_mode=4, out_sx=hsx)
+    _lib.call("dfh_gemm_fp8", ctypes.byref(d), gu.stream())
+    torch.cuda.synchronize()
+    xd, wd = _fp8_dequant(xq, xs), _fp8_dequant(wq, ws)
+    wdv = wd.view(-1, 2, 16, C)
+    wv, wg = wdv[:, 0].reshape(-1, C), wdv[:, 1].reshape(-1, C)
+    ref = (xd @ wv.T + b[:4 * C]) * F.gelu(xd @ wg.T + b[4 * C:])
+    got = _mx_dequant(hid, hsx)
+    assert not torch.isnan(got).any()
+    assert gu.rel_err(got, ref) <= 4e-2                                   # 3 mantissa bits
+    blk = ref.abs().view(M, -1, 32).amax(dim=2)                           # the scale each block should carry
+    want = torch.clamp(torch.ceil(torch.log2(blk / 448.0)) + 127, 1, 253)
+    have = hsx.float().t()
+    assert float((have != want).float().mean()) <= 2e-3                  # an amax that sits within rounding of a power-of-two boundary may tip
+    assert float(got.abs().view(M, -1, 32).amax(dim=2).div(torch.exp2(have - 127)).max()) <= 448.0
+    # ff.net.2 on that pair: + bias + residual, bf16 out AND e4m3 + E8M0 out (the operand of proj_out)
+    w2 = bf(rnd(C, 4 * C, seed=91, scale=0.05))
+    w2q, w2s = torch.empty((C, 4 * C), dtype=torch.uint8, device=DEV), torch.empty(C, device=DEV)
+    _lib.call("dfh_quantize_rows_fp8", _lib.ptr(w2), 4 * C, _lib.ptr(w2q), _lib.ptr(w2s), C, 4 * C, gu.stream())
+    b2, res = rnd(C, seed=92), bf(rnd(M, C, seed=93))
+    out = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    d2 = _fp8_desc(A=hid, sx=hsx, W=w2q, sW=w2s, M=M, N=C, K=4 * C, bias=b2, resid=res, ld_res=C, out=out, ld_out=C)
+    _lib.call("dfh_gemm_fp8", ctypes.byref(d2), gu.stream())
+    ref2 = got @ _fp8_dequant(w2q, w2s).T + b2 + res.float()
+    gu.assert_close_bf16(out, ref2, "ff2 on the block-scaled hidden tensor")
+    if C % 32 == 0:
+        o8 = torch.full((M, C), 0x7f, dtype=torch.uint8, device=DEV)
+        osx = torch.zeros((C // 32, M), dtype=torch.uint8, device=DEV)
+        d3 = _fp8_desc(A=hid, sx=hsx, W=w2q, sW=w2s, M=M, N=C, K=4 * C, bias=b2, resid=res, ld_res=C, out=o8, ld_out=C, out_mode=4, out_sx=osx)
+        _lib.call("dfh_gemm_fp8", ctypes.byref(d3), gu.stream())
+        torch.cuda.synchronize()
+        assert gu.rel_err(_mx_dequant(o8, osx), ref2) <= 4e-2
+
+
+def test_gemm_fp8_transposed_output_tracks_the_maximum_per_batch_element():
+    """The V projection's epilogue leaves max |V| per batch element (atomicMax on the float bits): the bound the attention output is
+    quantised against.  Batches of 192 rows (whole 32-row wave blocks: one atomic per wave) and of 200 rows (blocks straddle images: one
+    per lane)."""
+    for rows in (192, 200):
+        B, N, K = 3, 320, 320
+        x, w = bf(rnd(B * rows, K, seed=91)), bf(rnd(N, K, seed=92, scale=0.1))
+        x[rows:2 * rows] *= 3.0
+        am = torch.zeros(B, device=DEV)
+        out, xd, wd = _fp8_gemm(x, w, out_mode=1, rows_per_b=rows, amax=am)
+        torch.cuda.synchronize()
+        assert torch.equal(am, out.float().abs().amax(dim=(1, 2)))
+
+
+@pytest.mark.parametrize("B,HW,Cc", [(2, 4096, 320), (3, 1024, 640), (4, 256, 1280), (16, 64, 1280), (2, 16, 64)])
+def test_groupnorm_fp8_output_is_the_normalised_value_under_the_static_scale(B, HW, Cc):
+    """proj_in's e4m3 operand: the GroupNorm kernels (two-kernel path, one-slab path) emit (x - mean) * rstd * q_mul as e4m3 -- no
+    affine (the consumer's weights carry gamma), no statistics of the output needed (static scale).  Dequantised it must sit within the
+    e4m3 rounding of F.group_norm without affine."""
+    x = bf(rnd(B, HW, Cc, seed=140) * 2.0 + 0.7)
+    q = torch.full((B, HW, Cc), 0x7f, dtype=torch.uint8, device=DEV)
+    partial = torch.zeros(B * 64 * 64 * 2, device=DEV)
+    _lib.call("dfh_groupnorm_fp8", _lib.ptr(x), B, HW, Cc, 32, 1e-6, 14.0, _lib.ptr(q), _lib.ptr(partial), gu.stream())
+    torch.cuda.synchronize()
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, eps=1e-6).permute(0, 2, 1)
+    got = q.view(torch.float8_e4m3fn).float() / 14.0
+    assert not torch.isnan(got).any() and gu.rel_err(got, ref) <= 4e-2
+
+
+@pytest.mark.parametrize("B,H,D,Nq,Nk", [(2, 8, 40, 4096, 4096), (2, 8, 40, 1024, 77), (3, 8, 80, 1024, 1024), (2, 8, 160, 256, 256), (2, 8, 160, 64, 77),
+                                         (2, 2, 32, 16, 16)])
+def test_attention_fp8_output_is_scaled_by_the_maximum_of_v(B, H, D, Nq, Nk):
+    """to_out's e4m3 operand, written by the attention epilogues (32x32x16 kernel, the short-key kernel, the 16x16x32 kernel): the
+    normalised output times 448 / max |V| of the batch element.  Against the bf16 output of the same launch."""
+    Cc = H * D
+    q, k = bf(rnd(B, Nq, Cc, seed=150)), bf(rnd(B, Nk, Cc, seed=151))
+    Np = (Nk + 7) // 8 * 8
+    vt = torch.zeros(B, Cc, Np, dtype=torch.bfloat16, device=DEV)
+    vt[:, :, :Nk] = bf(rnd(B, Cc, Nk, seed=152))
+    vt[1] *= 5.0
+    am = vt.float().abs().amax(dim=(1, 2)).contiguous()
+    o16 = torch.empty(B, Nq, Cc, dtype=torch.bfloat16, device=DEV)
+    o8 = torch.full((B, Nq, Cc), 0x7f, dtype=torch.uint8, device=DEV)
+    args = (_lib.ptr(q), Cc, _lib.ptr(k), Cc, _lib.ptr(vt), Np)
+    _lib.call("dfh_attention", *args, _lib.ptr(o16), Cc, B, H, D, Nq, Nk, D ** -0.5, gu.stream())
+    _lib.call("dfh_attention_fp8out", *args, _lib.ptr(o8), Cc, _lib.ptr(am), B, H, D, Nq, Nk, D ** -0.5, gu.stream())
+    torch.cuda.synchronize()
+    got = o8.view(torch.float8_e4m3fn).float() * (am / 448.0)[:, None, None]
+    assert not torch.isnan(got).any() and gu.rel_err(got, o16.float()) <= 4e-2
+
+
+def test_amax_slabs():
+    B, rows, ld = 3, 640, 80
+    x = bf(rnd(B, rows, ld, seed=160))
+    x[:, :, 77:] = float("nan")                      # pad columns (77 text tokens in rows of 80): never read
+    row0 = torch.tensor([0, 64, 320], dtype=torch.int32, device=DEV)
+    nrows = torch.tensor([64, 256, 320], dtype=torch.int32, device=DEV)
+    out = torch.zeros(3, B, device=DEV)
+    _lib.call("dfh_amax_slabs", _lib.ptr(x), rows * ld, ld, 77, _lib.ptr(row0), _lib.ptr(nrows), _lib.ptr(out), 3, B, gu.stream())
+    torch.cuda.synchronize()
+    want = torch.stack([x[:, r:r + n, :77].float().abs().amax(dim=(1, 2)) for r, n in ((0, 64), (64, 256), (320, 320))])
+    assert torch.equal(out, want)
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 160, 64), (300, 320, 320), (1000, 640, 128), (4096, 2560, 320), (77, 24, 192), (12000, 960, 320)])

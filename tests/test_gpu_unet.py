@@ -128,6 +128,24 @@ def test_run_cache_reproduces_the_uncached_forward_bit_for_bit():
         m.end_run()
 
 
+def test_prepare_run_with_a_batch_above_max_batch_grows_the_context():
+    """Two outfits x 4 items x 3 guidance branches = 24 rows against max_batch = 16 (advisor finding, round 3): prepare_run must grow the
+    context the way forward() does instead of failing in dfh_unet_run_cache, and the cached steps must equal the plain forward."""
+    from difashion_amd import _lib
+    cfg = unet_ref.TINY
+    m = hip_unet(cfg, unet_ref.init_params(cfg, seed=8), max_batch=4)
+    x, e = inputs(cfg, 6, 19)
+    x, e = x.to(DEV), e.to(DEV)
+    with torch.no_grad():
+        m.prepare_run(e, [981, 501])                  # 6 rows > max_batch = 4
+        assert m.max_batch == 6
+        _lib.census_reset()
+        a = m(x, 981, e).sample
+        assert _lib.census()["text_cached"] == 1
+        m.end_run()
+        assert torch.equal(a, m(x, 981, e).sample)
+
+
 def test_batch_rows_independent_and_bf16_inputs():
     cfg = unet_ref.TINY
     m = hip_unet(cfg, unet_ref.init_params(cfg, seed=5))
@@ -267,7 +285,10 @@ def test_unet_sd15_full_size_batch16_matches_oracle():
     cen8 = _lib.census()
     e8 = rel_err(out8.cpu(), ref)
     print("sd15 B=16 fp8", f"{e8:.2e}", {k: v for k, v in cen8.items() if v})
-    assert e8 <= 6e-2 and cen8["gemm_fp8"] > 0
+    # BASELINE configs[4] as named: per transformer block proj_in, q|k, v, to_out, q (cross), to_out (cross), ff.net.0, ff.net.2 and
+    # proj_out on gemm_fp8_kernel = 9 x 16 blocks; no LayerNorm-fed bf16 linear is left, the 3x3 convs stay bf16
+    assert e8 <= 6e-2 and cen8["gemm_fp8"] == 9 * 16, cen8
+    assert cen8["gemm_lean"] + cen8["gemm_8wave"] + cen8["gemm_row"] < cen["gemm_lean"] + cen["gemm_8wave"] + cen["gemm_row"], (cen, cen8)
 
 
 @pytest.mark.timeout(900)
@@ -287,6 +308,18 @@ def test_unet_sd2base_full_size_matches_oracle():
     err = rel_err(out.cpu(), ref)
     print("sd2base", f"{err:.2e}")
     assert err <= TOL
+    # fp8 leg (BASELINE configs[4]) on the linear-projection variant: head dims 64 (5 / 10 / 20 heads), cross dim 1024
+    from difashion_amd import _lib
+    m.enable_fp8()
+    with torch.no_grad():
+        m(x.to(DEV), t.to(DEV), e.to(DEV))
+        torch.cuda.synchronize()
+        _lib.census_reset()
+        out8 = m(x.to(DEV), t.to(DEV), e.to(DEV)).sample
+        torch.cuda.synchronize()
+    e8 = rel_err(out8.cpu(), ref)
+    print("sd2base fp8", f"{e8:.2e}")
+    assert e8 <= 6e-2 and _lib.census()["gemm_fp8"] == 9 * 16
 
 
 @pytest.mark.parametrize("name,cfg", [("tiny", unet_ref.TINY), ("tiny_sd2", unet_ref.UNetConfig(
@@ -309,5 +342,21 @@ def test_fp8_linears_vs_oracle(name, cfg):
         y16b = m(x.to(DEV), t, e.to(DEV)).sample
     e16, e8, d = rel_err(y16.cpu(), ref), rel_err(y8.cpu(), ref), rel_err(y8, y16)
     print(name, f"bf16 vs oracle {e16:.2e}, fp8 vs oracle {e8:.2e}, fp8 vs bf16 {d:.2e}")
-    assert e8 <= 6e-2 and d <= 5e-2 and d > 0.0
+    assert e8 <= 6e-2 and d <= 5.5e-2 and d > 0.0
     assert torch.equal(y16, y16b)
+
+
+def test_fp8_walk_with_the_run_cache_equals_the_plain_fp8_forward():
+    """The fp8 walk under prepare_run: the cross-attention maxima of V (what the e4m3 attention output is scaled by) come from the run
+    cache instead of being recomputed -- same values, so the cached step equals the plain fp8 forward bit for bit."""
+    cfg = unet_ref.TINY
+    m = hip_unet(cfg, unet_ref.init_params(cfg, seed=9, w_std=0.05, affine_jitter=0.1), max_batch=4)
+    m.enable_fp8()
+    x, e = inputs(cfg, 4, 17)
+    x, e = x.to(DEV), e.to(DEV)
+    with torch.no_grad():
+        plain = m(x, 501, e).sample
+        m.prepare_run(e, [981, 501])
+        cached = m(x, 501, e).sample
+        m.end_run()
+    assert torch.equal(plain, cached)

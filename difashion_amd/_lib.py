@@ -190,7 +190,10 @@ SIGNATURES = {
     "dfh_groupnorm_fp8": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "dfh_attention_fp8out": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "dfh_amax_slabs": (_i, [_vp, C.c_long, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "dfh_attention_fp8": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "dfh_attn_scales": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dfh_unet_enable_fp8": (_i, [_vp]),
+    "dfh_unet_enable_fp8_attention": (_i, [_vp, _i]),
     "dfh_unet_arena8_bytes": (_sz, [_vp]),
     "dfh_unet_bind_fp8": (_i, [_vp, _vp]),
     "dfh_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),

@@ -31,7 +31,7 @@ static long g_census[CK_COUNT] = {0};
 void census(int id) { if (id >= 0 && id < CK_COUNT) ++g_census[id]; }
 static const char* const kCensusNames[CK_COUNT] = {"gemm_wide", "gemm_8wave", "gemm_lean", "gemm_other", "gemm_row", "splitk_reduce",
     "splitk_fused", "gstat_written", "gn_pre", "gn_stats", "gn_small", "gn_mid", "layernorm", "ln_folded", "attention_x32", "attention_16",
-    "gemm_fp8", "text_cached", "conv_phase", "conv_wino", "gemm_rows_geglu"};
+    "gemm_fp8", "text_cached", "conv_phase", "conv_wino", "gemm_rows_geglu", "attention_fp8"};
 
 struct ProfRec { hipEvent_t e0, e1; int cls; double flops, bytes; };
 static std::vector<ProfRec> g_recs;
@@ -444,6 +444,20 @@ int dfh_attention_fp8out(const void* Q, int ldq, const void* K, int ldk, const v
   a.O8 = (uint8_t*)O8; a.ldo = ldo; a.o_amax = v_amax; a.B = batch; a.H = heads; a.D = head_dim; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
   DFH_REQUIRE(O8 && v_amax, "fp8 attention output needs O8 and the per-batch maxima of V");
   return dfh::attention_launch(a, (hipStream_t)stream);
+}
+int dfh_attention_fp8(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo, const float* rq,
+                      const float* rk, const float* rv, const float* hs, int batch, int heads, int head_dim, int Nq, int Nk, float scale,
+                      void* stream) {
+  AttnArgs a; std::memset(&a, 0, sizeof(a));
+  a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.Vt = (const bf16_t*)Vt; a.ldvt = ldvt;
+  a.O = (bf16_t*)O; a.ldo = ldo; a.B = batch; a.H = heads; a.D = head_dim; a.Nq = Nq; a.Nk = Nk; a.scale = scale;
+  a.f8_rq = rq; a.f8_rk = rk; a.f8_rv = rv; a.f8_hs = hs;
+  DFH_REQUIRE(rq && rk && rv && hs, "fp8 attention needs its operand factors");
+  DFH_REQUIRE((head_dim == 40 || head_dim == 80 || head_dim == 160) && Nk >= 64 && Nk % 64 == 0, "fp8 attention: head dim 40 / 80 / 160, whole 64-key tiles");
+  return dfh::attention_launch(a, (hipStream_t)stream);
+}
+int dfh_attn_scales(const void* wf, const float* bf, int C, int heads, float* rq, float* rk, float* rv, float* hs, void* stream) {
+  return dfh::attn_scales_launch((const bf16_t*)wf, bf, C, heads, rq, rk, rv, hs, (hipStream_t)stream);
 }
 int dfh_amax_slabs(const void* x, long bstride, int ld, int cols, const int* row0, const int* nrows, float* out, int nslab, int batch,
                    void* stream) {

@@ -11,6 +11,10 @@ struct AttnArgs {
   // 448 / o_amax[b]: the attention output is a convex combination of the rows of V, so |O| <= max |V| of the batch element, which
   // the V projection's epilogue tracked (gemm.h Fp8GemmArgs::amax).  The consumer multiplies o_amax[b] / 448 back in.
   uint8_t* O8; const float* o_amax;
+  // fp8 attention products (attention_fp8.hip; BASELINE configs[4]): static per-channel operand factors [H * D] -- Q is quantised as
+  // q * f8_rq, K as k * f8_rk (f8_rq * f8_rk = 1 / f8_hs[h] for every channel of head h), V as v * f8_rv -- and the per-head factor the
+  // softmax scale absorbs, all derived from the projection weights (attn_scales_launch).  Null: the bf16 kernels.
+  const float* f8_rq; const float* f8_rk; const float* f8_rv; const float* f8_hs;
   int B, H, D, Nq, Nk;
   float scale;                  // D^-0.5
   float* lse;                   // optional [B][H][Nq] fp32: log2-domain log-sum-exp (m + log2 l) of the scaled scores, for backward
@@ -55,6 +59,8 @@ DFH_DEVICE float attn_qmul(const AttnArgs& a, int b) {
 
 namespace dfh {
 int attention_launch(const AttnArgs& a, hipStream_t stream);
+// operand factors of the fp8 attention from the LayerNorm-folded projection weights wf [3C][C] (rows q | k | v) and biases bf [3C]
+int attn_scales_launch(const bf16_t* wf, const float* bf, int C, int heads, float* rq, float* rk, float* rv, float* hs, hipStream_t stream);
 // delta[b][h][q] = sum_d dO[b][q][h*D+d] * O[b][q][h*D+d]
 int attention_delta_launch(const bf16_t* O, const bf16_t* dO, int ld, float* delta, int B, int H, int D, int Nq, hipStream_t stream);
 int attention_bwd_launch(const AttnBwdArgs& a, hipStream_t stream);

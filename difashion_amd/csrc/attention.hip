@@ -299,12 +299,16 @@ namespace dfh {
 // attention_x32.hip: the 32x32x16 kernel for the long self-attention launches (d = 40 / 80)
 bool attention_x32_eligible(const AttnArgs& a);
 int attention_x32_launch(const AttnArgs& a, hipStream_t stream);
+// attention_fp8.hip: both products on the e4m3 MFMA (operand factors given, whole 64-key tiles)
+bool attention_fp8_eligible(const AttnArgs& a);
+int attention_fp8_launch(const AttnArgs& a, hipStream_t stream);
 
 int attention_launch(const AttnArgs& a, hipStream_t stream) {
   DFH_REQUIRE(a.Nq > 0 && a.Nk > 0 && a.B > 0 && a.H > 0, "empty attention");
   DFH_REQUIRE(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 4 == 0, "leading dims must be 16-byte aligned");
   DFH_REQUIRE(a.ldvt >= ((a.Nk + 7) / 8) * 8, "V^T rows must be padded to a multiple of 8 keys");
   DFH_REQUIRE(a.O8 ? a.o_amax != nullptr : a.O != nullptr, "attention: no output (bf16 O, or e4m3 O8 with the per-batch maxima of V)");
+  if (attention_fp8_eligible(a)) return attention_fp8_launch(a, stream);
   static const bool x32_off = [] { const char* e = getenv("DFH_ATTN_X32"); return e && e[0] == '0'; }();   // A/B switch for the microbenchmarks
   if (!x32_off && attention_x32_eligible(a)) return attention_x32_launch(a, stream);
   census(CK_ATTN_16);

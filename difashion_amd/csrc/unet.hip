@@ -69,6 +69,13 @@ int dfh_unet_enable_fp8(dfh_unet* u) {
   DFH_REQUIRE(u->ws == nullptr, "dfh_unet_enable_fp8 must precede dfh_unet_workspace_bytes / dfh_unet_bind");
   return u->enable_fp8();
 }
+// before dfh_unet_enable_fp8: also run the self-attention products on the e4m3 MFMA (off by default: slower and less accurate than the bf16 kernels)
+int dfh_unet_enable_fp8_attention(dfh_unet* u, int on) {
+  DFH_REQUIRE(u != nullptr, "null context");
+  DFH_REQUIRE(!u->fp8, "dfh_unet_enable_fp8_attention must precede dfh_unet_enable_fp8");
+  u->fp8_attention = on != 0;
+  return 0;
+}
 size_t dfh_unet_arena8_bytes(const dfh_unet* u) { return u && u->fp8 ? u->a8 : 0; }
 int dfh_unet_bind_fp8(dfh_unet* u, void* arena8) {
   DFH_REQUIRE(u && arena8, "null argument");

@@ -65,6 +65,9 @@ struct AttL {
   // round 4 (BASELINE configs[4] as named: "attention + 1x1-conv path"): to_out of both attentions, ff.net.2, proj_out, and proj_in with
   // the GroupNorm affine folded in (W . diag(gamma), bias + W . beta: the GroupNorm kernel then emits the normalised value as e4m3)
   Mat8 o18, o28, ff28, pout8, pin8;
+  // fp8 attention products (attention_fp8.hip): operand factors rq | rk | rv ([C] each) and the per-head softmax factor ([heads]) as
+  // floats at arena8 + f8a_off, derived from the LayerNorm-folded q | k | v weights at pack time; f8a: allocated for this layer
+  size_t f8a_off = 0; bool f8a = false;
 };
 struct ConvL {
   Mat w; Vec b; int cin = 0, cout = 0; std::string pre; Mat wt;
@@ -157,6 +160,9 @@ struct dfh_unet {
   size_t plan_persist = 0, plan_temp = 0, plan_partial = 0, plan_total = 0; int plan_batch = 0;
   // fp8 linears (BASELINE configs[4]): e4m3 copies of qk / v / q2 / ff1 + per-row scales, in one caller-owned arena
   bool fp8 = false; unsigned char* arena8 = nullptr; size_t a8 = 0;
+  // fp8 walk: also the self-attention products QK^T / PV on the e4m3 MFMA (attention_fp8.hip).  OFF by default: built, parity-tested and
+  // measured slower than the bf16 kernels at every head dim of this model (profiles/r04/attn_fp8_microbench.txt)
+  bool fp8_attention = false;
   // taps of the last forward
   std::map<std::string, Tensor> taps; int last_batch = 0;
   // ---- training state (unet_train.hip)
@@ -215,12 +221,18 @@ struct dfh_unet {
     packs.push_back(op);
   }
 
+  // largest image (pixels) whose wide resnet convs take Winograd: 256 = the 16x16 level (default); DFH_WINO_MAXHW=1024 adds the 32x32 level
+  // (the A/B of profiles/r04: measured, not the default)
+  static int wino_max_hw() {
+    static const int v = [] { const char* e = getenv("DFH_WINO_MAXHW"); return e ? atoi(e) : 256; }();
+    return v;
+  }
   // res: side of the (square) image this resnet runs on
   void build_resnet(const std::string& pre, int cin, int cout, ResL& r, int res) {
     const int temb = cfg.block_out_channels[0] * 4;
     // Winograd (winograd.hip) where it pays and where its bf16 transform-domain roundings are a small part of the layer's error budget:
     // the wide layers (>= 512 channels both ways) of the levels of at most 16 x 16 pixels
-    if (res % 2 == 0 && res * res <= 256 && cin % 8 == 0 && cout % 8 == 0 && std::min(cin, cout) >= 512) {
+    if (res % 2 == 0 && res * res <= wino_max_hw() && cin % 8 == 0 && cout % 8 == 0 && std::min(cin, cout) >= 512) {
       r.has_u = true;
       r.u1 = fold16; fold16 += ((size_t)16 * cout * cin + 127) & ~(size_t)127;
       r.u2 = fold16; fold16 += ((size_t)16 * cout * cout + 127) & ~(size_t)127;
@@ -425,6 +437,14 @@ struct dfh_unet {
       take(a->qk, a->qk8); take(a->v, a->v8); take(a->q2, a->q28); take(a->ff1, a->ff18);
       if (ext_off) continue;
       take(a->o1, a->o18); take(a->o2, a->o28); take(a->ff2, a->ff28); take(a->pout, a->pout8); take(a->pin, a->pin8, true);
+      // opt-in (dfh_unet_enable_fp8_attention / DFH_FP8_ATTN=1): see fp8_attention above
+      static const bool attn_env = [] { const char* e = getenv("DFH_FP8_ATTN"); return e && e[0] == '1'; }();
+      const bool attn_off = !(fp8_attention || attn_env);
+      const int D = a->C / a->heads;
+      const bool v_contig = a->v.off == a->qk.off + (size_t)2 * a->C * a->C && a->v.K == a->qk.K;
+      if (!attn_off && v_contig && (D == 40 || D == 80 || D == 160)) {
+        a->f8a = true; a->f8a_off = a8; a8 += ((size_t)(3 * a->C + a->heads) * sizeof(float) + 255) & ~(size_t)255;
+      }
     }
     n_att = idx;
     // (row offset, row count) of every layer's slice of the batched cross-attention V^T: the slabs of amax_slabs_kernel
@@ -459,6 +479,17 @@ struct dfh_unet {
         if (int rc = dfh::ln_fold_launch(arena16 + a->pin.off, a->pin.K, arena32 + a->nw.off, arena32 + a->nb.off, arena32 + a->pinb.off, wf, sv,
                                          (float*)(arena8 + a->pin8.boff), C, C, s)) return rc;
         if (int rc = dfh::quant_rows_fp8_launch(wf, C, arena8 + a->pin8.off, (float*)(arena8 + a->pin8.soff), C, C, s)) return rc;
+      }
+      if (a->f8a) {
+        // operand factors of the fp8 attention: bounds of q, k, v behind LayerNorm 1 from W . diag(gamma) and W . beta (bf16 / fp32 scratch)
+        const int C = a->C;
+        DFH_REQUIRE(ws && fold_bytes() + (size_t)3 * C * C * 2 + (size_t)6 * C * 4 + 1024 <= ws_bytes, "workspace too small for the fp8 attention scales");
+        bf16_t* wf = (bf16_t*)(ws + fold_bytes());
+        float* sv = (float*)(ws + fold_bytes() + (((size_t)3 * C * C * 2 + 255) & ~(size_t)255));
+        float* bv = sv + 3 * C;
+        if (int rc = dfh::ln_fold_launch(arena16 + a->qk.off, C, arena32 + a->l1w.off, arena32 + a->l1b.off, nullptr, wf, sv, bv, 3 * C, C, s)) return rc;
+        float* f = (float*)(arena8 + a->f8a_off);
+        if (int rc = dfh::attn_scales_launch(wf, bv, C, a->heads, f, f + C, f + 2 * C, f + 3 * C, s)) return rc;
       }
     }
     return 0;
@@ -638,9 +669,10 @@ struct dfh_unet {
       rc = dfh::groupnorm_launch(a, s);
     }
     void attention8(const bf16_t* Q, int ldq, const bf16_t* K, int ldk, const bf16_t* Vt, int ldvt, uint8_t* O8, const float* amax, int C,
-                    int heads, int Nq, int Nk, long vt_bstride = 0) {
+                    int heads, int Nq, int Nk, long vt_bstride = 0, const float* f8 = nullptr) {
       if (rc || dry) return;
       AttnArgs a; std::memset(&a, 0, sizeof(a));
+      if (f8) { a.f8_rq = f8; a.f8_rk = f8 + C; a.f8_rv = f8 + 2 * C; a.f8_hs = f8 + 3 * C; }
       a.vt_bstride = vt_bstride;
       a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.Vt = Vt; a.ldvt = ldvt; a.O8 = O8; a.o_amax = amax; a.ldo = C;
       a.B = B; a.H = heads; a.D = C / heads; a.Nq = Nq; a.Nk = Nk;
@@ -651,10 +683,12 @@ struct dfh_unet {
       if (rc || dry) return;
       rc = dfh::layernorm_launch(x, v32(w), v32(b), y, M, C, 1e-5f, s);
     }
+    // f8: operand factors of the fp8 attention products (AttL::f8a_off) or null
     void attention(const bf16_t* Q, int ldq, const bf16_t* K, int ldk, const bf16_t* Vt, int ldvt, bf16_t* O, int C,
-                   int heads, int Nq, int Nk, long vt_bstride = 0) {
+                   int heads, int Nq, int Nk, long vt_bstride = 0, const float* f8 = nullptr) {
       if (rc || dry) return;
       AttnArgs a; std::memset(&a, 0, sizeof(a));
+      if (f8) { a.f8_rq = f8; a.f8_rk = f8 + C; a.f8_rv = f8 + 2 * C; a.f8_hs = f8 + 3 * C; }
       a.vt_bstride = vt_bstride;
       a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.Vt = Vt; a.ldvt = ldvt; a.O = O; a.ldo = C;
       a.B = B; a.H = heads; a.D = C / heads; a.Nq = Nq; a.Nk = Nk;
@@ -733,7 +767,7 @@ struct dfh_unet {
       Tensor h1 = talloc(H, W, r.cout);
       // DFH_WINO: 0 = direct implicit GEMM everywhere, 1 = Winograd at H * W <= 64 (the 8x8 level), 2 = also at H * W <= 256 (A/B)
       static const int wino_mode = [] { const char* e = getenv("DFH_WINO"); return e ? atoi(e) : 2; }();
-      const bool wino = r.has_u && (dry || u->fold_valid) && ((wino_mode >= 1 && H * W <= 64) || (wino_mode >= 2 && H * W <= 256));
+      const bool wino = r.has_u && (dry || u->fold_valid) && ((wino_mode >= 1 && H * W <= 64) || (wino_mode >= 2 && H * W <= wino_max_hw()));
       if (wino) {
         // the GroupNorms in front of the two convs run inside the input transforms where the (image, group) slab fits the kernel
         // (DFH_WINO_GN=0: separate GroupNorm launches, A/B)
@@ -885,13 +919,15 @@ struct dfh_unet {
       }
       Tensor at = talloc(H, W, C);
       Tensor h1 = talloc(H, W, C);
+      // self-attention products on the e4m3 MFMA where the layer has operand factors and the keys make whole 64-key tiles
+      const float* f8attn = (f8 && a.f8a && N % 64 == 0) ? (const float*)(u->arena8 + a.f8a_off) : nullptr;
       if (f8x) {
-        attention8(qk.p, 2 * C, qk.p + C, 2 * C, vt, Np, a8, am_self, C, a.heads, N, N);
+        attention8(qk.p, 2 * C, qk.p + C, 2 * C, vt, Np, a8, am_self, C, a.heads, N, N, 0, f8attn);
         Fp8GemmArgs g = args8(a8, M, a.o18, &a.o1b, h1.p);
         g.sA = am_self; g.sa_div = N; g.sa_mul = 1.0f / 448.0f; g.resid = h0.p; g.ld_res = C;
         gemm8(g);
       } else {
-        attention(qk.p, 2 * C, qk.p + C, 2 * C, vt, Np, at.p, C, a.heads, N, N);
+        attention(qk.p, 2 * C, qk.p + C, 2 * C, vt, Np, at.p, C, a.heads, N, N, 0, f8attn);
         linear(at.p, M, C, a.o1, &a.o1b, ACT_NONE, h0.p, h1.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
       }
       // --- cross attention over the T text tokens

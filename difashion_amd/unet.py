@@ -188,15 +188,21 @@ class UNet2DConditionModel(nn.Module):
     def enable_gradient_checkpointing(self):
         return None
 
-    def enable_fp8(self, on: bool = True):
+    fp8_attention = False
+
+    def enable_fp8(self, on: bool = True, attention: bool = False):
         """BASELINE configs[4]: run every linear / 1x1 convolution of every transformer block -- proj_in, attn1 q|k and v, both
         to_out, attn2 q, the GEGLU pair ff.net.0 / ff.net.2 and proj_out -- in OCP e4m3 on the block-scaled MFMA
         (csrc/gemm_fp8.hip), fp32 accumulation, per-output-channel weight scales.  Every activation operand is quantised by the
         kernel that produces it: LayerNorm (a scale per token), GroupNorm (the normalised value under a static scale, its affine
         folded into proj_in), the attention epilogues (per image, against the maximum of V), the GEGLU / ff.net.2 epilogues (E8M0
         block scales per 32 channels, consumed by the MFMA's scale operand).  The 3x3 convolutions and the attention products stay
-        bf16.  Sampling path only -- the training forward keeps bf16.  Takes effect at the next forward (the context is rebuilt)."""
+        bf16.  ``attention=True`` additionally runs the self-attention products QK^T / PV on the e4m3 MFMA (csrc/attention_fp8.hip, the
+        operands quantised inside the kernel with static factors derived from the projection weights): built and parity-tested, but
+        slower and less accurate than the bf16 kernels on this model, hence opt-in.  Sampling path only -- the training forward keeps
+        bf16.  Takes effect at the next forward (the context is rebuilt)."""
         self.fp8 = bool(on)
+        self.fp8_attention = bool(attention) and self.fp8
         return self
 
     def enable_xformers_memory_efficient_attention(self, *a, **k):
@@ -265,7 +271,7 @@ class UNet2DConditionModel(nn.Module):
             raise _lib.DfhError("conv_in must be a 3x3 / stride 1 / padding 1 convolution")
         if batch > self.max_batch:
             self.max_batch = batch
-        key = (in_ch, self.max_batch, dev.index, self.fp8, tuple(sorted((k, str(v)) for k, v in self.config.items())))
+        key = (in_ch, self.max_batch, dev.index, self.fp8, self.fp8_attention, tuple(sorted((k, str(v)) for k, v in self.config.items())))
         if self._ctx is not None and key == self._ctx_key:
             return
         if self._ctx is not None:
@@ -281,6 +287,8 @@ class UNet2DConditionModel(nn.Module):
                 raise _lib.DfhError(f"parameter {name}: expected shape {shape}, module has "
                                     f"{tuple(params[name].shape) if name in params else None}")
         if self.fp8:
+            if self.fp8_attention:
+                _lib.call("dfh_unet_enable_fp8_attention", ctx, 1)
             _lib.call("dfh_unet_enable_fp8", ctx)        # before the workspace is planned
         # zero-filled: padded weight columns (conv_in with 4 input channels -> 8) must read as 0
         a16 = torch.zeros(lib.dfh_unet_arena16_bytes(ctx), dtype=torch.uint8, device=dev)

@@ -100,6 +100,9 @@ int dfh_unet_bind(dfh_unet* u, void* arena16, void* arena32, void* workspace, si
 /* fp8 linears inside the U-Net walk (inference): call dfh_unet_enable_fp8 right after create (it changes the workspace plan),
  * allocate dfh_unet_arena8_bytes, bind it; dfh_unet_pack then also refreshes the e4m3 copies + per-channel scales. */
 int dfh_unet_enable_fp8(dfh_unet* u);
+/* optional, BEFORE dfh_unet_enable_fp8: also run the self-attention products QK^T / PV on the e4m3 MFMA (csrc/attention_fp8.hip; head dims
+ * 40 / 80 / 160, whole 64-key tiles).  Off by default: measured slower than the bf16 kernels on this model (profiles/r04). */
+int dfh_unet_enable_fp8_attention(dfh_unet* u, int on);
 size_t dfh_unet_arena8_bytes(const dfh_unet* u);
 int dfh_unet_bind_fp8(dfh_unet* u, void* arena8);
 
@@ -337,6 +340,14 @@ int dfh_attention_fp8out(const void* Q, int ldq, const void* K, int ldk, const v
                          int batch, int heads, int head_dim, int Nq, int Nk, float scale, void* stream);
 int dfh_amax_slabs(const void* x, long bstride, int ld, int cols, const int* row0, const int* nrows, float* out, int nslab, int batch,
                    void* stream);
+/* Self-attention with both products on the e4m3 MFMA (csrc/attention_fp8.hip): bf16 Q / K / V^T in HBM, quantised on the way into the
+ * matrix pipe with STATIC per-channel factors (q * rq, k * rk with rq * rk = 1 / hs[h] per head, v * rv; [heads * head_dim] each, hs
+ * [heads]); bf16 output.  head_dim 40 / 80 / 160, Nk a multiple of 64.  dfh_attn_scales derives the factors from the LayerNorm-folded
+ * projection weights wf [3C][C] (rows q | k | v, bf16) and biases bf [3C]: bound = |row|_2 sqrt(C) + |bias| for a LayerNorm-ed input. */
+int dfh_attention_fp8(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo, const float* rq,
+                      const float* rk, const float* rv, const float* hs, int batch, int heads, int head_dim, int Nq, int Nk, float scale,
+                      void* stream);
+int dfh_attn_scales(const void* wf, const float* bf, int C, int heads, float* rq, float* rk, float* rv, float* hs, void* stream);
 /* softmax(Q K^T * scale) V; Q [B][Nq][ldq], K [B][Nk][ldk], Vt [B][H*D][ldvt] (V transposed), O [B][Nq][ldo]; bf16 */
 int dfh_attention(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
                   int batch, int heads, int head_dim, int Nq, int Nk, float scale, void* stream);

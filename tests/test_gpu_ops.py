@@ -992,6 +992,51 @@ def test_attention_fp8_output_is_scaled_by_the_maximum_of_v(B, H, D, Nq, Nk):
     assert not torch.isnan(got).any() and gu.rel_err(got, o16.float()) <= 4e-2
 
 
+@pytest.mark.parametrize("B,H,D,N", [(2, 8, 40, 1024), (1, 8, 40, 4096), (2, 8, 80, 1024), (2, 8, 160, 256), (3, 8, 160, 64), (1, 4, 80, 200)])
+def test_attention_fp8_products_match_the_bf16_kernel(B, H, D, N):
+    """attention_fp8_kernel (both products on the e4m3 MFMA, operands quantised inside the kernel with static factors derived from the
+    projection weights) against fp32 softmax attention of the same bf16 q / k / v, and against the bf16 kernel.  q, k, v are REAL
+    projections of a LayerNorm-ed input (that is what the static bounds are derived for): x -> LayerNorm -> W' with channel-dependent
+    row norms (a 7 x spread: the per-channel balancing of q and k has work to do) and a bias.  N = 200: the 64-query tail / ragged rows.
+    Tolerance 8e-2: the output is a near-cancelling average of zero-mean V rows, so its relative error is about the element error of
+    e4m3 (3 mantissa bits on p and on v: ~5 %) however many keys are averaged -- the intrinsic price of an fp8 P.V (measured 4-6e-2)."""
+    Cc = H * D
+    Nk = N if N % 64 == 0 else 256
+    g = torch.Generator().manual_seed(180)
+    x = torch.randn(B * max(N, Nk), Cc, generator=g).to(DEV)
+    gamma, beta = 1.0 + 0.2 * rnd(Cc, seed=181), 0.2 * rnd(Cc, seed=182)
+    spread = torch.exp(torch.linspace(-1.0, 1.0, 3 * Cc))[torch.randperm(3 * Cc, generator=g)].to(DEV)
+    w = bf(rnd(3 * Cc, Cc, seed=183, scale=0.02) * spread[:, None])
+    wf = torch.empty_like(w)
+    sv, bv = torch.empty(3 * Cc, device=DEV), torch.empty(3 * Cc, device=DEV)
+    _lib.call("dfh_ln_fold", _lib.ptr(w), Cc, _lib.ptr(gamma), _lib.ptr(beta), None, _lib.ptr(wf), _lib.ptr(sv), _lib.ptr(bv), 3 * Cc, Cc, gu.stream())
+    rq, rk, rv, hs = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV), torch.empty(H, device=DEV)
+    _lib.call("dfh_attn_scales", _lib.ptr(wf), _lib.ptr(bv), Cc, H, _lib.ptr(rq), _lib.ptr(rk), _lib.ptr(rv), _lib.ptr(hs), gu.stream())
+    torch.cuda.synchronize()
+    qkv = F.layer_norm(x, (Cc,), gamma, beta, 1e-5) @ w.float().T
+    q = bf(qkv[:B * N, :Cc]).view(B, N, Cc).contiguous()
+    k = bf(qkv[:B * Nk, Cc:2 * Cc]).view(B, Nk, Cc).contiguous()
+    v = bf(qkv[:B * Nk, 2 * Cc:]).view(B, Nk, Cc)
+    vt = v.transpose(1, 2).contiguous()
+    # the factors really are bounds: no quantised operand can saturate
+    assert float((q.float().abs() * rq).max()) <= 448.0 and float((k.float().abs() * rk).max()) <= 448.0 and float((v.float().abs() * rv).max()) <= 448.0
+    torch.testing.assert_close((rq * rk).view(H, D), (1.0 / hs)[:, None].expand(H, D), rtol=1e-5, atol=0)
+    o16 = torch.empty(B, N, Cc, dtype=torch.bfloat16, device=DEV)
+    o8 = torch.full((B, N, Cc), float("nan"), dtype=torch.bfloat16, device=DEV)
+    args = (_lib.ptr(q), Cc, _lib.ptr(k), Cc, _lib.ptr(vt), Nk)
+    _lib.call("dfh_attention", *args, _lib.ptr(o16), Cc, B, H, D, N, Nk, D ** -0.5, gu.stream())
+    _lib.census_reset()
+    _lib.call("dfh_attention_fp8", *args, _lib.ptr(o8), Cc, _lib.ptr(rq), _lib.ptr(rk), _lib.ptr(rv), _lib.ptr(hs), B, H, D, N, Nk, D ** -0.5,
+              gu.stream())
+    torch.cuda.synchronize()
+    assert _lib.census()["attention_fp8"] == 1
+    ref = F.scaled_dot_product_attention(q.float().view(B, N, H, D).transpose(1, 2), k.float().view(B, Nk, H, D).transpose(1, 2),
+                                         v.float().view(B, Nk, H, D).transpose(1, 2)).transpose(1, 2).reshape(B, N, Cc)
+    e8, e16 = gu.rel_err(o8.float(), ref), gu.rel_err(o16.float(), ref)
+    print(f"fp8 attention D={D} N={N}: rel err {e8:.2e} (bf16 kernel {e16:.2e})")
+    assert not torch.isnan(o8).any() and e8 <= 8e-2
+
+
 def test_amax_slabs():
     B, rows, ld = 3, 640, 80
     x = bf(rnd(B, rows, ld, seed=160))

@@ -90,7 +90,9 @@ def test_sampler_vs_reference_golden(case, unet):
     eps_ref = glue_ref.cfg_combine(mode, rec["unet_out_0"], sc, sh, sm)
     eps_err = rel_err(taps["eps_0"].cpu(), eps_ref)
     print(case, f"eps_0 {eps_err:.2e}")
-    assert eps_err <= 0.25
+    # measured 1.6e-2 .. 7.9e-2 over the 14 cases (the guidance scales 12 / 5 / 4 amplify the per-branch error of <= 3e-2 by the
+    # norm ratio of the weighted difference to the combination); 0.25 until round 3
+    assert eps_err <= 0.10
 
 
 @pytest.mark.parametrize("case", ["gor_full_ddim10", "mix_full_pndm10", "gor_full_ddim50"])

@@ -288,6 +288,20 @@ def test_unet_sd15_full_size_batch16_matches_oracle():
     # BASELINE configs[4] as named: per transformer block proj_in, q|k, v, to_out, q (cross), to_out (cross), ff.net.0, ff.net.2 and
     # proj_out on gemm_fp8_kernel = 9 x 16 blocks; no LayerNorm-fed bf16 linear is left, the 3x3 convs stay bf16
     assert e8 <= 6e-2 and cen8["gemm_fp8"] == 9 * 16, cen8
+    assert cen8["attention_fp8"] == 0, cen8
+    # ... and with the self-attention products on the e4m3 MFMA as well (opt-in: slower on this model, profiles/r04): all 16 self-attention
+    # launches (head dims 40 / 80 / 160) on attention_fp8_kernel, same tolerance
+    m.enable_fp8(True, attention=True)
+    with torch.no_grad():
+        m(xd, td, ed)
+        torch.cuda.synchronize()
+        _lib.census_reset()
+        out8a = m(xd, td, ed).sample
+        torch.cuda.synchronize()
+    cen8a = _lib.census()
+    e8a = rel_err(out8a.cpu(), ref)
+    print("sd15 B=16 fp8 + fp8 attention", f"{e8a:.2e}")
+    assert e8a <= 6e-2 and cen8a["attention_fp8"] == 16 and cen8a["gemm_fp8"] == 9 * 16, cen8a
     assert cen8["gemm_lean"] + cen8["gemm_8wave"] + cen8["gemm_row"] < cen["gemm_lean"] + cen["gemm_8wave"] + cen["gemm_row"], (cen, cen8)
 
 

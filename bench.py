@@ -401,7 +401,10 @@ def main():
                     help="--mode train: gradient exchange format (bf16: all_to_all + fp32 accumulate + all_gather, half the bytes per link); "
                          "default: bf16 when more than one GPU takes part, fp32 (nothing is exchanged) on one")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
-                    help="fp8: BASELINE configs[4] -- the LayerNorm-fed transformer projections in e4m3 on the block-scaled MFMA")
+                    help="fp8: BASELINE configs[4] -- every linear / 1x1 convolution of the transformer blocks (proj_in, q|k, v, to_out, "
+                         "cross q, cross to_out, the GEGLU pair, proj_out) in e4m3 on the block-scaled MFMA; 3x3 convs stay bf16")
+    ap.add_argument("--fp8-attention", action="store_true",
+                    help="with --dtype fp8: also the self-attention products QK^T / PV on the e4m3 MFMA (opt-in: measured slower, profiles/r04)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -438,7 +441,7 @@ def main():
         return run_vae(args, da, _lib, ddist, rank, world, dev)
     unet, enc = build_models(dev, args.config)
     if args.dtype == "fp8":
-        unet.enable_fp8()
+        unet.enable_fp8(True, attention=args.fp8_attention)
         unet.pack(force=True)
     cross = unet.config.cross_attention_dim
     K, W = args.steps, args.warmup
@@ -537,9 +540,13 @@ def main():
         "metric": "U-Net denoise steps/sec, 4-item outfit @ 64x64x4 latent", "value": round(value, 3), "unit": "steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed * 1e3 / K, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if args.dtype == "bf16" else "fp8 e4m3 (attn1 q|k|v, attn2 q, GEGLU input projections) + bf16 (everything else)",
+        "dtype": "bf16" if args.dtype == "bf16" else
+                 ("fp8 e4m3 (all nine linears / 1x1 convs of every transformer block, GEGLU hidden tensor in e4m3 + E8M0 block scales"
+                  + (", self-attention QK^T / PV" if args.fp8_attention else "") + ") + bf16 (3x3 convs"
+                  + ("" if args.fp8_attention else ", attention products") + ", residual stream)"),
         "data": "synthetic",
-        "config": {"workload": ("BASELINE configs[1]" if args.dtype == "bf16" else "BASELINE configs[4] on one GPU (fp8 linears)") +
+        "config": {"workload": ("BASELINE configs[1]" if args.dtype == "bf16" else "BASELINE configs[4] on one GPU (fp8 transformer linears"
+                                + (" + fp8 attention products)" if args.fp8_attention else ")")) +
                                ": one 4-item outfit, CFG on (4 branches) -> U-Net batch 16, DDIM-50 schedule, "
                                f"{args.config} shape in_channels=8, 64x64x4 latents, 77 text tokens; one outfit per GPU",
                    "unet_batch": 16, "latent": "64x64x4", "parallelism": f"outfit-replicas x{world} (no data-path collective)"},

@@ -998,8 +998,8 @@ def test_attention_fp8_products_match_the_bf16_kernel(B, H, D, N):
     projection weights) against fp32 softmax attention of the same bf16 q / k / v, and against the bf16 kernel.  q, k, v are REAL
     projections of a LayerNorm-ed input (that is what the static bounds are derived for): x -> LayerNorm -> W' with channel-dependent
     row norms (a 7 x spread: the per-channel balancing of q and k has work to do) and a bias.  N = 200: the 64-query tail / ragged rows.
-    Tolerance 8e-2: the output is a near-cancelling average of zero-mean V rows, so its relative error is about the element error of
-    e4m3 (3 mantissa bits on p and on v: ~5 %) however many keys are averaged -- the intrinsic price of an fp8 P.V (measured 4-6e-2)."""
+    Tolerance 8e-2 (measured 0.4e-2 .. 3.3e-2 on these moderately peaked softmaxes; with logits spread over +-25 -- weights 2.5 x larger --
+    the e4m3 scores cost 0.10 - 0.15 where the bf16 kernel stays at 3e-3: the reason the kernel is opt-in beside being slower)."""
     Cc = H * D
     Nk = N if N % 64 == 0 else 256
     g = torch.Generator().manual_seed(180)

@@ -10,6 +10,11 @@ int unpack_matrix_launch(const float* g, float* grad, int N, int K, int ldw, int
 int unpack_conv3x3_launch(const float* g, float* grad, int Cout, int Cin, int ldw, int col_off, int cin_pad, hipStream_t s);
 int unpack_vector_launch(const float* g, float* grad, int N, int off, int geglu, hipStream_t s);
 int pool2x2_sum_launch(const bf16_t* in, bf16_t* out, int B, int H, int W, int C, hipStream_t s);
+// backward of an upsample conv through its four phase planes (gemm.h GemmArgs::phase2x): dY [B][2H][2W][C] -> [4][B][H][W][C];
+// dx (=|+=) sum of four planes; dW3 [N][9 C] (= | +=) from dWp [4][N][4 C]
+int phase_gather_launch(const bf16_t* in, bf16_t* out, int B, int H, int W, int C, hipStream_t s);
+int phase_sum4_launch(const bf16_t* planes, bf16_t* dx, long n, int accumulate, hipStream_t s);
+int ups_phase_unfold_launch(const float* dwp, float* dw3, int N, int C, int ldw, int overwrite, hipStream_t s);
 int add_bf16_launch(bf16_t* dst, const bf16_t* src, long n, int accumulate, hipStream_t s);
 int geglu_bwd_launch(const bf16_t* pre, const bf16_t* dy, bf16_t* dpre, long M, int N2, hipStream_t s);
 int geglu_fwd_launch(const bf16_t* pre, bf16_t* y, long M, int N2, hipStream_t s);

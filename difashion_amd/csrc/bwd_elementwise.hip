@@ -67,6 +67,58 @@ __global__ void unpack_vector_kernel(const float* __restrict__ g, float* __restr
   grad[i] += g[off + r];
 }
 
+// ---- phase planes of an upsample conv in the backward pass (gemm.h GemmArgs::phase2x, wgrad.h WgradArgs::tap2) -----------------------------
+// output gradient dY [B][2H][2W][C] -> phase-major [4][B][H][W][C]: plane (py, px) holds the pixels (2y + py, 2x + px)
+__global__ void phase_gather_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int B, int H, int W, int C8) {
+  const long i = gtid();
+  const long per = (long)B * H * W * C8;
+  if (i >= 4 * per) return;
+  const int plane = (int)(i / per);
+  long r = i - plane * per;
+  const int o = (int)(r % C8); r /= C8;
+  const int x = (int)(r % W); r /= W;
+  const int y = (int)(r % H);
+  const int b = (int)(r / H);
+  const int py = plane >> 1, px = plane & 1;
+  ((uint4*)out)[i] = *(const uint4*)(in + ((((long)b * 2 * H + 2 * y + py) * (2 * W) + 2 * x + px) * C8 + o) * 8);
+}
+// dx (=|+=) sum of the four planes' data gradients [4][n] (fp32 sum, one rounding)
+__global__ void phase_sum4_kernel(const bf16_t* __restrict__ planes, bf16_t* __restrict__ dx, long n8, int accumulate) {
+  const long i = gtid();
+  if (i >= n8) return;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (accumulate) unpack8(((const uint4*)dx)[i], acc);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    float f[8];
+    unpack8(((const uint4*)planes)[p * n8 + i], f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += f[k];
+  }
+  ((uint4*)dx)[i] = pack8(acc);
+}
+// gradient of the 3x3 weights (packed [N][9 * C], fp32) from the gradients of the four planes' SUMMED weights dWp [4][N][4 * C]:
+// plane (py, px) folded tap (ky, kx) into its slot (sr, sc) with sr = (py == 0 ? ky >= 1 : ky == 2), likewise sc (lnfold.hip
+// ups_phase_fold), so dW3[ky][kx] = sum over the four planes of dWp[plane][slot(plane, ky, kx)]
+__global__ void ups_phase_unfold_kernel(const float* __restrict__ dwp, float* __restrict__ dw3, int N, int C, int ldw, int overwrite) {
+  const long i = gtid();
+  if (i >= (long)N * 9 * C) return;
+  const int c = (int)(i % C);
+  long r = i / C;
+  const int t = (int)(r % 9), n = (int)(r / 9);
+  const int ky = t / 3, kx = t - ky * 3;
+  float acc = 0.f;
+#pragma unroll
+  for (int py = 0; py < 2; ++py)
+#pragma unroll
+    for (int px = 0; px < 2; ++px) {
+      const int sr = py == 0 ? (ky >= 1) : (ky == 2), sc = px == 0 ? (kx >= 1) : (kx == 2);
+      acc += dwp[(((long)(py * 2 + px) * N + n) * 4 + sr * 2 + sc) * C + c];
+    }
+  float* dst = dw3 + (long)n * ldw + t * C + c;
+  *dst = overwrite ? acc : *dst + acc;
+}
+
 // ---- activations / layout ---------------------------------------------------------------------------------
 // nearest-2x upsample backward: out[b][y][x][c] = sum of the 2x2 block of in[b][2y..][2x..][c]   (NHWC bf16)
 __global__ void pool2x2_sum_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int B, int H, int W, int C8) {
@@ -353,6 +405,17 @@ int unpack_conv3x3_launch(const float* g, float* grad, int Cout, int Cin, int ld
 }
 int unpack_vector_launch(const float* g, float* grad, int N, int off, int geglu, hipStream_t s) {
   EW_LAUNCH(unpack_vector_kernel, (long)N, g, grad, N, off, geglu);
+}
+int phase_gather_launch(const bf16_t* in, bf16_t* out, int B, int H, int W, int C, hipStream_t s) {
+  DFH_REQUIRE(C % 8 == 0, "phase gather: channels must be a multiple of 8");
+  EW_LAUNCH(phase_gather_kernel, 4L * B * H * W * (C / 8), in, out, B, H, W, C / 8);
+}
+int phase_sum4_launch(const bf16_t* planes, bf16_t* dx, long n, int accumulate, hipStream_t s) {
+  DFH_REQUIRE(n % 8 == 0, "phase sum: element count must be a multiple of 8");
+  EW_LAUNCH(phase_sum4_kernel, n / 8, planes, dx, n / 8, accumulate);
+}
+int ups_phase_unfold_launch(const float* dwp, float* dw3, int N, int C, int ldw, int overwrite, hipStream_t s) {
+  EW_LAUNCH(ups_phase_unfold_kernel, (long)N * 9 * C, dwp, dw3, N, C, ldw, overwrite);
 }
 int pool2x2_sum_launch(const bf16_t* in, bf16_t* out, int B, int H, int W, int C, hipStream_t s) {
   DFH_REQUIRE(C % 8 == 0, "channels must be a multiple of 8");

@@ -53,6 +53,9 @@ struct GemmArgs {
   // nbatch = 4 planes (grid.y = py * 2 + px), ntaps = 4 (tap s = (s >> 1, s & 1) reads the 3x3-tap position (s >> 1) + py,
   // (s & 1) + px of the source), W plane z = the summed weights [N][4 * conv_c] (lnfold.hip ups_phase_fold), Hin = Win = Hout = Wout =
   // source size, M = rows of ONE phase; row m = (b, y, x) is stored at output pixel (b, 2y + py, 2x + px) of the 2H x 2W image.
+  // phase2x = 2: the DATA GRADIENT of that conv (training): plane z convolves its own image of output-gradient pixels (conv_src + z * a_bs,
+  // the output gradient gathered phase-major: bwd_elementwise.hip phase_gather) with W plane z = the TRANSPOSED phase weights [Cin][4 * Cout],
+  // tap s at the mirrored position (2 - py - (s >> 1), 2 - px - (s & 1)); plane z writes plain rows at out + z * o_bs (summed afterwards).
   int phase2x;
   // profile accounting override (0 = derive from the shape): a launch that is one stage of a convolution (the batched transform-domain
   // GEMM of winograd.hip) reports the REFERENCE algorithm's multiply-adds (the direct conv) under the conv3x3 class

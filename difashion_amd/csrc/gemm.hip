@@ -125,7 +125,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
   const bool leanc = (a.ntaps == 9 || a.phase2x) && a.stride == 1 && a.ups == 0 && !a.pad0 && (a.conv_c % BK) == 0;
   // phase-decomposed upsample conv (GemmArgs::phase2x): segment s of this plane is 3x3-tap position ((s >> 1) + py, (s & 1) + px)
   const int ppy = a.phase2x ? (int)(blockIdx.y >> 1) : 0, ppx = a.phase2x ? (int)(blockIdx.y & 1) : 0;
-  auto tap_of = [&](int seg) { return a.phase2x ? ((seg >> 1) + ppy) * 3 + (seg & 1) + ppx : seg; };
+  // phase2x == 2 (the DATA GRADIENT of that conv, training): plane (py, px) convolves ITS image of output-gradient pixels (conv_src + plane *
+  // a_bs) with the transposed phase weights, tap s at the mirrored position (2 - py - (s >> 1), 2 - px - (s & 1)); plain output rows per plane
+  auto tap_of = [&](int seg) {
+    return a.phase2x == 1 ? ((seg >> 1) + ppy) * 3 + (seg & 1) + ppx : (a.phase2x == 2 ? (2 - ppy - (seg >> 1)) * 3 + 2 - ppx - (seg & 1) : seg);
+  };
   unsigned c_pre[IA], c_mask[IA];
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
@@ -144,6 +148,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
   // batched launch (GemmArgs::nbatch): grid.y selects the operand / output planes
   const long bz = (long)blockIdx.y;
   const bf16_t* psrc0 = a.p_src[0] + bz * a.a_bs;
+  const bf16_t* csrc = a.conv_src + (a.phase2x == 2 ? bz * a.a_bs : 0);
   const bf16_t* psrc1 = a.p_src[1];
   const bf16_t* Wb = a.W + bz * a.w_bs;
   bf16_t* const outb = (bf16_t*)a.out + bz * a.o_bs;
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
       const unsigned bit = 1u << tp;
 #pragma unroll
       for (int i = 0; i < IA; ++i)
-        glds((c_mask[i] & bit) ? a.conv_src + (c_pre[i] + delta) : a.zero, As + i * NWV * 1024);
+        glds((c_mask[i] & bit) ? csrc + (c_pre[i] + delta) : a.zero, As + i * NWV * 1024);
     } else if (it.seg < a.ntaps) {
       const int tp = tap_of(it.seg);
       const int ky = tp / 3, kx = tp - ky * 3;
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
                         ((a.ups != 2) | (((yy | xx) & 1) == 0));
         const int sy = a.ups ? (yy >> 1) : yy, sx = a.ups ? (xx >> 1) : xx;
         const unsigned off = (unsigned)(a_bbase[i] + sy * a.Win + sx) * cc + (unsigned)ch;
-        glds(ok ? a.conv_src + off : a.zero, As + i * NWV * 1024);
+        glds(ok ? csrc + off : a.zero, As + i * NWV * 1024);
       }
     } else {
       const int ps = it.seg - a.ntaps;
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
       const int row = c / CPR, cc = c - row * CPR;
       const int m = m0 + row, n = n0 + cc * 8;
       long orow = m;
-      if (a.phase2x) {                               // source pixel (b, y, x) -> pixel (2y + py, 2x + px) of the 2H x 2W output
+      if (a.phase2x == 1) {                          // source pixel (b, y, x) -> pixel (2y + py, 2x + px) of the 2H x 2W output
         const int b = m / HWo, rem = m - b * HWo;
         const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
         orow = (long)b * 4 * HWo + (long)(2 * oy + ppy) * (2 * a.Wout) + 2 * ox + ppx;
@@ -1019,7 +1024,7 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     const double flops = a.prof_flops > 0.0 ? a.prof_flops : (a.phase2x ? 9.0 / 4.0 : 1.0) * planes * 2.0 * a.M * a.N * kreal;
     prof_note_saved(flops - planes * 2.0 * a.M * a.N * kreal);
     ProfScope ps((a.ntaps || a.prof_flops > 0.0) ? PC_CONV3 : PC_LINEAR, flops,
-                 (a.phase2x ? abytes : planes * abytes) + planes * ((double)a.N * kreal * 2.0 + obytes), stream);
+                 (a.phase2x == 1 ? abytes : planes * abytes) + planes * ((double)a.N * kreal * 2.0 + obytes), stream);
     const bool wide_ok0 = split == 1 && a.out2 == nullptr && a.out_mode == OUT_BF16 && (a.act != ACT_GEGLU || a.N % 160 == 0 || a.N % 128 == 0) && (a.N & 7) == 0 &&
                          (a.ld_out & 7) == 0 && (!a.resid || (a.ld_res & 7) == 0);
     const bool wide_ok = wide_ok0 && a.nbatch <= 1;       // batched launches: gemm_bf16_kernel tiles only (the 256 x 320 one when pinned)

@@ -150,7 +150,7 @@ DFH_DEVICE void wide_epilogue(const GemmArgs& a, f32x4_t (&acc)[BM / 2 / 16][BN 
       }
       const uint4 packed = pack8(v);
       long orow = m;
-      if (a.phase2x) {                                 // phase plane of an upsample conv (gemm.h): source pixel -> its pixel of the 2H x 2W image
+      if (a.phase2x == 1) {                            // phase plane of an upsample conv (gemm.h): source pixel -> its pixel of the 2H x 2W image
         const int hw = a.Hout * a.Wout, pb = m / hw, rem = m - pb * hw;
         const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
         orow = (long)pb * 4 * hw + (long)(2 * oy + (int)(blockIdx.y >> 1)) * (2 * a.Wout) + 2 * ox + (int)(blockIdx.y & 1);

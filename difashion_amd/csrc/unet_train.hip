@@ -198,7 +198,63 @@ struct dfh_unet::TrainRun {
 #define TR_OP(call) do { if (!rc && !dry) rc = (call); } while (0)
 
   // ------------------------------------------------------------------ layers
+  // Upsample2D (nearest 2x, then conv3x3) through its four PHASE PLANES, forward AND backward (gemm.h GemmArgs::phase2x; the inference
+  // walk has run the forward this way since round 3): output pixel (2y + py, 2x + px) sees a 2x2 neighbourhood of the SOURCE image with
+  // the summed taps, so forward, data gradient and weight gradient each execute 4/9 of the multiply-adds of the conv over the upsampled
+  // image, and neither the upsampled tensor nor its gradient exists.
+  //   forward : one launch over the four planes with the summed weights WP [4][Co][4 Ci] (re-derived every step: the weights move)
+  //   dW      : the output gradient gathered phase-major, one weight-gradient launch per plane over the source image (WgradArgs::tap2)
+  //             into dWP [4][Co][4 Ci], un-folded onto the packed 3x3 gradient (each 3x3 tap sums the four slots it was folded into)
+  //   dX      : one launch over the four planes (phase2x = 2: mirrored taps, transposed weights WPT [4][Ci][4 Co]), the four planes summed
+  GT conv_up_phase(const GT& x, const ConvL& c) {
+    const int H = x.H, W = x.W, Ci = x.C, Co = c.cout, M = B * H * W;
+    GT o = act(2 * H, 2 * W, Co, true);
+    bf16_t* WP = buf((size_t)16 * Co * Ci);
+    bf16_t* WPT = buf((size_t)16 * Co * Ci);
+    TR_OP(dfh::ups_phase_fold_launch(w16(c.w), c.w.K, WP, Co, Ci, s));
+    for (int p = 0; p < 4; ++p)      // the four slots of a plane are [Co][Ci] blocks side by side: transposed block by block
+      TR_OP(dfh::transpose_bf16_launch(WP + (size_t)p * Co * 4 * Ci, WPT + (size_t)p * Ci * 4 * Co, 4, Co, Ci, 4 * Ci, 4 * Co, Ci, Co, s));
+    GemmArgs f = base(M, Co);
+    f.conv_src = x.p; f.conv_c = Ci; f.ntaps = 4; f.phase2x = 1; f.nbatch = 4; f.w_bs = (long)Co * 4 * Ci;
+    f.Hin = H; f.Win = W; f.Hout = H; f.Wout = W; f.stride = 1; f.rows_per_b = H * W;
+    f.W = WP; f.ldw = 4 * Ci; f.bias = v32(c.b); f.out = o.p;
+    gemm(f);
+    const size_t mark = gtemp.off;
+    bf16_t* dyp = gbuf((size_t)4 * M * Co);
+    bf16_t* dxp = gbuf((size_t)4 * M * Ci);
+    float* dwp = (float*)gtemp.alloc((size_t)16 * Co * Ci * sizeof(float));
+    gtemp.off = mark;
+    const ConvL* cp = &c;
+    tape.push_back([=] {
+      TR_OP(dfh::phase_gather_launch(o.g, dyp, B, H, W, Co, s));
+      for (int p = 0; p < 4 && !rc; ++p) {
+        WgradArgs w; std::memset(&w, 0, sizeof(w));
+        w.conv_src = x.p; w.conv_c = Ci; w.ntaps = 4; w.tap2 = 1; w.tap_py = p >> 1; w.tap_px = p & 1;
+        w.Hin = H; w.Win = W; w.Hout = H; w.Wout = W; w.stride = 1;
+        w.dY = dyp + (size_t)p * M * Co; w.ldy = Co; w.zero = zero; w.M = M; w.N = Co;
+        w.dW = dwp + (size_t)p * Co * 4 * Ci; w.ldw = 4 * Ci; w.overwrite = 1; w.dbias = g32(cp->b);
+        w.partial = partial; w.partial_cap = partial_cap / sizeof(float);
+        if (dry) { partial_need = std::max(partial_need, dfh::wgrad_partial_floats(w) * sizeof(float)); continue; }
+        rc = dfh::wgrad_launch(w, s);
+      }
+      if (dry && cur_entry >= 0) writes.push_back({(size_t)cur_entry, cp->w.off, cp->w.off + (size_t)Co * cp->w.K});
+      TR_OP(dfh::ups_phase_unfold_launch(dwp, u->grad16 + cp->w.off, Co, Ci, cp->w.K, 1, s));
+      GemmArgs g = base(M, Ci);
+      g.conv_src = dyp; g.conv_c = Co; g.ntaps = 4; g.phase2x = 2; g.nbatch = 4;
+      g.a_bs = (long)M * Co; g.w_bs = (long)Ci * 4 * Co; g.o_bs = (long)M * Ci;
+      g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.stride = 1; g.rows_per_b = H * W;
+      g.W = WPT; g.ldw = 4 * Co; g.out = dxp;
+      gemm(g);
+      const bool a = acc(x);
+      TR_OP(dfh::phase_sum4_launch(dxp, x.g, (long)M * Ci, a ? 1 : 0, s));
+    });
+    return o;
+  }
+
   GT conv(const GT& x, const ConvL& c, int stride, int ups) {
+    // DFH_TRAIN_UPS_PHASE=0: the upsample convs as one 3x3 conv over the virtual upsampled image + 2x2 sum pool in the backward (A/B)
+    static const bool ph_off = [] { const char* e = getenv("DFH_TRAIN_UPS_PHASE"); return e && e[0] == '0'; }();
+    if (ups == 1 && !ph_off && x.C % 8 == 0 && c.cout % 8 == 0 && x.C == c.cin) return conv_up_phase(x, c);
     const int Ho = ups ? x.H * 2 : (stride == 2 ? x.H / 2 : x.H);
     const int Wo = ups ? x.W * 2 : (stride == 2 ? x.W / 2 : x.W);
     GT o = act(Ho, Wo, c.cout, true);

@@ -17,6 +17,10 @@ struct WgradArgs {
   float* dbias;                  // optional fp32 [N]: += column sums of dY (bias gradient), fused into the same pass
   int msplit;                    // 0 = heuristic
   int xblocks;                   // filled by the launcher: n-tiles x kcol-chunks
+  // one PHASE PLANE of a nearest-2x upsample + 3x3 conv (gemm.h GemmArgs::phase2x): ntaps = 4, stride 1 over the SOURCE image, segment s =
+  // the 3x3-tap position (tap_py + (s >> 1), tap_px + (s & 1)); dY = the plane's rows of the output gradient (gathered phase-major);
+  // dW = the gradient of the plane's SUMMED weights [N][4 * conv_c] (un-folded onto the 3x3 taps by ups_phase_unfold)
+  int tap2, tap_py, tap_px;
 };
 
 namespace dfh {

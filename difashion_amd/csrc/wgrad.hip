@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradArgs a) {
   }
   const int c0 = kc * TK, wcol = base + c0;
   const bool conv = seg < a.ntaps;
-  const int ky = conv ? seg / 3 : 0, kx = conv ? seg - ky * 3 : 0;
+  // tap2 (phase plane (py, px) of an upsample conv, wgrad.h): the four segments are the 3x3-tap positions (py + (s >> 1), px + (s & 1))
+  const int ky = conv ? (a.tap2 ? a.tap_py + (seg >> 1) : seg / 3) : 0, kx = conv ? (a.tap2 ? a.tap_px + (seg & 1) : seg - (seg / 3) * 3) : 0;
   const bf16_t* psrc = conv ? a.conv_src : (seg == a.ntaps ? a.p_src[0] : a.p_src[1]);
   const int pc = seglen;
 
@@ -346,7 +347,7 @@ int wgrad_launch(WgradArgs a, hipStream_t s) {
   DFH_REQUIRE(a.M > 0 && a.N > 0 && a.N % 4 == 0 && a.ldy % 8 == 0 && a.ldy >= ((a.N + 7) & ~7),
               "wgrad: N must be a positive multiple of 4, dY rows padded to a multiple of 8 columns");
   DFH_REQUIRE(a.M < (1 << 24), "wgrad: M must be below 2^24");
-  DFH_REQUIRE(a.ntaps == 0 || a.ntaps == 9, "ntaps must be 0 or 9");
+  DFH_REQUIRE(a.ntaps == 0 || a.ntaps == 9 || (a.ntaps == 4 && a.tap2 && a.stride == 1 && a.ups == 0), "ntaps must be 0 or 9 (4: one phase plane of an upsample conv)");
   DFH_REQUIRE(a.ntaps + a.nplain >= 1 && a.zero && a.dY && a.dW, "wgrad: missing operand");
   DFH_REQUIRE(a.ldw % 4 == 0 && ((uintptr_t)a.dW & 15) == 0, "wgrad: dW rows must be 16-byte aligned");
   wgrad_plan(a);

@@ -7,7 +7,7 @@ to 12, so they are compared in relative L2: raw U-Net output <= 3e-2 at EVERY st
 trajectory feeds both U-Nets), final latents of the free-running sampler <= 8e-2 after 6-10 steps AND after 50
 (observed values are printed: ~1.6e-2 and ~0.01-0.06); the product sampler's combined guided epsilon is checked at step 0,
 where the trajectories have not yet diverged (the guidance mix u + 4(a-cm) + 5(cm-c) + 12(c-u) amplifies the per-branch
-error by its coefficients: bound 0.25, see test_sampler_vs_reference_golden)."""
+error by its coefficients: bound 0.10, see test_sampler_vs_reference_golden)."""
 import glob
 import os
 
@@ -93,6 +93,31 @@ def test_sampler_vs_reference_golden(case, unet):
     # measured 1.6e-2 .. 7.9e-2 over the 14 cases (the guidance scales 12 / 5 / 4 amplify the per-branch error of <= 3e-2 by the
     # norm ratio of the weighted difference to the combination); 0.25 until round 3
     assert eps_err <= 0.10
+
+
+@pytest.mark.parametrize("case", ["gor_full_ddim10", "fitb_full_ddim10"])
+def test_fp8_sampler_vs_reference_golden(case):
+    """BASELINE configs[4] end to end ("fp8 ... path, CFG batch, 4-item GOR sampling"): the product sampler with the U-Net in fp8 mode (every
+    transformer linear in e4m3) against the golden run of the REAL reference glue.  Stated tolerances of the fp8 walk: raw U-Net output
+    of the first step <= 6e-2, final latents after the 10 guided steps <= 0.15 (bf16 walk: 3e-2 / 8e-2)."""
+    from difashion_amd import _lib
+    rec = load(f"sample_{case}.npz")
+    m = hip_unet(GLUE_CFG, glue_unet_params(), max_batch=32)
+    m.enable_fp8()
+    sc, sh, sm = (float(v) for v in rec["scales"])
+    taps = {}
+    d = lambda k: rec[k].to(DEV)
+    _lib.census_reset()
+    final = da.sample_outfits(m, encoder(rec), da.DDIMScheduler(), olists=rec["olists"], all_latents=d("all_latents"),
+                              init_latents=d("init_latents"), hist_latents=d("hist_sel"), null_latent=d("null_latent"),
+                              category_prompts=d("category_prompts"), null_prompt=d("null_prompt"),
+                              num_inference_steps=int(rec["steps"]), cate_scale=sc, hist_scale=sh, mutual_scale=sm,
+                              eta=0.1, use_history=bool(rec["use_history"]), use_mutual_guidance=bool(rec["use_mutual"]), taps=taps)
+    torch.cuda.synchronize()
+    assert _lib.census()["gemm_fp8"] > 0
+    e0, ef = rel_err(taps["unet_out_0"].cpu(), rec["unet_out_0"]), rel_err(final.cpu(), rec["final"])
+    print(case, f"fp8: unet_out_0 {e0:.2e} final {ef:.2e}")
+    assert e0 <= 6e-2 and ef <= 0.15
 
 
 @pytest.mark.parametrize("case", ["gor_full_ddim10", "mix_full_pndm10", "gor_full_ddim50"])

@@ -49,7 +49,9 @@ DFH_DEVICE unsigned e8m0_of(float am, float* inv) {
 
 // PB x 32 pixel rows per wave (4 waves side by side along the pixels), BN output channels per tile; MX: the activations carry E8M0 block
 // scales (one byte per row and 32 contraction elements, Fp8GemmArgs::sx), fed to the MFMA's scale operand
-template <int PB, int BN, bool MX>
+// TOUT: the transposed (V^T) output mode, its own instantiation (the 256 x 160 tile is at the register limit: compiled into the row-major
+// kernel it spilled)
+template <int PB, int BN, bool MX, bool TOUT>
 __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
   constexpr int BM = 4 * PB * 32;
   constexpr int NCI = BN / 32;                               // 32-channel accumulator blocks per wave
@@ -203,9 +205,32 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
     const int m = m0 + wave * PB * 32 + pj * 32 + ql;
     const bool m_ok = m < a.M;
     const float sa = m_ok ? (a.sA ? a.sA[m / a.sa_div] : 1.0f) * a.sa_mul : 0.f;
-    if (a.out_mode == OUT_BF16_T) {                          // attention V^T: out[b][n][mm], scattered 2-byte stores
+    if constexpr (TOUT) {                                    // attention V^T: out[b][n][mm]
       float am = 0.f;
       const int b = m_ok ? m / a.rows_per_b : 0, mm = m - b * a.rows_per_b;
+      const int m_first = m0 + wave * PB * 32 + pj * 32;
+      // whole 32-row blocks inside one image: the block is staged TRANSPOSED through the wave's LDS region and leaves as 16-byte
+      // pieces along the pixel axis (10 store instructions per lane instead of 80 two-byte ones)
+      if (a.rows_per_b % 32 == 0 && m_first + 32 <= a.M && a.ld_out % 8 == 0 && n0 + BN <= a.N) {
+#pragma unroll
+        for (int ci = 0; ci < NCI; ++ci)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = ci * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+            float v = acc[ci][pj][r] * sa * swl[c];
+            if (a.bias) v += bl[c];
+            const bf16_t o = f2bf(v);
+            am = fmaxf(am, fabsf(bf2f(o)));
+            *(bf16_t*)(stage + c * 64 + ql * 2) = o;         // [BN columns][32 pixels]
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int bb = m_first / a.rows_per_b, mm0 = m_first - bb * a.rows_per_b;
+        for (int q = lane; q < BN * 4; q += 64) {
+          const int c = q >> 2, part = q & 3;
+          *(uint4*)((bf16_t*)a.out + ((long)bb * a.N + n0 + c) * a.ld_out + mm0 + part * 8) = *(const uint4*)(stage + c * 64 + part * 16);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else
       if (m_ok) {
 #pragma unroll
         for (int ci = 0; ci < NCI; ++ci)
@@ -227,14 +252,13 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
         if (a.rows_per_b % 32 == 0) {
 #pragma unroll
           for (int o = 32; o > 0; o >>= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
-          const int m_first = m0 + wave * PB * 32 + pj * 32;
           if (lane == 0 && m_first < a.M) atomicMax((unsigned*)a.amax + m_first / a.rows_per_b, __float_as_uint(am));
         } else if (m_ok) {
           atomicMax((unsigned*)a.amax + b, __float_as_uint(am));
         }
       }
       continue;
-    }
+    } else {
     if (geglu) {
       // rows 0..15 of a 32-row block are values, 16..31 the gates of the same 16 hidden units (packed in 16-row blocks): lane (ql, kh)
       // ends with hidden units ci*16 + 8 g + 4 kh + j (g = 0, 1; j = 0..3) of pixel ql
@@ -342,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the next block overwrites the region
+    }
   }
 }
 
@@ -460,18 +485,18 @@ __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const bf16_t* __rest
   }
 }
 
-template <int PB, int BN, bool MX>
+template <int PB, int BN, bool MX, bool TOUT = false>
 int launch_fp8(const Fp8GemmArgs& a, hipStream_t s) {
   constexpr int BM = 4 * PB * 32;
   constexpr int lds = NST8 * ((BM + BN) * KB8 + (MX ? 4 * PB * 64 : 0));
   static_assert(lds <= 80 * 1024, "two workgroups per CU");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_fp8_kernel<PB, BN, MX>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)gemm_fp8_kernel<PB, BN, MX, TOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_fp8_kernel<PB, BN, MX>), dim3(tiles), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((gemm_fp8_kernel<PB, BN, MX, TOUT>), dim3(tiles), dim3(256), lds, s, a);
   return dfh::check_launch("gemm_fp8_kernel");
 }
 
@@ -530,6 +555,11 @@ int gemm_fp8_launch(Fp8GemmArgs a, hipStream_t stream) {
   // 256-row tiles while they still give every CU two workgroups, 128-row tiles below
   const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + bn - 1) / bn);
   const bool big = tiles256 >= 384;
+  if (a.out_mode == OUT_BF16_T) {
+    DFH_REQUIRE(!mx, "fp8 GEMM: the transposed output takes per-row activation scales (no E8M0 block scales)");
+    if (bn == 160) return big ? launch_fp8<2, 160, false, true>(a, stream) : launch_fp8<1, 160, false, true>(a, stream);
+    return big ? launch_fp8<2, 128, false, true>(a, stream) : launch_fp8<1, 128, false, true>(a, stream);
+  }
   if (bn == 160) {
     if (mx) return big ? launch_fp8<2, 160, true>(a, stream) : launch_fp8<1, 160, true>(a, stream);
     return big ? launch_fp8<2, 160, false>(a, stream) : launch_fp8<1, 160, false>(a, stream);

@@ -503,6 +503,7 @@ struct dfh_unet {
     // fold slots, so the whole inference walk then stays on the unfolded path (fold_valid stays false)
     for (AttL* a : all_att()) if (a->C % 8) return 0;
     for (AttL* a : all_att()) {
+      if (fp8 && a->qk8.on) continue;                 // the fp8 walk of this layer reads none of the folded bf16 copies: not derived
       const Mat* src[4] = {&a->qk, &a->v, &a->q2, &a->ff1};
       const Fold* dst[4] = {&a->fqk, &a->fv, &a->fq2, &a->fff1};
       const Vec* gam[4] = {&a->l1w, &a->l1w, &a->l2w, &a->l3w};
@@ -535,6 +536,7 @@ struct dfh_unet {
     for (AttL* a : all_att()) {
       const int C = a->C;
       if (C % 8) continue;
+      if (fp8 && a->pout8.on) continue;               // fp8 walk: ff.net.2 and proj_out are two e4m3 launches, the folded matrix is unused
       DFH_REQUIRE(fold_bytes() + 256 + (size_t)4 * C * C * 2 <= ws_bytes, "workspace too small for the weight-fold scratch");
       bf16_t* w2t = scratch + 128;
       if (int rc = dfh::transpose_bf16_launch(arena16 + a->ff2.off, w2t, 1, C, 4 * C, 4 * C, C, 0, 0, s)) return rc;

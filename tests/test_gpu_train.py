@@ -390,6 +390,50 @@ def test_sd15_full_size_backward_matches_oracle_autograd():
     assert worst[1] <= GRAD_TOL and tot <= ALL_TOL and dx_err <= GRAD_TOL, (worst, tot, dx_err)
 
 
+@pytest.mark.timeout(1500)
+def test_sd15_full_size_batch32_gradients_are_the_mean_of_its_two_halves():
+    """BASELINE configs[2] at its FULL size (SD-1.5 shape, 8 outfits x 4 items = 32 rows, what bench.py --mode train times): a
+    size-independent property instead of the oracle (fp32 autograd through 32 rows of the 860 M-parameter net takes hours on the host).
+    The loss is a mean over rows, so the gradient of the 32-row batch equals the mean of the gradients of its two 16-row halves --
+    accumulated by the native backward into the same .grad views -- for every parameter; what differs is bf16 accumulation order and
+    tile choice (M = 131072 vs 65536 rows: other tiles, split factors, pixel splits of the weight-gradient GEMM).  The outputs of
+    the three forwards must agree row by row as well."""
+    cfg = unet_ref.SD15
+    params = unet_ref.init_params(cfg, seed=0)
+    m = hip_unet(cfg, params, max_batch=32).train()
+    del params
+    x, e = inputs(cfg, 32, 321)
+    g = torch.Generator().manual_seed(10)
+    t = torch.randint(0, 1000, (32,), generator=g)
+    dout = torch.randn(32, cfg.out_channels, cfg.sample_size, cfg.sample_size, generator=g)
+    xd, td, ed, dd = x.to(DEV), t.to(DEV), e.to(DEV), dout.to(DEV)
+    out = m(xd, td, ed).sample
+    out.backward(dd / 32)
+    torch.cuda.synchronize()
+    full = {k: p.grad.clone() for k, p in m.named_parameters()}
+    for p in m.parameters():
+        p.grad = None
+    halves = []
+    for sl in (slice(0, 16), slice(16, 32)):
+        o = m(xd[sl], td[sl], ed[sl]).sample
+        o.backward(dd[sl] / 32)                      # accumulates into the same gradient views
+        halves.append(o.detach())
+    torch.cuda.synchronize()
+    assert rel_err(torch.cat(halves), out.detach()) <= 2e-2
+    scale = max(float(v.norm()) for v in full.values())
+    worst, num, den = ("", 0.0), 0.0, 0.0
+    for k, p in m.named_parameters():
+        d = float((p.grad - full[k]).norm())
+        err = d / max(float(full[k].norm()), FLOOR * scale)
+        num += d * d
+        den += float(full[k].norm()) ** 2
+        if err > worst[1]:
+            worst = (k, err)
+    tot = (num / den) ** 0.5
+    print(f"sd15 B=32 vs 2 x B=16: worst={worst[0]}:{worst[1]:.2e} overall={tot:.2e}")
+    assert worst[1] <= 4e-2 and tot <= 2e-2, (worst, tot)
+
+
 def test_segmented_backward_equals_the_monolithic_one():
     """dfh_unet_backward_begin / _next / _finish (the pieces behind the overlapped gradient all-reduce): the ranges handed
     out are disjoint, cover every written float of the packed gradient arena exactly once, and the master gradients equal

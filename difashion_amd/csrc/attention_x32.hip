@@ -708,7 +708,12 @@ namespace dfh {
 
 // 0 = not handled here (the caller falls back to attention_kernel)
 bool attention_x32_eligible(const AttnArgs& a) {
-  if (a.D != 40 && a.D != 80) return false;
+  // 40 / 80: SD-1.5 (8 heads); 64: SD-2-base, the reference's own default (stabilityai/stable-diffusion-2-base, train.py:44,
+  // inf4eval.py:65: head dim 64 at every level)
+  if (a.D != 40 && a.D != 64 && a.D != 80) return false;
+  // d = 64: only the long self-attention launches (64x64 level 478 -> 412 us, 32x32 level equal); below that and for the 77 text keys
+  // the 16x16x32 kernel measures the same or a little better (profiles/r04/attn_sd2_microbench.txt)
+  if (a.D == 64) return a.Nq >= 1024 && a.Nk >= 1024;
   return a.Nq >= 256 && a.Nk >= 64;
 }
 
@@ -718,6 +723,7 @@ int attention_x32_launch(const AttnArgs& a, hipStream_t stream) {
   static const bool xs_off = [] { const char* e = getenv("DFH_ATTN_XS"); return e && e[0] == '0'; }();
   if (!xs_off && a.Nk <= 2 * KVT && a.lse == nullptr) {
     if (a.D == 40) return launch_xs<40, 2>(a, stream);
+    if (a.D == 64) return launch_xs<64, 1>(a, stream);
     if (a.D == 80) return launch_xs<80, 1>(a, stream);
   }
 #ifdef DFH_PROBES   // experiment instantiations (one / four query blocks per wave, phase stamps): probe builds only (scripts/probes/Makefile)
@@ -755,6 +761,10 @@ int attention_x32_launch(const AttnArgs& a, hipStream_t stream) {
 #endif
   switch (a.D) {
     case 40: return launch_x32<40, 2, 2>(a, stream);
+    case 64: {
+      static const int qb64 = [] { const char* e = getenv("DFH_ATTN_QB64"); return e ? atoi(e) : 2; }();     // probe knob
+      return qb64 == 1 ? launch_x32<64, 1, 2>(a, stream) : launch_x32<64, 2, 2>(a, stream);
+    }
     case 80: return launch_x32<80, 1, 2>(a, stream);
     default: break;
   }

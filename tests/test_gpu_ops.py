@@ -557,8 +557,8 @@ def test_attention_online_softmax_rescale_is_exercised():
     gu.assert_close_bf16(o, ref, "rescale", rel=1e-2, max_rel=4e-2)
 
 
-@pytest.mark.parametrize("d,heads", [(40, 8), (80, 4)])
-@pytest.mark.parametrize("Nq,Nk", [(256, 64), (512, 77), (300, 200), (2048, 2048), (512, 640), (1024, 129)])
+@pytest.mark.parametrize("d,heads", [(40, 8), (80, 4), (64, 5)])
+@pytest.mark.parametrize("Nq,Nk", [(256, 64), (512, 77), (300, 200), (2048, 2048), (512, 640), (1024, 129), (1030, 1100)])
 def test_attention_x32_shapes(d, heads, Nq, Nk):
     """The 32x32x16 kernel (attention_x32.hip) takes d = 40 / 80 with Nq >= 256, Nk >= 64: full tiles, ragged key
     tails in the first / second / a later LDS buffer (masked through the spare contraction slot), ragged query blocks."""

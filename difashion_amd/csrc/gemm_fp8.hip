@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
 
 // LayerNorm with the fp8 quantisation of its output fused: one wave per R token rows (C <= 2048), exact two-pass variance in
 // registers like layernorm_kernel (norm.hip, incl. its rows-in-flight scheme: all R rows are loaded before the first is reduced);
-// the row maximum of |y| gives the token's scale.
+// the row maximum of |y| (of the fp32 normalised value: it is quantised directly) gives the token's scale.
 template <int MAXO, int R>
 __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, uint8_t* __restrict__ q,
@@ -435,6 +435,8 @@ __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const bf16_t* __rest
   for (int r = 0; r < R; ++r) {
     const int row = row0 + r;
     if (row >= M) break;
+    // the kernel is VALU-issue bound (40 of 64 lanes hold data at C = 320): the centred values of the variance pass are kept and
+    // normalised with one multiply + one fma per element; the fp32 value is quantised directly (no bf16 round trip)
     float v[MAXO][8];
     float s = 0.f;
 #pragma unroll
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const bf16_t* __rest
     for (int i = 0; i < MAXO; ++i) {
       if (lane + i * 64 < C8) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mean; qq += d * d; }
+        for (int k = 0; k < 8; ++k) { v[i][k] -= mean; qq = fmaf(v[i][k], v[i][k], qq); }
       }
     }
     const float rstd = rsqrtf(wave_sum(qq) / (float)C + eps);
@@ -461,8 +463,7 @@ __global__ __launch_bounds__(256) void layernorm_fp8_kernel(const bf16_t* __rest
       if (lane + i * 64 < C8) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          // the bf16 path rounds the normalised value to bf16 before the GEMM reads it; quantise that same value
-          v[i][k] = bf2f(f2bf((v[i][k] - mean) * rstd * gg[i][k] + bb[i][k]));
+          v[i][k] = fmaf(v[i][k], rstd * gg[i][k], bb[i][k]);
           amax = fmaxf(amax, fabsf(v[i][k]));
         }
       }

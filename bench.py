@@ -167,7 +167,15 @@ def run_train(args, da, _lib, ddist, rank, world, dev):
         _lib.prof_begin()
         for _ in range(K):
             step()
+        dump = None
+        if os.environ.get("DFH_PROF_TABLE"):                      # per-shape launch table of the training step (diagnosis)
+            import tempfile
+            dump = os.path.join(tempfile.gettempdir(), f"dfh_prof_dump_{os.getpid()}.txt")
+            os.environ["DFH_PROF_DUMP"] = dump
         classes = _lib.prof_end()
+        if dump:
+            os.environ.pop("DFH_PROF_DUMP", None)
+            per_launch_bound(dump, K)
     if world > 1:
         ddist.barrier()
     if rank != 0:

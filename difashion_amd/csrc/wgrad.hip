@@ -325,14 +325,32 @@ static int wgrad_plan(WgradArgs& a) {
   a.ktot = a.ntaps * a.conv_c;
   for (int i = 0; i < a.nplain; ++i) a.ktot += a.p_c[i];
   if (a.msplit <= 0) {
-    // fill 256 CUs x 2 blocks with some slack, but keep >= 512 contraction rows per block so that the fp32-atomic
-    // epilogue (100 KB per block) stays small next to the 20 KB per 32 rows the pipeline streams
-    // m-slices come in multiples of 8 (one per XCD, see the kernel) or not at all
+    // m-slices come in multiples of 8 (one per XCD, see the kernel) or not at all.  The count is the cheapest candidate of a small cost
+    // model fitted to a sweep over the layer shapes of the step (profiles/r04/wgrad_msplit_sweep.txt): the chip holds 512 blocks at a
+    // time (256 CUs x 2), so the blocks run in rounds of 512 -- a last round of <= 256 blocks has a CU to itself per block and takes
+    // 0.7 of a full one -- at 0.9 PFLOP/s when full, and every slice adds one fp32 slab of the gradient that is written and read back.
     const int blocks = ntn * chunks;
-    int ms = std::min((640 + blocks - 1) / blocks, a.M / 512);
-    ms = blocks >= 384 ? 1 : (ms + 7) / 8 * 8;
-    while (ms > 8 && a.M / ms < 512) ms -= 8;
-    a.msplit = (ms >= 8 && a.M / ms >= 128) ? ms : 1;
+    static const bool old_rule = [] { const char* e = getenv("DFH_WGRAD_PLAN"); return e && e[0] == '0'; }();
+    if (old_rule) {
+      int ms = std::min((640 + blocks - 1) / blocks, a.M / 512);
+      ms = blocks >= 384 ? 1 : (ms + 7) / 8 * 8;
+      while (ms > 8 && a.M / ms < 512) ms -= 8;
+      a.msplit = (ms >= 8 && a.M / ms >= 128) ? ms : 1;
+    } else {
+      const double work_us = 2.0 * a.M * a.N * a.ktot / 0.9e15 * 1e6, slab_us = (double)a.N * a.ktot * 8.0 / 5e12 * 1e6;
+      auto cost = [&](int ms) {
+        const int b = blocks * ms, full = b / 512, rem = b % 512;
+        const double rounds = full + (rem == 0 ? 0.0 : rem <= 256 ? 0.7 : 1.0);
+        return work_us / b * 512.0 * rounds + (ms > 1 ? ms * slab_us : 0.0);
+      };
+      int best = 1;
+      double best_c = cost(1);
+      for (int ms = 8; ms <= 64 && a.M / ms >= 512; ms += 8) {
+        const double c = cost(ms);
+        if (c < best_c) { best_c = c; best = ms; }
+      }
+      a.msplit = best;
+    }
   }
   a.xblocks = ntn * chunks;
   return 0;

@@ -13,12 +13,16 @@ DFH_DEVICE int tab_geglu_row(int n, int N) {
 
 // Work decomposition per kind (tab_blocks() below): every global access is a coalesced run --
 //   VEC / PACK_MAT / UNPACK_MAT : 2048 consecutive master elements per block (k is contiguous on both sides);
-//   PACK_CONV / UNPACK_CONV     : 256 (o, c) pairs per block, each thread walks its 9 taps (36 contiguous master bytes;
-//                                 per tap the wave touches 64 consecutive packed channels);
-//   PACKT_MAT / PACKT_CONV      : 32 x 32 tiles transposed through LDS (rows of the master become columns of the pack).
+//   PACK_CONV / UNPACK_CONV     : 256 (o, c) pairs per block = 2304 consecutive master floats, moved as float4 and turned through LDS
+//                                 (per tap the wave touches 64 consecutive packed channels);
+//   PACKT_MAT / PACKT_CONV      : 64 x 32 tiles transposed through LDS (rows of the master become columns of the pack; 64 outputs =
+//                                 one full 128-byte line per store).
+constexpr int TT_O = 64, TT_C = 32, TT_LD = TT_C * 9 + 2;       // transposed-pack tile: 64 outputs x 32 inputs (x 9 taps), odd dword stride
 __global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ ops, int nops, void* arena_vec, void* arena_mat) {
   __shared__ int s_op;
-  __shared__ bf16_t tile[32][32 * 9 + 2];
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[TT_O * TT_LD * 2];
+  bf16_t (*tile)[TT_LD] = (bf16_t (*)[TT_LD])s_raw;
+  float* stage = (float*)s_raw;                                  // conv kinds: 256 pairs x 9 taps
   if (threadIdx.x == 0) {
     int lo = 0, hi = nops - 1;
     while (lo < hi) {
@@ -54,9 +58,29 @@ __global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ op
       break;
     }
     case TAB_PACK_MAT: case TAB_UNPACK_MAT: {        // p0 = row_off, p1 = col_off, p2 = geglu, p3 = overwrite (unpack)
+      const long total = (long)N * K;
+      if ((K & 3) == 0 && ((uintptr_t)op.master & 15) == 0 && ((op.dst | ld | op.p1) & 3) == 0) {      // four consecutive k of one row per thread
+        for (int j = 0; j < TAB_ELEMS_PER_BLOCK / 1024; ++j) {
+          const long i = blk * TAB_ELEMS_PER_BLOCK + (j * 256 + tid) * 4;
+          if (i >= total) break;
+          const int n = (int)(i / K), k = (int)(i - (long)n * K);
+          const int r = op.p2 ? tab_geglu_row(n, N) : n;
+          const long at = op.dst + (long)(op.p0 + r) * ld + op.p1 + k;
+          float4* m4 = (float4*)((float*)op.master + i);
+          if (op.kind == TAB_PACK_MAT) {
+            const float4 v = *m4;
+            *(uint2*)((bf16_t*)arena_mat + at) = uint2{pack2bf(v.x, v.y), pack2bf(v.z, v.w)};
+          } else {
+            float4 g = *(const float4*)((const float*)arena_mat + at);
+            if (!op.p3) { const float4 v = *m4; g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w; }
+            *m4 = g;
+          }
+        }
+        break;
+      }
       for (int j = 0; j < TAB_ELEMS_PER_BLOCK / 256; ++j) {
         const long i = blk * TAB_ELEMS_PER_BLOCK + j * 256 + tid;
-        if (i >= (long)N * K) break;
+        if (i >= total) break;
         const int n = (int)(i / K), k = (int)(i - (long)n * K);
         const int r = op.p2 ? tab_geglu_row(n, N) : n;
         const long at = op.dst + (long)(op.p0 + r) * ld + op.p1 + k;
@@ -66,50 +90,104 @@ __global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ op
       break;
     }
     case TAB_PACK_CONV: case TAB_UNPACK_CONV: {      // N = Cout, K = Cin, p1 = col_off, p3 = cin_pad, p0 = overwrite (unpack)
-      const long oc = blk * 256 + tid;
-      if (oc >= (long)N * K) break;
-      const int c = (int)(oc % K), o = (int)(oc / K);
+      const long pairs = (long)N * K, oc = blk * 256 + tid;
+      const long f0 = blk * 2304, fn = min((long)2304, pairs * 9 - f0);      // this block's run of master floats
+      float* mst = (float*)op.master + f0;
+      const bool vec4 = ((uintptr_t)mst & 15) == 0 && (fn & 3) == 0;
+      const bool live = oc < pairs;
+      const int c = live ? (int)(oc % K) : 0, o = live ? (int)(oc / K) : 0;
       const long at = op.dst + (long)o * ld + op.p1 + c;
-      if (op.kind == TAB_PACK_CONV) {
-        const float* w = (const float*)op.master + oc * 9;
+      if (op.kind == TAB_PACK_CONV) {                  // reads: nine strided passes over the same 36 lines, absorbed by the L1
+        if (live) {
+          const float* w = (const float*)op.master + oc * 9;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) ((bf16_t*)arena_mat)[at + t * op.p3] = f2bf(w[t]);
+          for (int t = 0; t < 9; ++t) ((bf16_t*)arena_mat)[at + t * op.p3] = f2bf(w[t]);
+        }
       } else {
-        float* g = (float*)op.master + oc * 9;
+        if (live) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) g[t] = op.p0 ? ((const float*)arena_mat)[at + t * op.p3] : g[t] + ((const float*)arena_mat)[at + t * op.p3];
-      }
-      break;
-    }
-    case TAB_PACKT_MAT: {       // out[(p0 + k) * ld + p1 + r(n)] = w[n][k];  p2 = geglu; tiles of 32 n x 32 k
-      const int tk = (K + 31) / 32;
-      const int n0 = (int)(blk / tk) * 32, k0 = (int)(blk % tk) * 32;
-      for (int j = tid; j < 1024; j += 256) {
-        const int n = n0 + (j >> 5), k = k0 + (j & 31);
-        tile[j >> 5][j & 31] = (n < N && k < K) ? f2bf(((const float*)op.master)[(long)n * K + k]) : (bf16_t)0;
-      }
-      __syncthreads();
-      for (int j = tid; j < 1024; j += 256) {
-        const int k = k0 + (j >> 5), n = n0 + (j & 31);
-        if (n < N && k < K) {
-          const int r = op.p2 ? tab_geglu_row(n, N) : n;      // runs of 16 consecutive n stay consecutive
-          ((bf16_t*)arena_mat)[op.dst + (long)(op.p0 + k) * ld + op.p1 + r] = tile[j & 31][j >> 5];
+          for (int t = 0; t < 9; ++t) stage[tid * 9 + t] = ((const float*)arena_mat)[at + t * op.p3];
+        }
+        __syncthreads();
+        if (vec4) {
+          for (int j = tid * 4; j < fn; j += 1024) {
+            float4 v = *(const float4*)(stage + j);
+            if (!op.p0) { const float4 g = *(const float4*)(mst + j); v.x += g.x; v.y += g.y; v.z += g.z; v.w += g.w; }
+            *(float4*)(mst + j) = v;
+          }
+        } else {
+          for (int j = tid; j < fn; j += 256) mst[j] = op.p0 ? stage[j] : mst[j] + stage[j];
         }
       }
       break;
     }
-    case TAB_PACKT_CONV: {      // out[c * ld + p1 + (8 - t) * o_pad + o] = w[o][c][t];  N = Cout, K = Cin, p3 = o_pad; 32 o x 32 c tiles
-      const int tc = (K + 31) / 32;
-      const int o0 = (int)(blk / tc) * 32, c0 = (int)(blk % tc) * 32;
-      const int cw = min(32, K - c0);                // channels of this tile: a master row piece of cw * 9 contiguous floats
-      for (int ol = 0; ol < 32; ++ol) {
-        const int o = o0 + ol;
-        for (int j = tid; j < cw * 9; j += 256)
-          tile[ol][j] = o < N ? f2bf(((const float*)op.master)[((long)o * K + c0) * 9 + j]) : (bf16_t)0;
+    case TAB_PACKT_MAT: {       // out[(p0 + k) * ld + p1 + r(n)] = w[n][k];  p2 = geglu; tiles of 64 n x 32 k
+      const int tk = (K + TT_C - 1) / TT_C;
+      const int n0 = (int)(blk / tk) * TT_O, k0 = (int)(blk % tk) * TT_C;
+      const bool fast = (K & 31) == 0 && n0 + TT_O <= N && ((uintptr_t)op.master & 15) == 0 && ((op.dst | ld | op.p1) & 1) == 0;
+      if (fast) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                // 64 rows x 8 float4
+          const int j = u * 256 + tid, nl = j >> 3, q = j & 7;
+          const float4 v = *(const float4*)((const float*)op.master + (long)(n0 + nl) * K + k0 + q * 4);
+          *(uint32_t*)&tile[nl][q * 4] = pack2bf(v.x, v.y);
+          *(uint32_t*)&tile[nl][q * 4 + 2] = pack2bf(v.z, v.w);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                // 32 k x 32 pairs of n: one 128-byte line per 32 lanes
+          const int j = u * 256 + tid, k = j >> 5, nl = (j & 31) * 2;
+          const uint32_t pr = (uint32_t)tile[nl][k] | ((uint32_t)tile[nl + 1][k] << 16);
+          const int r = op.p2 ? tab_geglu_row(n0 + nl, N) : n0 + nl;      // runs of 16 consecutive n stay consecutive: pairs stay adjacent
+          *(uint32_t*)((bf16_t*)arena_mat + op.dst + (long)(op.p0 + k0 + k) * ld + op.p1 + r) = pr;
+        }
+        break;
+      }
+      for (int j = tid; j < TT_O * TT_C; j += 256) {
+        const int n = n0 + (j >> 5), k = k0 + (j & 31);
+        tile[j >> 5][j & 31] = (n < N && k < K) ? f2bf(((const float*)op.master)[(long)n * K + k]) : (bf16_t)0;
       }
       __syncthreads();
-      for (int j = tid; j < cw * 9 * 32; j += 256) {
-        const int ol = j & 31, ct = j >> 5;          // ct = c_local * 9 + t
+      for (int j = tid; j < TT_O * TT_C; j += 256) {
+        const int k = k0 + (j >> 6), n = n0 + (j & 63);
+        if (n < N && k < K) {
+          const int r = op.p2 ? tab_geglu_row(n, N) : n;      // runs of 16 consecutive n stay consecutive
+          ((bf16_t*)arena_mat)[op.dst + (long)(op.p0 + k) * ld + op.p1 + r] = tile[j & 63][j >> 6];
+        }
+      }
+      break;
+    }
+    case TAB_PACKT_CONV: {      // out[c * ld + p1 + (8 - t) * o_pad + o] = w[o][c][t];  N = Cout, K = Cin, p3 = o_pad; 64 o x 32 c tiles
+      const int tc = (K + TT_C - 1) / TT_C;
+      const int o0 = (int)(blk / tc) * TT_O, c0 = (int)(blk % tc) * TT_C;
+      const int cw = min(TT_C, K - c0);              // channels of this tile: a master row piece of cw * 9 contiguous floats
+      const int run = cw * 9;
+      const bool fast = (K & 31) == 0 && o0 + TT_O <= N && ((uintptr_t)op.master & 15) == 0 && ((op.dst | ld | op.p1 | op.p3) & 1) == 0;
+      if (fast) {                                    // run = 288 floats = 72 float4 per output row; fixed trip counts, loads batched
+#pragma unroll 6
+        for (int u = 0; u < 18; ++u) {
+          const int j = u * 256 + tid, ol = j / 72, q = j - ol * 72;
+          const float4 v = *(const float4*)((const float*)op.master + ((long)(o0 + ol) * K + c0) * 9 + q * 4);
+          *(uint32_t*)&tile[ol][q * 4] = pack2bf(v.x, v.y);
+          *(uint32_t*)&tile[ol][q * 4 + 2] = pack2bf(v.z, v.w);
+        }
+        __syncthreads();
+#pragma unroll 6
+        for (int u = 0; u < 36; ++u) {               // 288 (c, t) columns x 32 pairs of outputs
+          const int j = u * 256 + tid, ct = j >> 5, ol = (j & 31) * 2;
+          const int cl = ct / 9, t = ct - cl * 9;
+          const uint32_t pr = (uint32_t)tile[ol][ct] | ((uint32_t)tile[ol + 1][ct] << 16);
+          *(uint32_t*)((bf16_t*)arena_mat + op.dst + (long)(c0 + cl) * ld + op.p1 + (8 - t) * op.p3 + o0 + ol) = pr;
+        }
+        break;
+      }
+      for (int j = tid; j < TT_O * run; j += 256) {
+        const int ol = j / run, jj = j - ol * run, o = o0 + ol;
+        tile[ol][jj] = o < N ? f2bf(((const float*)op.master)[((long)o * K + c0) * 9 + jj]) : (bf16_t)0;
+      }
+      __syncthreads();
+      for (int j = tid; j < run * TT_O; j += 256) {
+        const int ol = j & 63, ct = j >> 6;          // ct = c_local * 9 + t
         const int cl = ct / 9, t = ct - cl * 9, o = o0 + ol;
         if (o < N) ((bf16_t*)arena_mat)[op.dst + (long)(c0 + cl) * ld + op.p1 + (8 - t) * op.p3 + o] = tile[ol][ct];
       }
@@ -127,7 +205,7 @@ unsigned tab_blocks(int kind, int N, int K) {
     case TAB_PACK_VEC: case TAB_UNPACK_VEC: return (unsigned)((N + TAB_ELEMS_PER_BLOCK - 1) / TAB_ELEMS_PER_BLOCK);
     case TAB_PACK_MAT: case TAB_UNPACK_MAT: return (unsigned)(((long)N * K + TAB_ELEMS_PER_BLOCK - 1) / TAB_ELEMS_PER_BLOCK);
     case TAB_PACK_CONV: case TAB_UNPACK_CONV: return (unsigned)(((long)N * K + 255) / 256);
-    default: return (unsigned)(((N + 31) / 32) * ((K + 31) / 32));       // transposed packs: 32 x 32 tiles
+    default: return (unsigned)(((N + 63) / 64) * ((K + 31) / 32));       // transposed packs: 64 x 32 tiles
   }
 }
 int table_launch(const TabOp* dev_ops, int nops, unsigned total_blocks, void* arena_vec, void* arena_mat, hipStream_t s) {

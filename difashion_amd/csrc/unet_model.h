@@ -172,6 +172,9 @@ struct dfh_unet {
   char* tws = nullptr; size_t tws_bytes = 0; int train_max_batch = 0;
   size_t tplan_total = 0; int tplan_batch = 0;
   struct TrainRun; TrainRun* tr = nullptr;
+  // backward walk: the weight-gradient GEMM of a layer runs on a second stream beside the data-gradient GEMM of the same layer
+  // (both only read dY): the tail round of one is filled with blocks of the other (unet_train.hip TrainRun::wgrad / join)
+  hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int build_train();
   size_t plan_train(int B);
   int forward_train(const void* sample, int sample_bf16, const float* timestep, const void* ehs, int ehs_bf16, float* out, int B,

@@ -32,6 +32,8 @@ struct dfh_unet::TrainRun {
   dfh_unet* u = nullptr; int B = 0; hipStream_t s = nullptr; bool dry = true;
   Bump persist, gtemp;
   size_t partial_need = 0; float* partial = nullptr; size_t partial_cap = 0;
+  float* partial2 = nullptr;                                   // slab region of the weight-gradient launches on the side stream
+  hipStream_t s2 = nullptr; bool forked = false;               // see wgrad() / join()
   float* gn_partial = nullptr; bf16_t* zero = nullptr;
   int rc = 0;
   std::vector<std::function<void()>> tape;
@@ -116,7 +118,26 @@ struct dfh_unet::TrainRun {
       if (cur_entry >= 0) writes.push_back({(size_t)cur_entry, w_off, w_off + (size_t)f.N * f.ldw});
       return;
     }
+    // A large weight-gradient GEMM goes to the side stream: it only READS dY and the saved forward operand, as does the data-gradient
+    // GEMM that follows on the main stream, so the two run side by side and each fills the other's tail round (576 tiles on 512
+    // resident slots leave 64 blocks alone on the chip).  join() orders the main stream behind it: before anything writes a buffer the
+    // launch reads, and at the end of every tape entry (gradient ranges are handed out / temporaries are reused per entry).
+    double kreal = (double)f.ntaps * f.conv_c + f.p_c[0] + (f.nplain > 1 ? f.p_c[1] : 0);
+    if (s2 && 2.0 * f.M * f.N * kreal >= 2e10) {
+      (void)hipEventRecord(u->ev_fork, s);                     // everything dY depends on
+      (void)hipStreamWaitEvent(s2, u->ev_fork, 0);
+      w.partial = partial2;
+      rc = dfh::wgrad_launch(w, s2);
+      forked = true;
+      return;
+    }
     rc = dfh::wgrad_launch(w, s);
+  }
+  void join() {
+    if (!forked || dry) return;
+    (void)hipEventRecord(u->ev_join, s2);
+    (void)hipStreamWaitEvent(s, u->ev_join, 0);
+    forked = false;
   }
   void colsum(const bf16_t* Y, int ldy, int N, int groups, int rows_per_group, float* out, int ld_out) {
     if (rc || dry) return;
@@ -394,6 +415,7 @@ struct dfh_unet::TrainRun {
       TR_OP(dfh::geglu_bwd_launch(ffpre.p, ff.g, ffpre.g, M, 8 * C, s));
       wgrad(f_ff1, ffpre.g, 8 * C, a.ff1.off, &a.ff1b);
       dgrad_linear(ffpre.g, M, 8 * C, w16t(a.ff1t), 8 * C, C, n3.g, false);
+      join();                                                                         // the ff.net.2 weight gradient reads gh
       layernorm_bwd(h2, n3.g, a.l3w, a.l3b, gh, 1, M, C);                             // gh = d h2
       // h2 = o2(at2) + h1
       wgrad(f_o2, gh, C, a.o2.off, &a.o2b);
@@ -402,6 +424,7 @@ struct dfh_unet::TrainRun {
                     dvx + a.x_off, XT, heads, N, T);
       wgrad(f_q2, q2.g, C, a.q2.off);
       dgrad_linear(q2.g, M, C, w16t(a.q2t), C, C, n2.g, false);
+      join();
       layernorm_bwd(h1, n2.g, a.l2w, a.l2b, gh, 1, M, C);                             // gh = d h1
       // h1 = o1(at) + h0
       wgrad(f_o1, gh, C, a.o1.off, &a.o1b);
@@ -411,6 +434,7 @@ struct dfh_unet::TrainRun {
       wgrad(f_qk, qk.g, 2 * C, a.qk.off);
       wgrad(f_v, v.g, C, a.v.off);
       dgrad_linear(qk.g, M, 2 * C, w16t(a.qkvt), 3 * C, C, n1.g, false, v.g, C);      // [dQ dK | dV] . [Wq; Wk; Wv]
+      join();
       layernorm_bwd(h0, n1.g, a.l1w, a.l1b, gh, 1, M, C);                             // gh = d h0
       // h0 = proj_in(gn)
       wgrad(f_pin, gh, C, a.pin.off, &a.pinb);
@@ -532,7 +556,12 @@ struct dfh_unet::TrainRun {
   }
 };
 
-dfh_unet::~dfh_unet() { delete tr; }
+dfh_unet::~dfh_unet() {
+  delete tr;
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
+  if (ev_join) (void)hipEventDestroy(ev_join);
+  if (side_stream) (void)hipStreamDestroy(side_stream);
+}
 
 // ------------------------------------------------------------------------------------------- build / plan
 int dfh_unet::build_train() {
@@ -596,7 +625,7 @@ int dfh_unet::build_train() {
 
 namespace {
 size_t head_bytes_for(int B, size_t partial) {
-  Bump hd; hd.alloc(256); hd.alloc((size_t)B * GN_MAX_CHUNKS * 64 * 2 * sizeof(float)); hd.alloc(partial);
+  Bump hd; hd.alloc(256); hd.alloc((size_t)B * GN_MAX_CHUNKS * 64 * 2 * sizeof(float)); hd.alloc(partial); hd.alloc(partial);
   return (hd.off + 255) & ~(size_t)255;
 }
 }
@@ -630,6 +659,7 @@ int dfh_unet::forward_train(const void* sample, int sample_bf16, const float* ti
   r.zero = (bf16_t*)hd.alloc(256);
   r.gn_partial = (float*)hd.alloc((size_t)B * GN_MAX_CHUNKS * 64 * 2 * sizeof(float));
   r.partial = (float*)hd.alloc(partial); r.partial_cap = partial;
+  r.partial2 = (float*)hd.alloc(partial);
   r.persist.base = tws + head;
   r.gtemp.base = tws + head + persist_bytes;
   (void)hipMemsetAsync(r.zero, 0, 256, s);
@@ -656,6 +686,13 @@ int dfh_unet::backward_begin(const float* d_out, float* d_sample, size_t bucket_
   DFH_REQUIRE(bucket_floats > 0, "bucket size must be positive");
   TrainRun& r = *tr;
   r.s = s; r.d_out = d_out; r.d_sample = d_sample;
+  static const bool side_off = [] { const char* e = getenv("DFH_TRAIN_SIDE"); return e && e[0] == '0'; }();     // A/B
+  if (!side_off && !side_stream) {
+    if (hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) { dfh::set_error("side stream / events"); return -2; }
+  }
+  r.s2 = side_off ? nullptr : side_stream; r.forked = false;
   std::fill(r.gstate.begin(), r.gstate.end(), 0);
   (void)hipMemsetAsync(grad32, 0, a32 * sizeof(float), s);
   (void)hipMemsetAsync(r.dtemb_all, 0, r.dtemb_bytes, s);
@@ -677,6 +714,7 @@ int dfh_unet::backward_next(size_t* lo, size_t* hi, hipStream_t s) {
   while (r.ready.empty() && r.next_entry >= 0 && !r.rc) {
     const int i = r.next_entry--;
     r.tape[i]();
+    r.join();                                   // side-stream weight gradients of this entry: done before its ranges are handed out
     // buckets whose last writer just ran; neighbours that finish together are handed out as one range
     for (size_t b = 0; b < r.bucket_last.size(); ++b) {
       if (r.bucket_last[b] != i) continue;

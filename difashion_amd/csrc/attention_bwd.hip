@@ -261,18 +261,35 @@ __global__ __launch_bounds__(256, ((D <= 40 && !KV_SIDE) ? 3 : 1)) void attentio
   }
 }
 
-// delta[b][h][q] = sum_d dO * O : one wave per (b, q) row, lanes over channels, per-head segments reduced by shuffles
+// delta[b][h][q] = sum_d dO * O.  A block takes DELTA_ROWS token rows: every thread multiplies 8 channels (one 16-byte load per tensor)
+// into a partial in LDS, then one thread per (row, head) adds the D / 8 partials of its head.
+constexpr int DELTA_ROWS = 32;
 __global__ __launch_bounds__(256) void attention_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, int ld,
                                                               float* __restrict__ delta, int B, int H, int D, int Nq) {
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= (long)B * Nq) return;
-  const int lane = threadIdx.x & 63;
-  const int b = (int)(row / Nq), q = (int)(row - (long)b * Nq);
-  for (int h = 0; h < H; ++h) {
+  extern __shared__ float part[];                         // [DELTA_ROWS][H * D / 8]
+  const long rows = (long)B * Nq, row0 = (long)blockIdx.x * DELTA_ROWS;
+  const int c8 = H * D / 8, d8 = D / 8;
+  const int nrow = (int)min((long)DELTA_ROWS, rows - row0);
+  for (int i = threadIdx.x; i < nrow * c8; i += 256) {
+    const int r = i / c8, c = i - r * c8;
+    const long at = (row0 + r) * ld + c * 8;
+    float a[8], g[8];
+    unpack8(*(const uint4*)(O + at), a);
+    unpack8(*(const uint4*)(dO + at), g);
     float s = 0.f;
-    for (int d = lane; d < D; d += 64) s += bf2f(O[row * ld + h * D + d]) * bf2f(dO[row * ld + h * D + d]);
-    s = wave_sum(s);
-    if (lane == 0) delta[((long)b * H + h) * Nq + q] = s;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += a[k] * g[k];
+    part[i] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nrow * H; i += 256) {
+    const int h = i / nrow, r = i - h * nrow;           // consecutive threads -> consecutive q of one head: coalesced stores
+    const float* p = part + r * c8 + h * d8;
+    float s = 0.f;
+    for (int k = 0; k < d8; ++k) s += p[k];
+    const long row = row0 + r;
+    const int b = (int)(row / Nq), q = (int)(row - (long)b * Nq);
+    delta[((long)b * H + h) * Nq + q] = s;
   }
 }
 
@@ -303,7 +320,9 @@ namespace dfh {
 
 int attention_delta_launch(const bf16_t* O, const bf16_t* dO, int ld, float* delta, int B, int H, int D, int Nq, hipStream_t stream) {
   const long rows = (long)B * Nq;
-  hipLaunchKernelGGL(attention_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, O, dO, ld, delta, B, H, D, Nq);
+  DFH_REQUIRE(D % 8 == 0 && ld % 8 == 0 && (size_t)DELTA_ROWS * H * D / 8 * 4 <= 64 * 1024, "attention delta: head dim / row stride must be multiples of 8");
+  hipLaunchKernelGGL(attention_delta_kernel, dim3((unsigned)((rows + DELTA_ROWS - 1) / DELTA_ROWS)), dim3(256), DELTA_ROWS * H * D / 8 * 4, stream,
+                     O, dO, ld, delta, B, H, D, Nq);
   return check_launch("attention_delta_kernel");
 }
 

@@ -283,7 +283,26 @@ __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restr
   __shared__ float red[4];
   __shared__ bool last;
   float s = 0.f;
-  for (long i = gtid(); i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
+  const long stride = (long)gridDim.x * blockDim.x;
+  if (((uintptr_t)g & 15) == 0) {                                // 16-byte loads, four running sums (fixed order for a fixed grid)
+    const long n4 = n >> 2;
+    float4 acc = float4{0.f, 0.f, 0.f, 0.f};
+    long i = gtid();
+    for (; i + 3 * stride < n4; i += 4 * stride) {               // four loads in flight per thread
+      const float4 a = ((const float4*)g)[i], b = ((const float4*)g)[i + stride], c = ((const float4*)g)[i + 2 * stride],
+                   d = ((const float4*)g)[i + 3 * stride];
+      acc.x += a.x * a.x + b.x * b.x + c.x * c.x + d.x * d.x; acc.y += a.y * a.y + b.y * b.y + c.y * c.y + d.y * d.y;
+      acc.z += a.z * a.z + b.z * b.z + c.z * c.z + d.z * d.z; acc.w += a.w * a.w + b.w * b.w + c.w * c.w + d.w * d.w;
+    }
+    for (; i < n4; i += stride) {
+      const float4 a = ((const float4*)g)[i];
+      acc.x += a.x * a.x; acc.y += a.y * a.y; acc.z += a.z * a.z; acc.w += a.w * a.w;
+    }
+    s = (acc.x + acc.y) + (acc.z + acc.w);
+    for (long j = (n4 << 2) + gtid(); j < n; j += stride) s += g[j] * g[j];
+  } else {
+    for (long i = gtid(); i < n; i += stride) s += g[i] * g[i];
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();

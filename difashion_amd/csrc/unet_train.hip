@@ -370,17 +370,18 @@ struct dfh_unet::TrainRun {
     // --- self attention
     GT n1 = act(H, W, C);
     layernorm(h0, a.l1w, a.l1b, n1.p, M, C);
-    GT qk = act(H, W, 2 * C);
-    GemmArgs f_qk = linear(n1.p, M, C, a.qk, nullptr, nullptr, qk.p, 2 * C);
-    GT v = act(H, W, C);
-    GemmArgs f_v = linear(n1.p, M, C, a.v, nullptr, nullptr, v.p, C);
+    // q | k | v in one [M][3C] buffer (the three matrices are packed back to back: build_attn): one projection, one weight-gradient
+    // launch over N = 3C, one data-gradient launch over K = 3C
+    if (a.v.off != a.qk.off + (size_t)2 * C * C || a.v.K != a.qk.K) { dfh::set_error("to_q | to_k | to_v are not packed back to back"); rc = -1; }
+    GT qkv = act(H, W, 3 * C);
+    GemmArgs f_qkv = linear(n1.p, M, C, a.qk, nullptr, nullptr, qkv.p, 3 * C);
     const int Np = (N + 7) & ~7;
     bf16_t* vt = buf((size_t)B * C * Np);
-    transpose(v.p, vt, N, C, C, Np, (long)N * C, (long)C * Np);
+    transpose(qkv.p + 2 * C, vt, N, C, 3 * C, Np, (long)N * 3 * C, (long)C * Np);
     GT at = act(H, W, C);
     float* lse1 = fbuf((size_t)B * heads * N);
     float* delta = fbuf((size_t)B * heads * N);
-    attention(qk.p, 2 * C, qk.p + C, 2 * C, vt, Np, at.p, C, heads, N, N, 0, lse1);
+    attention(qkv.p, 3 * C, qkv.p + C, 3 * C, vt, Np, at.p, C, heads, N, N, 0, lse1);
     GemmArgs f_o1 = linear(at.p, M, C, a.o1, &a.o1b, h0, h1, C);
     // --- cross attention over the T text tokens
     const int Tp = (T + 7) & ~7;
@@ -429,11 +430,10 @@ struct dfh_unet::TrainRun {
       // h1 = o1(at) + h0
       wgrad(f_o1, gh, C, a.o1.off, &a.o1b);
       dgrad_linear(gh, M, C, w16t(a.o1t), C, C, at.g, false);
-      attention_bwd(qk.p, 2 * C, qk.p + C, 2 * C, v.p, C, at.p, at.g, C, lse1, delta, qk.g, 2 * C, qk.g + C, 2 * C, v.g, C,
-                    heads, N, N);
-      wgrad(f_qk, qk.g, 2 * C, a.qk.off);
-      wgrad(f_v, v.g, C, a.v.off);
-      dgrad_linear(qk.g, M, 2 * C, w16t(a.qkvt), 3 * C, C, n1.g, false, v.g, C);      // [dQ dK | dV] . [Wq; Wk; Wv]
+      attention_bwd(qkv.p, 3 * C, qkv.p + C, 3 * C, qkv.p + 2 * C, 3 * C, at.p, at.g, C, lse1, delta, qkv.g, 3 * C, qkv.g + C, 3 * C,
+                    qkv.g + 2 * C, 3 * C, heads, N, N);
+      wgrad(f_qkv, qkv.g, 3 * C, a.qk.off);
+      dgrad_linear(qkv.g, M, 3 * C, w16t(a.qkvt), 3 * C, C, n1.g, false);             // [dQ dK dV] . [Wq; Wk; Wv]
       join();
       layernorm_bwd(h0, n1.g, a.l1w, a.l1b, gh, 1, M, C);                             // gh = d h0
       // h0 = proj_in(gn)

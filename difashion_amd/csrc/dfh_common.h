@@ -139,6 +139,18 @@ DFH_DEVICE uint2 geglu4(const f32x4_t v, const f32x4_t g, const float4 bv, const
   return o;
 }
 
+// geglu4 that also hands back the four (value, gate) PRE-activations as bf16 (training: the backward needs them, gemm.h GemmArgs::pre_out)
+DFH_DEVICE uint2 geglu4p(const f32x4_t v, const f32x4_t g, const float4 bv, const float4 bg, const GeluK& k, uint2& pre_v, uint2& pre_g) {
+  const f32x2_t v0 = f32x2_t{v[0] + bv.x, v[1] + bv.y}, v1 = f32x2_t{v[2] + bv.z, v[3] + bv.w};
+  const f32x2_t g0 = f32x2_t{g[0] + bg.x, g[1] + bg.y}, g1 = f32x2_t{g[2] + bg.z, g[3] + bg.w};
+  pre_v.x = pack2bf(v0[0], v0[1]); pre_v.y = pack2bf(v1[0], v1[1]);
+  pre_g.x = pack2bf(g0[0], g0[1]); pre_g.y = pack2bf(g1[0], g1[1]);
+  const f32x2_t o0 = v0 * gelu_erf_f2(g0, k), o1 = v1 * gelu_erf_f2(g1, k);
+  uint2 o;
+  o.x = pack2bf(o0[0], o0[1]); o.y = pack2bf(o1[0], o1[1]);
+  return o;
+}
+
 // Value of lane (l ^ 16) / (l ^ 32): gfx950's v_permlane{16,32}_swap exchange 16- / 32-lane rows between two registers in
 // the VALU (a few cycles); __shfl_xor goes through ds_bpermute_b32, an LDS round trip of ~100+ cycles on the critical path
 // of every softmax tile.  swap(x, x) leaves {x of the even row, x of the odd row} of each row pair in both rows.

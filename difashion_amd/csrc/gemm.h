@@ -43,6 +43,9 @@ struct GemmArgs {
   // rows_per_b rows) while columns [0, n_split) follow out / out_mode -- attention's q | k and V^T from ONE launch over the shared
   // LayerNorm-ed (or folded-LayerNorm) rows.  n_split must be a multiple of the column tile; single-pass gemm_bf16_kernel launches only.
   void* out2; int ld_out2; int n_split;
+  // GEGLU launches of the TRAINING walk: the bias-added pre-activations [M][N] (packed value / gate layout, bf16) as a second output of
+  // the epilogue that gates them -- the backward needs them, and a separate gating pass would read them back (gemm_wide.hip, 256 x 128 tile)
+  void* pre_out; int ld_pre;
   // BATCHED launch (grid.y): batch z reads plain segment 0 at p_src[0] + z * a_bs, the weights at W + z * w_bs and writes out + z * o_bs
   // (elements).  The sixteen transform-domain GEMMs of a Winograd F(2x2, 3x3) convolution (winograd.hip) in ONE launch: 16 x the tiles of
   // one, so the deep levels fill the chip without split-K.  Single plain segment, bf16 row-major output, gemm_bf16_kernel tiles only.

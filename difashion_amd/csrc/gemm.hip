@@ -1017,7 +1017,8 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     double abytes = a.ntaps ? (double)(a.M / (a.Hout * a.Wout)) * a.Hin * a.Win * a.conv_c * 2.0 : 0.0;
     for (int i = 0; i < a.nplain; ++i) { kreal += a.p_c[i]; abytes += (double)a.M * a.p_c[i] * 2.0; }
     const double obytes = (double)a.M * (a.act == ACT_GEGLU ? a.N / 2 : a.N) * ((a.out_mode == OUT_F32 || a.out_mode == OUT_F32_T) ? 4.0 : 2.0) +
-                          (a.resid ? (double)a.M * a.N * 2.0 : 0.0);      // the residual is an operand too: read once
+                          (a.resid ? (double)a.M * a.N * 2.0 : 0.0) +     // the residual is an operand too: read once
+                          (a.pre_out ? (double)a.M * a.N * 2.0 : 0.0);
     const double planes = a.nbatch > 1 ? (double)a.nbatch : 1.0;       // a phase launch reads its source image once for all four planes
     // algorithmic multiply-adds = the reference algorithm's: the four phase planes of an upsample conv stand for the
     // 3x3 conv over the upsampled image (9 taps per output pixel, of which the planes execute 4)
@@ -1036,11 +1037,14 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     // tile id 23: the 256 x 256 GEGLU tile
     const bool force_bigg = force_wide == 18;
     if (force_bigg) force_wide = 0;
-    const bool bigg = wide_ok && !force_deep && a.act == ACT_GEGLU && a.N % 32 == 0 && !a.resid && !a.rowvec &&
+    const bool pre = a.pre_out != nullptr;      // training GEGLU with its pre-activations as a second output: the 256 x 128 wide tile only
+    if (pre) DFH_REQUIRE(wide_ok && a.act == ACT_GEGLU && a.N % 128 == 0 && !a.ln_stat && !a.resid && !a.rowvec && (a.ld_pre & 7) == 0 && a.ld_pre >= a.N,
+                         "pre_out: GEGLU launches with N % 128 == 0, no split-K, no folded LayerNorm");
+    const bool bigg = !pre && wide_ok && !force_deep && a.act == ACT_GEGLU && a.N % 32 == 0 && !a.resid && !a.rowvec &&
                       (force_bigg || (!force_wide && force_tile == 0 && force_split == 0 && gemm_big_geglu_pick(a)));
     const bool big_ok = wide_ok0 && !force_deep && a.act != ACT_GEGLU && !a.ln_stat && (a.nbatch <= 1 || force_big);
     const bool big = big_ok && (force_big || (!force_wide && force_tile == 0 && force_split == 0 && gemm_big_pick(a)));
-    int wide = (!wide_ok || force_deep || big || force_big || bigg || force_bigg) ? 0 : (force_wide ? force_wide : ((force_tile == 0 && force_split == 0) ? gemm_wide_pick(a) : 0));
+    int wide = pre ? 5 : (!wide_ok || force_deep || big || force_big || bigg || force_bigg) ? 0 : (force_wide ? force_wide : ((force_tile == 0 && force_split == 0) ? gemm_wide_pick(a) : 0));
     int ws = 0; bool halo = false;
 #ifdef DFH_PROBES
     // Probe builds only (scripts/probes/Makefile): tile ids 11 / 12 = the wave-specialised kernel (scripts/probes/kernels/gemm_ws.hip, opt-in
@@ -1060,7 +1064,7 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     if (bigg) gemm_pick_tile_order(a, split, 256, 256);
     else if (big) gemm_pick_tile_order(a, split, 256, 320);
     else if (ws) gemm_pick_tile_order(a, split, 256, ws);
-    else if (wide) gemm_pick_tile_order(a, split, wide == 2 ? 128 : 256, wide == 3 ? 320 : (wide == 4 ? 128 : 160));
+    else if (wide) gemm_pick_tile_order(a, split, wide == 2 ? 128 : 256, wide == 3 ? 320 : ((wide == 4 || wide == 5) ? 128 : 160));
     else gemm_pick_tile_order(a, split, kTiles[tile].bm, kTiles[tile].bn);
     if (force_wide == 6 || force_wide == 7) wide = 0;                      // not eligible (odd N, transposed / fp32 output): the default tile runs
     if (force_wide == 15) wide = halo ? 1 : 0;
@@ -1073,7 +1077,7 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     // per-row output statistics for a LayerNorm folded into the consumer: the staged bf16 epilogue of gemm_bf16_kernel and the 256-row
     // epilogue write them, on whole column tiles
     {
-      const int bn = big ? 320 : (wide == 1 ? 160 : (wide == 4 ? 128 : (wide || ws ? 0 : kTiles[tile].bn)));
+      const int bn = big ? 320 : (wide == 1 ? 160 : ((wide == 4 || wide == 5) ? 128 : (wide || ws ? 0 : kTiles[tile].bn)));
       const bool staged_ok = split == 1 && a.out_mode == OUT_BF16 && a.act != ACT_GEGLU && (a.N & 7) == 0 && (a.ld_out & 7) == 0;
       if (!(a.rowstat && bn > 0 && staged_ok && a.N % bn == 0 && !halo)) a.rowstat = nullptr;
       else if (rowstat_bn) *rowstat_bn = bn;

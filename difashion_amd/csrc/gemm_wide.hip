@@ -318,7 +318,18 @@ __global__ __launch_bounds__(WN * 128, WN == 2 ? 2 : 1) void gemm_wide_kernel(co
         for (int jj = 0; jj < FN / 2; ++jj) {
           // value / gate with their additive constants (bias, or the folded-LayerNorm fix-up: two FMAs per element), GELU and product on
           // packed fp32 pairs: this epilogue is VALU-bound, every instruction shows in the launch time (dfh_common.h geglu4)
-          const uint2 o = geglu4(acc[i][2 * jj], acc[i][2 * jj + 1], bv[jj], bg[jj], sv[jj], sg[jj], lnf, mr.y, ms, gk);
+          uint2 o;
+          if constexpr ((ABL & 8) != 0) {                // training: the pre-activations leave as a second output (GemmArgs::pre_out)
+            uint2 pv, pg;
+            o = geglu4p(acc[i][2 * jj], acc[i][2 * jj + 1], bv[jj], bg[jj], gk, pv, pg);
+            const int m = m0 + row, n = n0 + wn * TN + jj * 32 + fg * 4;
+            if (m < a.M && n + 16 < a.N) {
+              bf16_t* pr = (bf16_t*)a.pre_out + (long)m * a.ld_pre + n;
+              *(uint2*)pr = pv; *(uint2*)(pr + 16) = pg;
+            }
+          } else {
+            o = geglu4(acc[i][2 * jj], acc[i][2 * jj + 1], bv[jj], bg[jj], sv[jj], sg[jj], lnf, mr.y, ms, gk);
+          }
           const int ocl = ((wn * TN) >> 1) + jj * 16 + fg * 4;           // output column inside the tile
           *(uint2*)(smem + row * RSG + ocl * 2) = o;
         }
@@ -402,6 +413,7 @@ static int wide_launch_t(GemmArgs a, hipStream_t s) {
 
 int gemm_wide_launch(GemmArgs a, hipStream_t s, int variant) {
   if (variant == 4) return wide_launch_t<256, 128, 2, 3>(a, s);
+  if (variant == 5) return wide_launch_t<256, 128, 2, 3, 8>(a, s);      // GEGLU with the pre-activations as a second output (training)
 #ifdef DFH_PROBES   // experiment tiles (eight-wave 256 x 320, 128-row sibling) and the k-loop ablations: probe builds only
   if (variant == 3) return wide_launch_t<256, 320, 4, 4>(a, s);
   if (variant == 2) return wide_launch_t<128, 160, 2, 3>(a, s);

@@ -397,9 +397,21 @@ struct dfh_unet::TrainRun {
     GT n3 = act(H, W, C);
     layernorm(h2, a.l3w, a.l3b, n3.p, M, C);
     GT ffpre = act(H, W, 8 * C);
-    GemmArgs f_ff1 = linear(n3.p, M, C, a.ff1, &a.ff1b, nullptr, ffpre.p, 8 * C);
     GT ff = act(H, W, 4 * C);
-    TR_OP(dfh::geglu_fwd_launch(ffpre.p, ff.p, M, 8 * C, s));
+    // ff.net.0: the GEMM epilogue gates (value x exact-erf GELU(gate)) into ff AND writes the bias-added pre-activations the backward
+    // needs as a second output -- a separate gating pass read the 8C-wide tensor back (DFH_TRAIN_GEGLU_FUSED=0: the two-launch form, A/B)
+    static const bool geglu_split = [] { const char* e = getenv("DFH_TRAIN_GEGLU_FUSED"); return e && e[0] == '0'; }();
+    GemmArgs f_ff1;
+    if (!geglu_split && (8 * C) % 128 == 0) {
+      f_ff1 = base(M, 8 * C);
+      f_ff1.p_src[0] = n3.p; f_ff1.p_c[0] = C; f_ff1.nplain = 1;
+      f_ff1.W = w16(a.ff1); f_ff1.ldw = a.ff1.K; f_ff1.bias = v32(a.ff1b);
+      f_ff1.act = ACT_GEGLU; f_ff1.out = ff.p; f_ff1.ld_out = 4 * C; f_ff1.pre_out = ffpre.p; f_ff1.ld_pre = 8 * C;
+      gemm(f_ff1);
+    } else {
+      f_ff1 = linear(n3.p, M, C, a.ff1, &a.ff1b, nullptr, ffpre.p, 8 * C);
+      TR_OP(dfh::geglu_fwd_launch(ffpre.p, ff.p, M, 8 * C, s));
+    }
     GemmArgs f_ff2 = linear(ff.p, M, 4 * C, a.ff2, &a.ff2b, h2, h3, C);
     GemmArgs f_pout = linear(h3, M, C, a.pout, &a.poutb, x.p, out.p, C);
     gtemp.off = mark;

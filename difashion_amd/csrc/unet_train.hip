@@ -123,7 +123,9 @@ struct dfh_unet::TrainRun {
     // resident slots leave 64 blocks alone on the chip).  join() orders the main stream behind it: before anything writes a buffer the
     // launch reads, and at the end of every tape entry (gradient ranges are handed out / temporaries are reused per entry).
     double kreal = (double)f.ntaps * f.conv_c + f.p_c[0] + (f.nplain > 1 ? f.p_c[1] : 0);
-    if (s2 && 2.0 * f.M * f.N * kreal >= 2e10) {
+    // DFH_TRAIN_SIDE_MIN_FLOP: smaller launches stay on the main stream (two event operations cost more than their tail); tests set it to 0
+    static const double side_min = [] { const char* e = getenv("DFH_TRAIN_SIDE_MIN_FLOP"); return e ? atof(e) : 2e10; }();
+    if (s2 && 2.0 * f.M * f.N * kreal >= side_min) {
       (void)hipEventRecord(u->ev_fork, s);                     // everything dY depends on
       (void)hipStreamWaitEvent(s2, u->ev_fork, 0);
       w.partial = partial2;

@@ -436,6 +436,35 @@ def test_sd15_full_size_batch32_gradients_are_the_mean_of_its_two_halves():
     assert worst[1] <= 6e-2 and tot <= ALL_TOL, (worst, tot)
 
 
+def test_side_stream_weight_gradients_are_bit_identical_to_the_one_stream_walk(tmp_path):
+    """The backward walk runs large weight-gradient GEMMs on a second stream beside the data-gradient GEMM of the same layer
+    (unet_train.hip TrainRun::wgrad / join).  Same kernels, same slices, same summation order: with the side stream forced on for EVERY
+    weight-gradient launch (DFH_TRAIN_SIDE_MIN_FLOP=0) every matrix gradient must be bit-identical to the one-stream walk
+    (DFH_TRAIN_SIDE=0), run after run -- a missing join (a buffer overwritten while the side stream still reads it) shows up here as a
+    difference.  Vector gradients (biases, norm scales) are accumulated with float atomics in either mode: compared to 1e-5."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for name, env in (("one", {"DFH_TRAIN_SIDE": "0"}), ("side", {"DFH_TRAIN_SIDE_MIN_FLOP": "0"})):
+        out = tmp_path / f"{name}.pt"
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "train_side_worker.py"), str(out)], env={**os.environ, **env},
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        got[name] = torch.load(out)
+    mats = 0
+    for rep in (0, 1):
+        for k, ref in got["one"][0].items():
+            for other in (got["one"][rep][k], got["side"][rep][k]):
+                if ref.ndim >= 2:
+                    assert torch.equal(other, ref), (k, rep, float((other - ref).abs().max()))
+                    mats += 1
+                else:
+                    torch.testing.assert_close(other, ref, rtol=1e-5, atol=1e-6 * float(ref.abs().max() + 1e-30), msg=k)
+    assert mats > 100
+
+
 def test_segmented_backward_equals_the_monolithic_one():
     """dfh_unet_backward_begin / _next / _finish (the pieces behind the overlapped gradient all-reduce): the ranges handed
     out are disjoint, cover every written float of the packed gradient arena exactly once, and the master gradients equal

@@ -422,3 +422,45 @@ def test_bench_gpus_n_launches_its_own_ranks_and_fails_with_them():
     assert r.returncode == 1
     assert "ranks failed" in r.stderr and "needs an MI355X" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_wgrad_slice_plan_picks_within_a_few_percent_of_the_measured_best():
+    """The m-slice count of the weight-gradient GEMM comes from a cost model (wgrad.hip wgrad_plan) fitted to a sweep on the MI355X over
+    the layer shapes of the training step (profiles/r04/wgrad_msplit_sweep.txt: microseconds per shape and slice count).  The plan is host
+    code: dfh_gemm_wgrad_partial_floats(desc, 0) = slices x N x K floats (0 when it does not split).  For every swept shape the slice
+    count it picks must be one the sweep measured within 8 % of that shape's best time, must keep >= 512 pixel rows per slice, and
+    must be 1 or a multiple of 8 (one slice set per XCD)."""
+    import ctypes as C
+    import re
+    from difashion_amd import _lib
+    lib = _lib.raw()
+    table, ms = {}, None
+    for line in open(os.path.join(ROOT, "profiles", "r04", "wgrad_msplit_sweep.txt")):
+        if line.startswith("=="):
+            ms = int(line.split()[-1])
+            continue
+        m = re.match(r"(.{24}) M=\s*(\d+) N=\s*(\d+) K=\s*(\d+)\s+([\d.]+) us", line)
+        if m:
+            table.setdefault((m.group(1).strip(), int(m.group(2)), int(m.group(3)), int(m.group(4))), {})[ms] = float(m.group(5))
+    assert len(table) >= 12
+    dummy = (C.c_char * 256)()
+    ptr = C.addressof(dummy)
+    checked = 0
+    for (name, M, N, K), times in table.items():
+        d = _lib.GemmDesc()
+        if name.startswith("conv"):
+            hw = int(name.split("@")[1])
+            d.conv_src, d.conv_c, d.conv = ptr, K // 9, 1
+            d.batch, d.Hin, d.Win, d.stride, d.upsample = M // (hw * hw), hw, hw, 1, 0
+        else:
+            d.a0, d.a0_c = ptr, K
+        d.M, d.N, d.zero_page = M, N, ptr
+        floats = lib.dfh_gemm_wgrad_partial_floats(C.byref(d), 0)
+        assert floats % (N * K) == 0, (name, floats)
+        slices = max(1, floats // (N * K))
+        assert slices == 1 or (slices % 8 == 0 and slices <= 64 and M // slices >= 512), (name, slices)
+        best = min(times.values())
+        if slices in times:                       # 48 was not swept
+            assert times[slices] <= 1.08 * best, (name, slices, times[slices], best)
+            checked += 1
+    assert checked >= 12

@@ -26,7 +26,8 @@ DFH_DEVICE const uint4* gn_src(const GnArgs& a, int b, int p, int o) {
 }
 
 // grid (chunks, B); block = roundup64(C8 * PL) threads; thread -> (pixel lane pl, octet o)
-__global__ void gn_stats_kernel(const GnArgs a) {
+// (<= 512 threads: C <= 4096; without the bound the compiler budgets for 1024 threads, 128 VGPRs, and spills 28 of them inside the load loop)
+__global__ __launch_bounds__(512) void gn_stats_kernel(const GnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [PL][C][2]
   const int C8 = a.C >> 3;
   const int tid = threadIdx.x;
@@ -469,7 +470,7 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
     DFH_REQUIRE(a.C1 == 0 && a.pre_chunks > 0 && a.pre_chunks <= (int)GN_MAX_CHUNKS, "producer statistics: one source, 1..64 chunks");
     int block, achunks;
     gn_geometry(a, &block, &achunks);
-    DFH_REQUIRE(block <= 1024, "block too large");
+    DFH_REQUIRE(block <= 512, "block too large (more than 4096 channels)");
     a.partial = const_cast<float*>(a.pre); a.chunks = a.pre_chunks;
     ProfScope ps(PC_GNORM, 0.0, (a.out8 ? 3.0 : 4.0) * a.B * (double)a.HW * a.C, stream);
     census(CK_GN_PRE);
@@ -522,7 +523,7 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
   }
   int block, achunks;
   gn_geometry(a, &block, &achunks);
-  DFH_REQUIRE(block <= 1024, "block too large");
+  DFH_REQUIRE(block <= 512, "block too large (more than 4096 channels)");
   const size_t lds = (size_t)a.PL * a.C * 2 * sizeof(float);
   DFH_REQUIRE(lds <= 64 * 1024, "GroupNorm LDS reduction too large");
   ProfScope ps(PC_GNORM, 0.0, (a.out8 ? 3.0 : 4.0) * a.B * (double)a.HW * a.C, stream);   // algorithmic: one read + one write (bf16)

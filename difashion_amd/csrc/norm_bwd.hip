@@ -26,7 +26,8 @@ DFH_DEVICE float dsilu(float z) {
 }
 
 // grid (chunks, B): per-channel sums A_c = sum dz, B_c = sum dz*x^ over this chunk's pixels
-__global__ void gn_bwd_stats_kernel(const GnBwdArgs a) {
+// (blocks of <= 512 threads, see groupnorm_bwd_launch: without the bound the compiler budgets 128 VGPRs for 1024 threads and spills in the loops)
+__global__ __launch_bounds__(512) void gn_bwd_stats_kernel(const GnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [PL][C][2]
   const int C8 = a.C >> 3, cpg = a.C / a.G;
   const int tid = threadIdx.x;
@@ -88,7 +89,7 @@ __global__ void gn_bwd_stats_kernel(const GnBwdArgs a) {
 }
 
 // grid (achunks, B): dx
-__global__ void gn_bwd_apply_kernel(const GnBwdArgs a) {
+__global__ __launch_bounds__(512) void gn_bwd_apply_kernel(const GnBwdArgs a) {
   __shared__ float s1_s[64], s2_s[64];
   const int C8 = a.C >> 3, cpg = a.C / a.G;
   const int tid = threadIdx.x;
@@ -292,7 +293,7 @@ int groupnorm_bwd_launch(GnBwdArgs a, hipStream_t stream) {
   if (PL > a.HW) PL = a.HW;
   a.PL = PL;
   const int block = ((C8 * PL + 63) / 64) * 64;
-  DFH_REQUIRE(block <= 1024, "block too large");
+  DFH_REQUIRE(block <= 512, "block too large (more than 4096 channels)");
   const int max_by_pix = (a.HW + PL - 1) / PL;
   int chunks = std::max(1, std::min({(512 + a.B - 1) / a.B, max_by_pix, (int)GN_MAX_CHUNKS}));
   a.pix_per_chunk = (a.HW + chunks - 1) / chunks;

@@ -36,6 +36,16 @@ def init(backend: str | None = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def active(group=None) -> bool:
+    """Do the gradient collectives run?  A process group with more than one rank -- or, with ``DFH_DIST_SINGLE_RANK=1``, any initialised
+    group: a world of ONE rank then still goes through every RCCL call of the data-parallel step (all_reduce, all_to_all_single,
+    all_gather_into_tensor, broadcast on the side stream, with the event ordering around them), which is how the ``nccl`` branch is
+    exercised on a one-GPU box (tests/test_gpu_ddp.py::test_rccl_branch_runs_in_a_world_of_one)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("DFH_DIST_SINGLE_RANK") == "1"
+
+
 def shard_range(n_items: int, rank: int, world: int) -> range:
     """Contiguous shard of ``n_items`` outfits for ``rank``: sizes differ by at most one, earlier ranks
     take the remainder (every outfit assigned exactly once, order preserved)."""
@@ -75,7 +85,7 @@ def gather_mean(value: torch.Tensor) -> torch.Tensor:
     """Mean over the ranks of a per-rank tensor (the logged loss: ``accelerator.gather(loss.repeat(b)).mean()``,
     train.py:695, with equal per-rank batches).  Returns a new tensor; nothing on the optimisation path depends on it."""
     out = value.detach().clone().float()
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         if dist.get_backend() != "nccl":
             out = out.cpu()
         dist.all_reduce(out, op=dist.ReduceOp.SUM)
@@ -139,7 +149,7 @@ def exchange_bf16(t: torch.Tensor, capacity: int = 0) -> torch.Tensor:
     The buffers are persistent (Bf16Exchange; ``capacity`` = the largest range the caller will pass, in floats): no device allocation
     per call.  gloo has no all_to_all: there step 1 is an all_gather of the whole bf16 range staged through the host (test path only,
     same arithmetic, same device buffers)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return t
     world, rank = dist.get_world_size(), dist.get_rank()
     n = t.numel()
@@ -197,7 +207,7 @@ def all_reduce_gradients(flat_grad: torch.Tensor, average: bool = True, wire: st
     batch of outfits; the gradients of ALL parameters live in one flat fp32 buffer (training.FusedAdamW.flat_grad /
     UNet2DConditionModel.grad_views), so the exchange is ONE RCCL all-reduce sized for xGMI instead of DDP's
     25 MB buckets: a ring over 8 GPUs moves 2 * 7/8 of the buffer per link once, with no per-bucket launch latency."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active():
         return flat_grad
     if wire == "bf16":
         if not average:
@@ -212,7 +222,7 @@ def all_reduce_gradients(flat_grad: torch.Tensor, average: bool = True, wire: st
 def broadcast_parameters(flat_param: torch.Tensor, src: int = 0) -> torch.Tensor:
     """Make every replica start from rank ``src``'s weights (what DDP does when it wraps a module, train.py:611): ONE
     broadcast of the flat fp32 parameter buffer (training.FusedAdamW.flat_param -- the parameters are views of it)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         dist.broadcast(flat_param, src=src)
     return flat_param
 

@@ -100,7 +100,8 @@ class FusedAdamW(torch.optim.Optimizer):
         if self.ddp_group is None or not (tdist.is_available() and tdist.is_initialized()):
             return
         group = None if isinstance(self.ddp_group, str) else self.ddp_group
-        if tdist.get_world_size(group) <= 1:
+        from .dist import active as _dist_active
+        if not _dist_active(group):
             return
         plist = [p for g in self.param_groups for p in g["params"]]
         local = [1 if self._fresh(p) else 0 for p in plist]

@@ -460,7 +460,8 @@ class UNet2DConditionModel(nn.Module):
         self.grads_synced = False
         _lib.stamp_grads(plist)           # FusedAdamW.step() updates only parameters whose gradient was written this epoch
         import torch.distributed as tdist
-        if self.sync_grads_in_backward and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+        from .dist import active as _dist_active
+        if self.sync_grads_in_backward and _dist_active():
             self._backward_overlapped(d_out, d_sample, arr, len(plist), overwrite, tdist)
             self.grads_synced = True      # training.train_step then all-reduces only what lies outside this module
         else:

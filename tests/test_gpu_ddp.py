@@ -67,3 +67,15 @@ def test_bench_launches_its_own_ranks():
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0
     assert rec["collective_backend"] == ("nccl" if TWO_GPUS else "gloo")
     assert rec["rccl_ranks"] == (2 if TWO_GPUS else None)
+
+
+def test_rccl_branch_runs_in_a_world_of_one():
+    """The "nccl" (RCCL) branch of the data-parallel step on the box's one GPU: a process group of ONE rank with
+    DFH_DIST_SINGLE_RANK=1 (difashion_amd.dist.active) sends every collective of the step through RCCL on its side stream --
+    tests/rccl_single_rank_worker.py lists what must hold (averaging over one rank is the identity)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               DFH_DIST_SINGLE_RANK="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_single_rank_worker.py")], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    print(out.stdout[-3000:], out.stderr[-3000:])
+    assert out.returncode == 0 and "RCCL single-rank run OK" in out.stdout

@@ -131,6 +131,11 @@ def train_inputs(dev, cross_dim, rank, outfits):
                 dropout_mask=((torch.rand(n, 256, generator=g) >= 0.1).float() / 0.9).to(dev))
 
 
+def backend_name():
+    import torch.distributed as tdist
+    return tdist.get_backend() if tdist.is_initialized() else None
+
+
 def run_train(args, da, _lib, ddist, rank, world, dev):
     """BASELINE configs[2]/[3]: one optimisation step = loss forward + native backward + RCCL gradient all-reduce + clip/AdamW
     + EMA over a per-GPU batch of 8 outfits x 4 items (weak scaling: global batch = 32 x N items)."""
@@ -143,9 +148,9 @@ def run_train(args, da, _lib, ddist, rank, world, dev):
     kw = train_inputs(dev, unet.config.cross_attention_dim, rank, args.outfits)
     K, W = args.steps, args.warmup
     if args.wire is None:
-        args.wire = "bf16" if world > 1 else "fp32"
+        args.wire = "bf16" if ddist.active() else "fp32"
     unet.grad_wire_dtype = args.wire
-    unet.measure_comm = world > 1          # two event records per step on the compute stream around its wait for the side stream
+    unet.measure_comm = ddist.active()     # two event records per step on the compute stream around its wait for the side stream
     step = lambda: da.train_step(unet, enc, sched, opt, ema_unet=ema, **kw)
     for _ in range(W):
         loss = step()
@@ -154,7 +159,7 @@ def run_train(args, da, _lib, ddist, rank, world, dev):
     exposed = []
     for _ in range(K):
         loss = step()
-        if world > 1:
+        if ddist.active():
             exposed.append(unet._comm_events)          # read after the timed region (no host sync inside it)
     torch.cuda.synchronize(); ddist.barrier(); torch.cuda.synchronize()
     elapsed = ddist.max_over_ranks(time.perf_counter() - t0)
@@ -192,6 +197,9 @@ def run_train(args, da, _lib, ddist, rank, world, dev):
            # walk did not hide (max over ranks; null on one GPU: no exchange)
            "comm_exposed_ms": None if comm_exposed_ms is None else round(comm_exposed_ms, 3), "grad_wire": args.wire,
            "rccl_ranks": args.ranks_seen if args.backend in (None, "nccl") else None, "collective_backend": args.backend}
+    if world == 1 and ddist.active():      # DFH_DIST_SINGLE_RANK=1: the gradient exchange ran over RCCL in a world of one rank
+        out["single_rank_collectives"] = True
+        out["collective_backend"] = backend_name()
     if classes is not None:
         tot_f = sum(v["flops"] for v in classes.values())
         out["kernel_classes"] = {c: dict(launches_per_step=v["launches"] // K, ms_per_step=round(v["ms"] / K, 3),
@@ -429,7 +437,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     local_dev = int(os.environ.get("LOCAL_RANK", 0)) % max(1, torch.cuda.device_count()) if backend != "nccl" else None
-    rank, world, local = ddist.init(backend if args.gpus > 1 else None)
+    # DFH_DIST_SINGLE_RANK=1: a world of ONE rank that still runs the gradient exchange over RCCL (what the data-parallel machinery
+    # costs on one GPU when the wire is free: --mode train prints comm_exposed_ms for it)
+    single_rank = os.environ.get("DFH_DIST_SINGLE_RANK") == "1"
+    rank, world, local = ddist.init(backend if (args.gpus > 1 or single_rank) else None)
     if world != args.gpus:
         log(f"[bench] WARNING: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if local_dev is not None:

@@ -25,7 +25,8 @@ def init(backend: str | None = None) -> Tuple[int, int, int]:
     """Initialise the default process group when WORLD_SIZE > 1.  backend: "nccl" (= RCCL on ROCm) on
     GPUs, "gloo" for the CPU tests."""
     rank, world, local = env_world()
-    if world > 1 and not dist.is_initialized():
+    single = os.environ.get("DFH_DIST_SINGLE_RANK") == "1"      # a world of one rank that still runs its collectives (see active())
+    if (world > 1 or single) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -444,6 +444,10 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
 // queries: 44 us for 84 MB at the 64x64 level); here the chain is paid once per workgroup and the per-block work of the four
 // waves of a workgroup (and of the two workgroups of a CU) overlaps freely.  The softmax is the exact deferred-max form of the
 // streaming kernel's SAFE pass on both tiles (two tiles: nothing to win from the fast pass), same fragment layouts, same numerics.
+#ifndef XS_PREFETCH_Q
+#define XS_PREFETCH_Q(QB) ((QB) == 1)
+#define XS_STAGE_O(QB) true
+#endif
 template <int D, int QB>
 __global__ __launch_bounds__(256, 2) void attention_xs_kernel(const AttnArgs a, const int qrep) {
   using G = X32Geom<D>;
@@ -517,9 +521,27 @@ __global__ __launch_bounds__(256, 2) void attention_xs_kernel(const AttnArgs a, 
   }
   const float c = a.scale * 1.44269504088896340736f;
 
+  // the Q rows of the NEXT block are requested before the current block is computed: load -> scores -> softmax -> P.V -> store was one
+  // dependent chain per block and wave, with nothing in flight while it computed
+  constexpr bool PREFETCH_Q = XS_PREFETCH_Q(QB), STAGE_O = XS_STAGE_O(QB);
+  uint4 qraw[QB][KS];
+  auto fetch_q = [&](int q0) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const int q = q0 + qb * 32 + ql;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int ch = 2 * ks + hi;
+        qraw[qb][ks] = uint4{0u, 0u, 0u, 0u};
+        if (ch < DCH && q < a.Nq) qraw[qb][ks] = *(const uint4*)(Qb + (long)q * a.ldq + ch * 8);
+      }
+    }
+  };
+  if (PREFETCH_Q) fetch_q(qblk * per_wg + wave * WQ);
   for (int rep = 0; rep < qrep; ++rep) {
     const int q0 = qblk * per_wg + rep * 4 * WQ + wave * WQ;
     if (q0 >= a.Nq) break;                                    // wave-uniform
+    if (!PREFETCH_Q) fetch_q(q0);
     uint4 qf[QB][KS];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -529,9 +551,8 @@ __global__ __launch_bounds__(256, 2) void attention_xs_kernel(const AttnArgs a, 
         uint4 v = uint4{0u, 0u, 0u, 0u};
         const int ch = 2 * ks + hi;
         if (ch < DCH && q < a.Nq) {
-          const uint4 raw = *(const uint4*)(Qb + (long)q * a.ldq + ch * 8);
           float f[8];
-          unpack8(raw, f);
+          unpack8(qraw[qb][ks], f);
 #pragma unroll
           for (int e = 0; e < 8; ++e) f[e] *= c;
           v = pack8(f);
@@ -541,6 +562,7 @@ __global__ __launch_bounds__(256, 2) void attention_xs_kernel(const AttnArgs a, 
         qf[qb][ks] = v;
       }
     }
+    if (PREFETCH_Q && rep + 1 < qrep) fetch_q(q0 + 4 * WQ);
     f32x16_t o[DB][QB];
     float m_run[QB];
 #pragma unroll
@@ -648,7 +670,41 @@ __global__ __launch_bounds__(256, 2) void attention_xs_kernel(const AttnArgs a, 
           }
       }
     }
-    // ---- normalise and store (layout as in the streaming kernel)
+    // ---- normalise and store.  bf16 output: the wave's WQ x D block is turned through a wave-private LDS region so that a row leaves as
+    // D / 8 consecutive 16-byte stores (one 2 * D-byte run per row) -- straight from the accumulator layout a row left in 16-byte pieces
+    // from five different instructions, and this launch is nothing but Q in / O out (84 MB at the 64x64 level)
+    if (STAGE_O && !a.O8) {
+      unsigned char* st = smem + 2 * G::BUF + 16 + wave * (WQ * D * 2);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        const float lv = o[D / 32][qb][G::L_REG];
+        const float lo = lane_xor32(lv);
+        const float l = hi == G::L_HI ? lv : lo;
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int d0 = db * 32 + g * 8 + hi * 4;
+            if (d0 < D) {
+              uint2 w;
+              w.x = pack2bf(o[db][qb][4 * g] * inv, o[db][qb][4 * g + 1] * inv);
+              w.y = pack2bf(o[db][qb][4 * g + 2] * inv, o[db][qb][4 * g + 3] * inv);
+              *(uint2*)(st + (qb * 32 + ql) * (D * 2) + d0 * 2) = w;
+            }
+          }
+      }
+      constexpr int CH = D / 8;                                // 16-byte chunks per row
+#pragma unroll
+      for (int i0 = 0; i0 < WQ * CH; i0 += 64) {
+        const int i = i0 + lane;
+        const int row = i / CH, ch = i - row * CH;
+        const int q = q0 + row;
+        if (i < WQ * CH && q < a.Nq)
+          *(uint4*)(a.O + ((long)b * a.Nq + q) * a.ldo + h * D + ch * 8) = *(const uint4*)(st + row * (D * 2) + ch * 16);
+      }
+      continue;
+    }
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       const float lv = o[D / 32][qb][G::L_REG];
@@ -671,7 +727,8 @@ __global__ __launch_bounds__(256, 2) void attention_xs_kernel(const AttnArgs a, 
 
 template <int D, int QB>
 int launch_xs(const AttnArgs& a, hipStream_t stream) {
-  constexpr int lds = 2 * X32Geom<D>::BUF + 16;
+  constexpr int lds = 2 * X32Geom<D>::BUF + 16 + 4 * QB * 32 * D * 2;      // + the four waves' output staging blocks
+  static_assert(lds <= 160 * 1024, "LDS");
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attention_xs_kernel<D, QB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

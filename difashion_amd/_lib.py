@@ -127,6 +127,7 @@ SIGNATURES = {
     "dfh_unet_train_workspace_bytes": (_sz, [_vp, _i]),
     "dfh_unet_bind_train": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
     "dfh_unet_pack_train": (_i, [_vp, C.POINTER(_vp), _i, _vp]),
+    "dfh_unet_pack_all": (_i, [_vp, C.POINTER(_vp), _i, _vp]),
     "dfh_unet_forward_train": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "dfh_unet_backward": (_i, [_vp, _vp, _vp, C.POINTER(_vp), _i, _i, _vp]),
     "dfh_unet_backward_begin": (_i, [_vp, _vp, _vp, _sz, _vp]),
@@ -213,7 +214,7 @@ _NO_STATUS = {"dfh_abi_version", "dfh_census_count", "dfh_unet_num_params", "dfh
               "dfh_vae_param_ndim", "dfh_vae_param_dim"}
 
 _lib = None
-ABI_VERSION = 4          # == DFH_ABI_VERSION of include/difashion_hip.h (checked when the library is loaded)
+ABI_VERSION = 5          # == DFH_ABI_VERSION of include/difashion_hip.h (checked when the library is loaded)
 
 
 def build(force: bool = False) -> str:

@@ -18,7 +18,7 @@ DFH_DEVICE int tab_geglu_row(int n, int N) {
 //   PACKT_MAT / PACKT_CONV      : 64 x 32 tiles transposed through LDS (rows of the master become columns of the pack; 64 outputs =
 //                                 one full 128-byte line per store).
 constexpr int TT_O = 64, TT_C = 32, TT_LD = TT_C * 9 + 2;       // transposed-pack tile: 64 outputs x 32 inputs (x 9 taps), odd dword stride
-__global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ ops, int nops, void* arena_vec, void* arena_mat) {
+__global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ ops, int nops, void* arena_vec, void* arena_mat, void* arena_mat2) {
   __shared__ int s_op;
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[TT_O * TT_LD * 2];
   bf16_t (*tile)[TT_LD] = (bf16_t (*)[TT_LD])s_raw;
@@ -193,6 +193,102 @@ __global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ op
       }
       break;
     }
+    case TAB_PACK2_MAT: {       // PACK_MAT (dst, ld, p0 = row_off, p1 = col_off, p2 = geglu) + PACKT_MAT (dst2, ld2, q0, q1) from one read
+      const int tk = (K + TT_C - 1) / TT_C;
+      const int n0 = (int)(blk / tk) * TT_O, k0 = (int)(blk % tk) * TT_C;
+      const bool fast = (K & 31) == 0 && n0 + TT_O <= N && ((uintptr_t)op.master & 15) == 0 && ((op.dst2 | op.ld2 | op.q1) & 1) == 0 &&
+                        ((op.dst | ld | op.p1) & 1) == 0;
+      if (fast) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int j = u * 256 + tid, nl = j >> 3, q = j & 7;
+          const float4 v = *(const float4*)((const float*)op.master + (long)(n0 + nl) * K + k0 + q * 4);
+          const uint32_t lo = pack2bf(v.x, v.y), hi = pack2bf(v.z, v.w);
+          *(uint32_t*)&tile[nl][q * 4] = lo;
+          *(uint32_t*)&tile[nl][q * 4 + 2] = hi;
+          const int r = op.p2 ? tab_geglu_row(n0 + nl, N) : n0 + nl;       // plain pack: straight from the registers, 8 bytes per lane
+          *(uint2*)((bf16_t*)arena_mat + op.dst + (long)(op.p0 + r) * ld + op.p1 + k0 + q * 4) = uint2{lo, hi};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = u * 256 + tid, k = j >> 5, nl = (j & 31) * 2;
+          const uint32_t pr = (uint32_t)tile[nl][k] | ((uint32_t)tile[nl + 1][k] << 16);
+          const int r = op.p2 ? tab_geglu_row(n0 + nl, N) : n0 + nl;
+          *(uint32_t*)((bf16_t*)arena_mat2 + op.dst2 + (long)(op.q0 + k0 + k) * op.ld2 + op.q1 + r) = pr;
+        }
+        break;
+      }
+      for (int j = tid; j < TT_O * TT_C; j += 256) {
+        const int n = n0 + (j >> 5), k = k0 + (j & 31);
+        bf16_t v = 0;
+        if (n < N && k < K) {
+          v = f2bf(((const float*)op.master)[(long)n * K + k]);
+          const int r = op.p2 ? tab_geglu_row(n, N) : n;
+          ((bf16_t*)arena_mat)[op.dst + (long)(op.p0 + r) * ld + op.p1 + k] = v;
+        }
+        tile[j >> 5][j & 31] = v;
+      }
+      __syncthreads();
+      for (int j = tid; j < TT_O * TT_C; j += 256) {
+        const int k = k0 + (j >> 6), n = n0 + (j & 63);
+        if (n < N && k < K) {
+          const int r = op.p2 ? tab_geglu_row(n, N) : n;
+          ((bf16_t*)arena_mat2)[op.dst2 + (long)(op.q0 + k) * op.ld2 + op.q1 + r] = tile[j & 63][j >> 6];
+        }
+      }
+      break;
+    }
+    case TAB_PACK2_CONV: {      // PACK_CONV (dst, ld, p1 = col_off, p3 = cin_pad) + PACKT_CONV (dst2, ld2, q1 = t_col_off, q3 = o_pad) from one read
+      const int tc = (K + TT_C - 1) / TT_C;
+      const int o0 = (int)(blk / tc) * TT_O, c0 = (int)(blk % tc) * TT_C;
+      const int cw = min(TT_C, K - c0);
+      const int run = cw * 9;
+      const bool fast = (K & 31) == 0 && o0 + TT_O <= N && ((uintptr_t)op.master & 15) == 0 && ((op.dst2 | op.ld2 | op.q1 | op.q3) & 1) == 0 &&
+                        ((op.dst | ld | op.p1 | op.p3) & 1) == 0;
+      if (fast) {
+#pragma unroll 6
+        for (int u = 0; u < 18; ++u) {
+          const int j = u * 256 + tid, ol = j / 72, q = j - ol * 72;
+          const float4 v = *(const float4*)((const float*)op.master + ((long)(o0 + ol) * K + c0) * 9 + q * 4);
+          *(uint32_t*)&tile[ol][q * 4] = pack2bf(v.x, v.y);
+          *(uint32_t*)&tile[ol][q * 4 + 2] = pack2bf(v.z, v.w);
+        }
+        __syncthreads();
+#pragma unroll 6
+        for (int u = 0; u < 36; ++u) {               // transposed pack: 288 (c, t) columns x 32 pairs of outputs
+          const int j = u * 256 + tid, ct = j >> 5, ol = (j & 31) * 2;
+          const int cl = ct / 9, t = ct - cl * 9;
+          const uint32_t pr = (uint32_t)tile[ol][ct] | ((uint32_t)tile[ol + 1][ct] << 16);
+          *(uint32_t*)((bf16_t*)arena_mat2 + op.dst2 + (long)(c0 + cl) * op.ld2 + op.q1 + (8 - t) * op.q3 + o0 + ol) = pr;
+        }
+#pragma unroll 6
+        for (int u = 0; u < 36; ++u) {               // plain pack: 64 outputs x 9 taps x 16 pairs of channels (64-byte runs per (o, t))
+          const int j = u * 256 + tid, cl = (j & 15) * 2, ot = j >> 4;
+          const int ol = ot / 9, t = ot - ol * 9;
+          const uint32_t pr = (uint32_t)tile[ol][cl * 9 + t] | ((uint32_t)tile[ol][(cl + 1) * 9 + t] << 16);
+          *(uint32_t*)((bf16_t*)arena_mat + op.dst + (long)(o0 + ol) * ld + op.p1 + t * op.p3 + c0 + cl) = pr;
+        }
+        break;
+      }
+      for (int j = tid; j < TT_O * run; j += 256) {
+        const int ol = j / run, jj = j - ol * run, o = o0 + ol;
+        bf16_t v = 0;
+        if (o < N) {
+          v = f2bf(((const float*)op.master)[((long)o * K + c0) * 9 + jj]);
+          const int cl = jj / 9, t = jj - cl * 9;
+          ((bf16_t*)arena_mat)[op.dst + (long)o * ld + op.p1 + t * op.p3 + c0 + cl] = v;
+        }
+        tile[ol][jj] = v;
+      }
+      __syncthreads();
+      for (int j = tid; j < run * TT_O; j += 256) {
+        const int ol = j & 63, ct = j >> 6;
+        const int cl = ct / 9, t = ct - cl * 9, o = o0 + ol;
+        if (o < N) ((bf16_t*)arena_mat2)[op.dst2 + (long)(c0 + cl) * op.ld2 + op.q1 + (8 - t) * op.q3 + o] = tile[ol][ct];
+      }
+      break;
+    }
     default: break;
   }
 }
@@ -208,9 +304,9 @@ unsigned tab_blocks(int kind, int N, int K) {
     default: return (unsigned)(((N + 63) / 64) * ((K + 31) / 32));       // transposed packs: 64 x 32 tiles
   }
 }
-int table_launch(const TabOp* dev_ops, int nops, unsigned total_blocks, void* arena_vec, void* arena_mat, hipStream_t s) {
+int table_launch(const TabOp* dev_ops, int nops, unsigned total_blocks, void* arena_vec, void* arena_mat, hipStream_t s, void* arena_mat2) {
   if (nops <= 0 || total_blocks == 0) return 0;
-  hipLaunchKernelGGL(table_kernel, dim3(total_blocks), dim3(256), 0, s, dev_ops, nops, arena_vec, arena_mat);
+  hipLaunchKernelGGL(table_kernel, dim3(total_blocks), dim3(256), 0, s, dev_ops, nops, arena_vec, arena_mat, arena_mat2);
   return check_launch("table_kernel");
 }
 }  // namespace dfh

@@ -104,7 +104,13 @@ struct OpTable {
     blocks += dfh::tab_blocks(kind, N, K);
     host.push_back(op);
   }
-  int launch(void* arena_vec, void* arena_mat, hipStream_t s) {
+  // a PACK2 op: the plain pack (dst .. p3 as in add) and the transposed pack (dst2, ld2, q0 = t_row_off, q1 = t_col_off, q3 = o_pad) of one master
+  void add2(void* master, int kind, long dst, int N, int K, int ld, int p0, int p1, int p2, int p3, long dst2, int ld2, int q0, int q1, int q3) {
+    add(master, kind, dst, N, K, ld, p0, p1, p2, p3, 0);
+    TabOp& op = host.back();
+    op.dst2 = dst2; op.ld2 = ld2; op.q0 = q0; op.q1 = q1; op.q3 = q3;
+  }
+  int launch(void* arena_vec, void* arena_mat, hipStream_t s, void* arena_mat2 = nullptr) {
     if (host.empty()) return 0;
     const size_t bytes = host.size() * sizeof(TabOp);
     if (host.size() != uploaded.size() || std::memcmp(host.data(), uploaded.data(), bytes) != 0) {
@@ -119,7 +125,7 @@ struct OpTable {
       }
       uploaded = host;
     }
-    return dfh::table_launch(dev, (int)host.size(), blocks, arena_vec, arena_mat, s);
+    return dfh::table_launch(dev, (int)host.size(), blocks, arena_vec, arena_mat, s, arena_mat2);
   }
   ~OpTable() { if (dev) (void)hipFree(dev); }
 };
@@ -1185,7 +1191,8 @@ struct dfh_unet {
     return r.rc;
   }
 
-  OpTable tab_pack, tab_pack_acc, tab_packt, tab_unpack;
+  OpTable tab_pack, tab_pack_acc, tab_packt, tab_unpack, tab_pack2;
+  int pack_all(const float* const* master, int count, hipStream_t s);      // training: pack() + pack_train() with one read of the weights (unet_train.hip)
   // every PackOp in one launch (plus one for the few biases that ADD onto an already packed vector)
   int pack(const float* const* master, int count, hipStream_t s) {
     DFH_REQUIRE(count == (int)params.size(), "parameter count mismatch");

@@ -775,6 +775,51 @@ int dfh_unet::pack_train(const float* const* master, int count, hipStream_t s) {
   return tab_packt.launch(nullptr, arena16t, s);
 }
 
+// pack() + pack_train() of a training step in one pass over the masters: every weight that has exactly one plain and one transposed pack
+// goes through a PACK2 op (read once, written to arena16 AND arena16t); vectors, the few weights packed more than once and the
+// accumulating biases keep their own ops.  Same bytes in both arenas as the two separate calls (tests/test_gpu_train.py).
+int dfh_unet::pack_all(const float* const* master, int count, hipStream_t s) {
+  DFH_REQUIRE(count == (int)params.size(), "parameter count mismatch");
+  DFH_REQUIRE(arena16 && arena32 && arena16t, "arenas not bound");
+  std::vector<int> n_plain(params.size(), 0), n_tr(params.size(), 0), tr_at(params.size(), -1);
+  for (const PackOp& op : packs) if (op.kind != PK_VEC) ++n_plain[op.param];
+  for (size_t i = 0; i < tpacks.size(); ++i) { ++n_tr[tpacks[i].param]; tr_at[tpacks[i].param] = (int)i; }
+  tab_pack2.clear(); tab_pack_acc.clear(); tab_packt.clear();
+  for (const PackOp& op : packs) {
+    void* src = (void*)master[op.param];
+    DFH_REQUIRE(src != nullptr, "null master parameter: " + params[op.param].name);
+    if (op.kind == PK_VEC) {
+      (op.accumulate ? tab_pack_acc : tab_pack2).add(src, TAB_PACK_VEC, (long)op.dst, op.N, 0, 0, op.geglu, op.accumulate, 0, 0, op.N);
+      continue;
+    }
+    const bool twin = n_plain[op.param] == 1 && n_tr[op.param] == 1;
+    const TPackOp* t = twin ? &tpacks[tr_at[op.param]] : nullptr;
+    if (t && t->N == op.N && t->K == op.K && (t->conv != 0) == (op.kind != PK_MAT) && t->geglu == op.geglu) {
+      if (op.kind == PK_MAT)
+        tab_pack2.add2(src, TAB_PACK2_MAT, (long)op.dst, op.N, op.K, op.ldw, op.row_off, op.col_off, op.geglu, 0, (long)t->dst, t->ldt, t->t_row_off, t->t_col_off, 0);
+      else
+        tab_pack2.add2(src, TAB_PACK2_CONV, (long)op.dst, op.N, op.K, op.ldw, 0, op.col_off, 0, op.cin_pad, (long)t->dst, t->ldt, 0, t->t_col_off, t->o_pad);
+      n_tr[op.param] = -1;                      // its transposed pack is done
+    } else if (op.kind == PK_MAT) {
+      tab_pack2.add(src, TAB_PACK_MAT, (long)op.dst, op.N, op.K, op.ldw, op.row_off, op.col_off, op.geglu, 0, (long)op.N * op.K);
+    } else {
+      tab_pack2.add(src, TAB_PACK_CONV, (long)op.dst, op.N, op.K, op.ldw, 0, op.col_off, 0, op.cin_pad, (long)op.N * op.K * 9);
+    }
+  }
+  for (const TPackOp& op : tpacks) {            // transposed packs without a twin
+    if (n_tr[op.param] < 0) continue;
+    void* src = (void*)master[op.param];
+    if (op.conv) tab_packt.add(src, TAB_PACKT_CONV, (long)op.dst, op.N, op.K, op.ldt, 0, op.t_col_off, 0, op.o_pad, (long)op.N * op.K * 9);
+    else tab_packt.add(src, TAB_PACKT_MAT, (long)op.dst, op.N, op.K, op.ldt, op.t_row_off, op.t_col_off, op.geglu, 0, (long)op.N * op.K);
+  }
+  if (int rc = tab_pack2.launch(arena32, arena16, s, arena16t)) return rc;
+  if (int rc = tab_pack_acc.launch(arena32, arena16, s)) return rc;
+  if (int rc = tab_packt.launch(nullptr, arena16t, s)) return rc;
+  if (int rc = quantize_fp8(s)) return rc;
+  fold_valid = false; fold_dirty = true;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------- C ABI
 extern "C" {
 
@@ -802,6 +847,12 @@ int dfh_unet_bind_train(dfh_unet* u, void* arena16t, void* grad16, void* grad32,
 int dfh_unet_pack_train(dfh_unet* u, const float* const* master_params, int count, void* stream) {
   DFH_REQUIRE(u && master_params, "null argument");
   return u->pack_train(master_params, count, (hipStream_t)stream);
+}
+
+int dfh_unet_pack_all(dfh_unet* u, const float* const* master_params, int count, void* stream) {
+  DFH_REQUIRE(u && master_params, "null argument");
+  u->build_train();
+  return u->pack_all(master_params, count, (hipStream_t)stream);
 }
 
 int dfh_unet_forward_train(dfh_unet* u, const void* sample, int sample_bf16, const float* timestep, const void* ehs, int ehs_bf16,

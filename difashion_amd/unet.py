@@ -338,9 +338,10 @@ class UNet2DConditionModel(nn.Module):
         if not force and sig == self._packed_sig:
             return
         arr = (C.c_void_p * len(plist))(*[p.data_ptr() for p in plist])
-        _lib.call("dfh_unet_pack", self._ctx, arr, len(plist), _lib.stream_ptr())
-        if self._train_buffers is not None:
-            _lib.call("dfh_unet_pack_train", self._ctx, arr, len(plist), _lib.stream_ptr())
+        if self._train_buffers is not None:      # plain + transposed packs from ONE read of the masters
+            _lib.call("dfh_unet_pack_all", self._ctx, arr, len(plist), _lib.stream_ptr())
+        else:
+            _lib.call("dfh_unet_pack", self._ctx, arr, len(plist), _lib.stream_ptr())
         self._packed_sig = sig
 
     # ------------------------------------------------------------------ per-run constants of a sampling loop

@@ -29,7 +29,7 @@ extern "C" {
 /* Bumped whenever an entry point, a struct layout or the meaning of an argument changes (round 4: 4).  The Python host side
  * (difashion_amd/_lib.py ABI_VERSION) refuses a library that reports another number: a stale .so next to new Python, or the reverse,
  * fails at load time instead of at a symbol lookup or silently. */
-#define DFH_ABI_VERSION 4
+#define DFH_ABI_VERSION 5
 #define DFH_MAX_BLOCKS 4
 
 /* ------------------------------------------------------------------ library */
@@ -146,6 +146,9 @@ int dfh_unet_bind_train(dfh_unet* u, void* arena16t, void* grad16, void* grad32,
                         int max_batch);
 /* master parameters -> arena16t; call together with dfh_unet_pack after every weight update */
 int dfh_unet_pack_train(dfh_unet* u, const float* const* master_params, int count, void* stream);
+/* dfh_unet_pack + dfh_unet_pack_train in one pass over the master parameters (each weight is read once and written to both arenas);
+ * what a training step calls after the optimizer moved the weights.  Needs dfh_unet_bind_train. */
+int dfh_unet_pack_all(dfh_unet* u, const float* const* master_params, int count, void* stream);
 /* same arguments and result as dfh_unet_forward; keeps the activations the backward needs */
 int dfh_unet_forward_train(dfh_unet* u, const void* sample, int sample_bf16, const float* timestep,
                            const void* ehs, int ehs_bf16, float* out, int batch, void* stream);

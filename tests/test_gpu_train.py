@@ -465,6 +465,33 @@ def test_side_stream_weight_gradients_are_bit_identical_to_the_one_stream_walk(t
     assert mats > 100
 
 
+@pytest.mark.parametrize("cfg", [GLUE_CFG, LINEAR_CFG], ids=["glue", "linear_proj"])
+def test_pack_all_writes_the_same_arenas_as_pack_plus_pack_train(cfg):
+    """dfh_unet_pack_all (one read of every master weight, written to the plain AND the transposed arena: what the training step calls
+    after an optimizer update) against dfh_unet_pack + dfh_unet_pack_train: both bf16 arenas and the fp32 vector arena bit for bit."""
+    import ctypes as C
+    from difashion_amd import _lib
+    params = unet_ref.init_params(cfg, seed=11)
+    m = hip_unet(cfg, params, max_batch=2).train()
+    x, e = inputs(cfg, 2, 5)
+    m(x.to(DEV), torch.tensor([10, 700], device=DEV), e.to(DEV))           # binds the training arenas; packs through pack_all
+    torch.cuda.synchronize()
+    a16, a32 = m._buffers_dev[0], m._buffers_dev[1]
+    a16t = m._train_buffers[0]
+    got = (a16.clone(), a32.clone(), a16t.clone())
+    named = dict(m.named_parameters())
+    plist = [named[n] for n in m._names]
+    arr = (C.c_void_p * len(plist))(*[p.data_ptr() for p in plist])
+    for buf in (a16, a32, a16t):
+        buf.zero_()
+    _lib.call("dfh_unet_pack", m._ctx, arr, len(plist), _lib.stream_ptr())
+    _lib.call("dfh_unet_pack_train", m._ctx, arr, len(plist), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    for name, new, ref in zip(("arena16", "arena32", "arena16t"), got, (a16, a32, a16t)):
+        assert torch.equal(new, ref), (name, int((new != ref).sum()))
+    assert int((a16t != 0).sum()) > a16t.numel() // 4
+
+
 def test_segmented_backward_equals_the_monolithic_one():
     """dfh_unet_backward_begin / _next / _finish (the pieces behind the overlapped gradient all-reduce): the ranges handed
     out are disjoint, cover every written float of the packed gradient arena exactly once, and the master gradients equal

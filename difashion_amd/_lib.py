@@ -128,6 +128,7 @@ SIGNATURES = {
     "dfh_unet_bind_train": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i]),
     "dfh_unet_pack_train": (_i, [_vp, C.POINTER(_vp), _i, _vp]),
     "dfh_unet_pack_all": (_i, [_vp, C.POINTER(_vp), _i, _vp]),
+    "dfh_unet_grad_sumsq": (_i, [_vp, _vp]),
     "dfh_unet_forward_train": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "dfh_unet_backward": (_i, [_vp, _vp, _vp, C.POINTER(_vp), _i, _i, _vp]),
     "dfh_unet_backward_begin": (_i, [_vp, _vp, _vp, _sz, _vp]),

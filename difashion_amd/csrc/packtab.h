@@ -28,5 +28,9 @@ namespace dfh {
 unsigned tab_blocks(int kind, int N, int K);   // blocks one op occupies in the fused grid
 // arena: arena32 (VEC) / arena16 / arena16t / grad32 / grad16 according to the op kinds in the table
 // arena_mat2: the transposed arena of the PACK2 kinds (nullptr otherwise)
-int table_launch(const TabOp* dev_ops, int nops, unsigned total_blocks, void* arena_vec, void* arena_mat, hipStream_t s, void* arena_mat2 = nullptr);
+// sq_partials (un-pack tables): one float per block = sum of the squares of the gradient values the block wrote
+int table_launch(const TabOp* dev_ops, int nops, unsigned total_blocks, void* arena_vec, void* arena_mat, hipStream_t s, void* arena_mat2 = nullptr,
+                 float* sq_partials = nullptr);
+// out[0] = sum of the n block partials, in a fixed order; scratch = 257 floats (256 block sums + a zero-initialised ticket counter)
+int table_sq_reduce_launch(const float* partials, long n, float* scratch, float* out, hipStream_t s);
 }

@@ -18,7 +18,8 @@ DFH_DEVICE int tab_geglu_row(int n, int N) {
 //   PACKT_MAT / PACKT_CONV      : 64 x 32 tiles transposed through LDS (rows of the master become columns of the pack; 64 outputs =
 //                                 one full 128-byte line per store).
 constexpr int TT_O = 64, TT_C = 32, TT_LD = TT_C * 9 + 2;       // transposed-pack tile: 64 outputs x 32 inputs (x 9 taps), odd dword stride
-__global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ ops, int nops, void* arena_vec, void* arena_mat, void* arena_mat2) {
+__global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ ops, int nops, void* arena_vec, void* arena_mat, void* arena_mat2,
+                                                    float* __restrict__ sq_partials) {
   __shared__ int s_op;
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[TT_O * TT_LD * 2];
   bf16_t (*tile)[TT_LD] = (bf16_t (*)[TT_LD])s_raw;
@@ -35,6 +36,7 @@ __global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ op
   const TabOp op = ops[s_op];
   const long blk = (long)(blockIdx.x - op.first_block);
   const int N = op.N, K = op.K, ld = op.ld, tid = threadIdx.x;
+  float sq = 0.f;              // un-pack kinds: sum of the squares of the gradient values this thread wrote (sq_partials, below)
   switch (op.kind) {
     case TAB_PACK_VEC: {        // p0 = geglu, p1 = accumulate
       for (int j = 0; j < TAB_ELEMS_PER_BLOCK / 256; ++j) {
@@ -53,7 +55,9 @@ __global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ op
         if (i >= N) break;
         const int r = op.p0 ? tab_geglu_row((int)i, N) : (int)i;
         const float gv = ((const float*)arena_vec)[op.dst + r];
-        ((float*)op.master)[i] = op.p1 ? gv : ((float*)op.master)[i] + gv;      // p1 = overwrite
+        const float nv = op.p1 ? gv : ((float*)op.master)[i] + gv;              // p1 = overwrite
+        ((float*)op.master)[i] = nv;
+        sq += nv * nv;
       }
       break;
     }
@@ -74,6 +78,7 @@ __global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ op
             float4 g = *(const float4*)((const float*)arena_mat + at);
             if (!op.p3) { const float4 v = *m4; g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w; }
             *m4 = g;
+            sq += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
           }
         }
         break;
@@ -85,7 +90,11 @@ __global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ op
         const int r = op.p2 ? tab_geglu_row(n, N) : n;
         const long at = op.dst + (long)(op.p0 + r) * ld + op.p1 + k;
         if (op.kind == TAB_PACK_MAT) ((bf16_t*)arena_mat)[at] = f2bf(((const float*)op.master)[i]);
-        else ((float*)op.master)[i] = op.p3 ? ((const float*)arena_mat)[at] : ((float*)op.master)[i] + ((const float*)arena_mat)[at];
+        else {
+          const float nv = op.p3 ? ((const float*)arena_mat)[at] : ((float*)op.master)[i] + ((const float*)arena_mat)[at];
+          ((float*)op.master)[i] = nv;
+          sq += nv * nv;
+        }
       }
       break;
     }
@@ -114,9 +123,10 @@ __global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ op
             float4 v = *(const float4*)(stage + j);
             if (!op.p0) { const float4 g = *(const float4*)(mst + j); v.x += g.x; v.y += g.y; v.z += g.z; v.w += g.w; }
             *(float4*)(mst + j) = v;
+            sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
           }
         } else {
-          for (int j = tid; j < fn; j += 256) mst[j] = op.p0 ? stage[j] : mst[j] + stage[j];
+          for (int j = tid; j < fn; j += 256) { const float nv = op.p0 ? stage[j] : mst[j] + stage[j]; mst[j] = nv; sq += nv * nv; }
         }
       }
       break;
@@ -291,6 +301,41 @@ __global__ __launch_bounds__(256) void table_kernel(const TabOp* __restrict__ op
     }
     default: break;
   }
+  // gradient norm (dfh_unet_grad_sumsq): one partial per block, fixed order inside the block; table_sq_reduce sums the blocks in order
+  if (sq_partials) {
+    __shared__ float sq_red[4];
+    sq = wave_sum(sq);
+    __syncthreads();                                  // (the cases above are done with the shared tile)
+    if ((tid & 63) == 0) sq_red[tid >> 6] = sq;
+    __syncthreads();
+    if (tid == 0) sq_partials[blockIdx.x] = (sq_red[0] + sq_red[1]) + (sq_red[2] + sq_red[3]);
+  }
+}
+
+// out[0] = sum of p[0..n): 256 blocks of 256 threads, each thread a strided run in ascending order, then the block, then (the last block
+// to arrive, by ticket) the 256 block sums in order -- no float atomics: the same bits on every run and every rank
+__global__ __launch_bounds__(256) void table_sq_reduce_kernel(const float* __restrict__ p, long n, float* __restrict__ block_sums,
+                                                              unsigned* __restrict__ counter, float* __restrict__ out) {
+  __shared__ float red[4];
+  __shared__ bool last;
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += p[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    block_sums[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    __threadfence();
+    last = atomicAdd(counter, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float t = threadIdx.x < gridDim.x ? ((const volatile float*)block_sums)[threadIdx.x] : 0.f;
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) { *out = (red[0] + red[1]) + (red[2] + red[3]); *counter = 0u; }
 }
 
 }  // namespace
@@ -304,9 +349,15 @@ unsigned tab_blocks(int kind, int N, int K) {
     default: return (unsigned)(((N + 63) / 64) * ((K + 31) / 32));       // transposed packs: 64 x 32 tiles
   }
 }
-int table_launch(const TabOp* dev_ops, int nops, unsigned total_blocks, void* arena_vec, void* arena_mat, hipStream_t s, void* arena_mat2) {
+int table_launch(const TabOp* dev_ops, int nops, unsigned total_blocks, void* arena_vec, void* arena_mat, hipStream_t s, void* arena_mat2,
+                 float* sq_partials) {
   if (nops <= 0 || total_blocks == 0) return 0;
-  hipLaunchKernelGGL(table_kernel, dim3(total_blocks), dim3(256), 0, s, dev_ops, nops, arena_vec, arena_mat, arena_mat2);
+  hipLaunchKernelGGL(table_kernel, dim3(total_blocks), dim3(256), 0, s, dev_ops, nops, arena_vec, arena_mat, arena_mat2, sq_partials);
   return check_launch("table_kernel");
+}
+int table_sq_reduce_launch(const float* partials, long n, float* scratch, float* out, hipStream_t s) {
+  // scratch: 256 block sums + the ticket counter (zeroed once by the owner; the kernel resets it)
+  hipLaunchKernelGGL(table_sq_reduce_kernel, dim3(256), dim3(256), 0, s, partials, n, scratch, (unsigned*)(scratch + 256), out);
+  return check_launch("table_sq_reduce_kernel");
 }
 }  // namespace dfh

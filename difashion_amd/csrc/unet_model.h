@@ -110,7 +110,7 @@ struct OpTable {
     TabOp& op = host.back();
     op.dst2 = dst2; op.ld2 = ld2; op.q0 = q0; op.q1 = q1; op.q3 = q3;
   }
-  int launch(void* arena_vec, void* arena_mat, hipStream_t s, void* arena_mat2 = nullptr) {
+  int launch(void* arena_vec, void* arena_mat, hipStream_t s, void* arena_mat2 = nullptr, float* sq_partials = nullptr) {
     if (host.empty()) return 0;
     const size_t bytes = host.size() * sizeof(TabOp);
     if (host.size() != uploaded.size() || std::memcmp(host.data(), uploaded.data(), bytes) != 0) {
@@ -125,7 +125,7 @@ struct OpTable {
       }
       uploaded = host;
     }
-    return dfh::table_launch(dev, (int)host.size(), blocks, arena_vec, arena_mat, s, arena_mat2);
+    return dfh::table_launch(dev, (int)host.size(), blocks, arena_vec, arena_mat, s, arena_mat2, sq_partials);
   }
   ~OpTable() { if (dev) (void)hipFree(dev); }
 };
@@ -181,6 +181,9 @@ struct dfh_unet {
   // backward walk: the weight-gradient GEMM of a layer runs on a second stream beside the data-gradient GEMM of the same layer
   // (both only read dY): the tail round of one is filled with blocks of the other (unet_train.hip TrainRun::wgrad / join)
   hipStream_t side_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // dfh_unet_grad_sumsq: the un-pack of the backward also leaves the sum of the squares of every gradient value it wrote in *grad_sumsq_out
+  // (the clip norm of the optimizer without another pass over 3.4 GB); per-block partials + a fixed-order reduce, no float atomics
+  float* grad_sumsq_out = nullptr; float* sq_partials = nullptr; size_t sq_cap = 0; float* sq_scratch = nullptr;
   int build_train();
   size_t plan_train(int B);
   int forward_train(const void* sample, int sample_bf16, const float* timestep, const void* ehs, int ehs_bf16, float* out, int B,

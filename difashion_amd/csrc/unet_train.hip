@@ -575,6 +575,8 @@ dfh_unet::~dfh_unet() {
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (ev_join) (void)hipEventDestroy(ev_join);
   if (side_stream) (void)hipStreamDestroy(side_stream);
+  if (sq_partials) (void)hipFree(sq_partials);
+  if (sq_scratch) (void)hipFree(sq_scratch);
 }
 
 // ------------------------------------------------------------------------------------------- build / plan
@@ -759,7 +761,20 @@ int dfh_unet::backward_finish(float* const* master_grads, int count, hipStream_t
     else if (op.kind == PK_MAT) tab_unpack.add(g, TAB_UNPACK_MAT, (long)op.dst, op.N, op.K, op.ldw, op.row_off, op.col_off, op.geglu, overwrite, (long)op.N * op.K);
     else tab_unpack.add(g, TAB_UNPACK_CONV, (long)op.dst, op.N, op.K, op.ldw, overwrite, op.col_off, 0, op.cin_pad, (long)op.N * op.K * 9);
   }
-  return tab_unpack.launch(grad32, grad16, s);
+  if (!grad_sumsq_out) return tab_unpack.launch(grad32, grad16, s);
+  if (tab_unpack.blocks > sq_cap) {
+    if (sq_partials) (void)hipFree(sq_partials);
+    sq_partials = nullptr; sq_cap = 0;
+    if (hipMalloc((void**)&sq_partials, (size_t)tab_unpack.blocks * sizeof(float)) != hipSuccess) { dfh::set_error("hipMalloc of the norm partials failed"); return -1; }
+    sq_cap = tab_unpack.blocks;
+  }
+  if (!sq_scratch) {
+    if (hipMalloc((void**)&sq_scratch, 257 * sizeof(float)) != hipSuccess || hipMemset(sq_scratch, 0, 257 * sizeof(float)) != hipSuccess) {
+      dfh::set_error("hipMalloc of the norm scratch failed"); return -1;
+    }
+  }
+  if (int rc = tab_unpack.launch(grad32, grad16, s, nullptr, sq_partials)) return rc;
+  return dfh::table_sq_reduce_launch(sq_partials, (long)tab_unpack.blocks, sq_scratch, grad_sumsq_out, s);
 }
 
 int dfh_unet::pack_train(const float* const* master, int count, hipStream_t s) {
@@ -847,6 +862,12 @@ int dfh_unet_bind_train(dfh_unet* u, void* arena16t, void* grad16, void* grad32,
 int dfh_unet_pack_train(dfh_unet* u, const float* const* master_params, int count, void* stream) {
   DFH_REQUIRE(u && master_params, "null argument");
   return u->pack_train(master_params, count, (hipStream_t)stream);
+}
+
+int dfh_unet_grad_sumsq(dfh_unet* u, float* out) {
+  DFH_REQUIRE(u, "null argument");
+  u->grad_sumsq_out = out;
+  return 0;
 }
 
 int dfh_unet_pack_all(dfh_unet* u, const float* const* master_params, int count, void* stream) {

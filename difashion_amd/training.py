@@ -181,10 +181,25 @@ class FusedAdamW(torch.optim.Optimizer):
         """Global L2 norm of the gradients at the last step() (device scalar; no host sync)."""
         return self._sumsq.sqrt()[0]
 
+    def _module_range(self, params) -> Optional[tuple]:
+        """[lo, hi) of the flat buffers when ``params`` occupy one gap-free run of it, else None."""
+        if not params or any(id(p) not in self._slices for p in params):
+            return None
+        offs = sorted(self._slices[id(p)] for p in params)
+        end = offs[0][0]
+        for off, n in offs:
+            if off != end:
+                return None
+            end = off + _align(n)
+        return offs[0][0], end
+
     @torch.no_grad()
-    def step(self, closure=None, ema: Optional["EMAModel"] = None):
+    def step(self, closure=None, ema: Optional["EMAModel"] = None, presummed=None):
         """``ema``: an EMAModel over a prefix of this optimizer's parameters (same order): its update is folded into the
-        AdamW launch for that range (the caller must then NOT call ema.step())."""
+        AdamW launch for that range (the caller must then NOT call ema.step()).
+        ``presummed``: ``(parameters, tensor)`` -- ``tensor[0]`` already holds the sum of the squares of the CURRENT gradients of
+        ``parameters`` (UNet2DConditionModel leaves it behind its backward's gradient un-pack): the clip norm then skips that range of
+        the flat gradient buffer (3.4 GB less to read per step).  Ignored unless the parameters are one gap-free, fully fresh run."""
         loss = closure() if closure is not None else None
         ema_end, ema_decay = 0, 0.0
         if ema is not None:
@@ -205,9 +220,18 @@ class FusedAdamW(torch.optim.Optimizer):
                 if self._fresh(p):
                     self._pstep[id(p)] = self._pstep.get(id(p), 0) + 1
         fresh_all = self._fresh_ranges(0, total)
+        pre = None
+        if presummed is not None and self.max_grad_norm is not None:
+            rng = self._module_range(list(presummed[0]))
+            if rng is not None and all(p.requires_grad and self._fresh(p) for p in presummed[0]):
+                pre = (rng[0], rng[1], presummed[1])
         self._sumsq.zero_()
         for lo, hi, _ in fresh_all:            # the clip norm counts fresh gradients only (clip_grad_norm_ skips grad None);
-            _lib.call("dfh_sumsq", self.flat_grad.data_ptr() + 4 * lo, hi - lo, _lib.ptr(self._sumsq), s)   # fixed order: deterministic
+            pieces = [(lo, hi)] if pre is None else [(a, b) for a, b in ((lo, min(hi, pre[0])), (max(lo, pre[1]), hi)) if b > a]
+            for a, b in pieces:
+                _lib.call("dfh_sumsq", self.flat_grad.data_ptr() + 4 * a, b - a, _lib.ptr(self._sumsq), s)   # fixed order: deterministic
+        if pre is not None:
+            self._sumsq.add_(pre[2].to(self._sumsq.device))
         clip = self.max_grad_norm is not None
         for g, (a, b) in zip(self.param_groups, self._group_ranges):
             if b == a:
@@ -422,7 +446,13 @@ def train_step(unet, fashion_encoder, scheduler, optimizer: FusedAdamW, *, lr_sc
     first = next(iter(unet.parameters()))
     fuse_ema = (ema_unet is not None and ema_unet.flat.device.type == "cuda"
                 and first.data_ptr() == optimizer.flat_param.data_ptr() and all(p.requires_grad for p in unet.parameters()))
-    optimizer.step(ema=ema_unet if fuse_ema else None)
+    # the U-Net's backward left sum(g^2) of its gradients behind its un-pack: valid if nothing wrote them since (they were averaged over the
+    # ranks INSIDE the backward, or there is nothing to average)
+    pres = None
+    if getattr(unet, "grad_sumsq_valid", False) and (getattr(unet, "grads_synced", False) or not _dist.active()):
+        pres = (list(unet.parameters()), unet._grad_sumsq)
+    unet.grad_sumsq_valid = False
+    optimizer.step(ema=ema_unet if fuse_ema else None, presummed=pres)
     if lr_scheduler is not None:
         lr_scheduler.step()
     optimizer.zero_grad(lazy_modules=(unet,))

@@ -325,6 +325,13 @@ class UNet2DConditionModel(nn.Module):
         self._train_buffers = (a16t, g16, g32, ws)
         self._train_batch = batch
         self._packed_sig = None             # the transposed packs have to be (re)built
+        # the gradient un-pack at the end of backward also leaves sum(g^2) of everything it wrote here: the optimizer's clip norm without
+        # another pass over the gradients (training.train_step / FusedAdamW.step(presummed=...)); DFH_TRAIN_UNPACK_NORM=0 switches it off (A/B)
+        self._grad_sumsq = None
+        self.grad_sumsq_valid = False
+        if os.environ.get("DFH_TRAIN_UNPACK_NORM", "1") != "0":
+            self._grad_sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+            _lib.call("dfh_unet_grad_sumsq", ctx, _lib.ptr(self._grad_sumsq))
 
     def _signature(self, params):
         return tuple((p.data_ptr(), p._version) for p in params) + (_lib.weight_epoch(),)
@@ -468,12 +475,16 @@ class UNet2DConditionModel(nn.Module):
         else:
             _lib.call("dfh_unet_backward", self._ctx, _lib.ptr(d_out), _lib.ptr(d_sample) if need_dsample else None, arr,
                       len(plist), overwrite, _lib.stream_ptr())
+        # sum(g^2) of the gradients as they now stand (valid until something else writes them; consumed by training.train_step)
+        self.grad_sumsq_valid = self._grad_sumsq is not None and all(p.requires_grad and p.grad is not None for p in plist)
         return d_sample
 
     # data-parallel: gradients averaged over the ranks INSIDE backward (DDP semantics; set False around the non-final
     # micro-batches of a gradient-accumulation step, like DDP.no_sync(), and reduce once with dist.all_reduce_gradients)
     sync_grads_in_backward = True
     grads_synced = False
+    grad_sumsq_valid = False
+    _grad_sumsq = None
     grad_bucket_bytes = 256 << 20         # few, large buckets: xGMI rings are per-link bound, not latency bound
     # wire format of the gradient exchange: "bf16" (default: half the bytes per xGMI link, fp32 accumulation in rank order,
     # dist.exchange_bf16) or "fp32" (one RCCL all-reduce per range).  Nothing is exchanged in a single-process run.

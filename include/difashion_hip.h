@@ -149,6 +149,11 @@ int dfh_unet_pack_train(dfh_unet* u, const float* const* master_params, int coun
 /* dfh_unet_pack + dfh_unet_pack_train in one pass over the master parameters (each weight is read once and written to both arenas);
  * what a training step calls after the optimizer moved the weights.  Needs dfh_unet_bind_train. */
 int dfh_unet_pack_all(dfh_unet* u, const float* const* master_params, int count, void* stream);
+/* out != NULL: from now on the gradient un-pack at the end of dfh_unet_backward / _backward_finish also writes
+ * out[0] = sum of the squares of every gradient value it wrote into master_grads (the final values, also when it accumulates): the
+ * clip norm of train.py:700 without another pass over the gradients.  Deterministic (per-block partials, fixed-order reduce).
+ * out == NULL switches it off.  The float must stay valid until then. */
+int dfh_unet_grad_sumsq(dfh_unet* u, float* out);
 /* same arguments and result as dfh_unet_forward; keeps the activations the backward needs */
 int dfh_unet_forward_train(dfh_unet* u, const void* sample, int sample_bf16, const float* timestep,
                            const void* ehs, int ehs_bf16, float* out, int batch, void* stream);

@@ -100,8 +100,9 @@ def main():
     # same kernels, same order; bias / norm-scale gradients are accumulated with float atomics in either run, hence not bit for bit
     r = [rel(g1[0], g0[0]), rel(g1[1], g0[1]), rel(p1 - p0 + p0, p0), rel(e1, e0)]
     print("fp32 wire vs no collective: gradient step 1 / step 2 / parameters / EMA relative differences " + " ".join(f"{v:.2e}" for v in r), flush=True)
-    # (measured 3.7e-8 / 1.5e-5 / 4.2e-7 / 3.5e-7: the atomics' last bits of step 1 flip a few bf16 roundings of the re-packed weights in step 2)
-    assert r[0] < 1e-6 and r[1] < 1e-3 and r[2] < 1e-5 and r[3] < 1e-5, r
+    # (measured 2e-8 .. 4e-8 / 1.5e-5 .. 4.2e-4 / 4e-7 .. 1.6e-5 / 3e-7 .. 1.3e-5 over repeated runs: the atomics' last bits of step 1 move AdamW's
+    # normalised update of near-zero gradients and flip a few bf16 roundings of the re-packed weights in step 2)
+    assert r[0] < 1e-6 and r[1] < 5e-3 and r[2] < 2e-4 and r[3] < 2e-4, r
     p2, e2, g2 = two_steps(rec, sched, kw, collectives=True, wire="bf16")
     # the U-Net's ranges went over the wire as bf16, the encoder's through the flat exchange as bf16 too: every gradient = bf16 of the exact one
     r16 = rel(g2[0], g0[0].to(torch.bfloat16).float())

@@ -492,6 +492,46 @@ def test_pack_all_writes_the_same_arenas_as_pack_plus_pack_train(cfg):
     assert int((a16t != 0).sum()) > a16t.numel() // 4
 
 
+def test_unpack_leaves_the_gradient_norm_and_the_optimizer_uses_it():
+    """dfh_unet_grad_sumsq: the gradient un-pack at the end of the native backward also leaves sum(g^2) of everything it wrote; FusedAdamW.step
+    (presummed=...) then skips the U-Net's range of the flat gradient buffer when it computes the clip norm (train.py:700).  Checked:
+    the number against torch over the very gradients (also when the backward ACCUMULATES into existing ones), the optimizer's norm with and
+    without it, and that train_step consumes it exactly once."""
+    from difashion_amd.pipeline import train_forward
+    rec = load(f"train_{TRAIN[0]}.npz")
+    unet = hip_unet(GLUE_CFG, glue_unet_params(), max_batch=32).train()
+    enc = make_encoder(rec)
+    sched = da.DDIMScheduler(prediction_type=str(rec["pred_type"]))
+    opt = da.FusedAdamW(list(unet.parameters()) + list(enc.parameters()), lr=2e-4, weight_decay=1e-2, max_grad_norm=1.0)
+    kw = batch_kwargs(rec, DEV)
+
+    def torch_sumsq(params):
+        return float(sum((p.grad.double() ** 2).sum() for p in params if p.grad is not None))
+
+    for rep in range(2):                     # second round: the backward adds onto the gradients of the first (no zero_grad in between)
+        train_forward(unet, enc, sched, **kw).backward()
+        torch.cuda.synchronize()
+        assert unet.grad_sumsq_valid
+        got, want = float(unet._grad_sumsq), torch_sumsq(unet.parameters())
+        assert abs(got - want) <= 1e-5 * want, (rep, got, want)
+    want_all = torch_sumsq(list(unet.parameters()) + list(enc.parameters())) ** 0.5
+    state = (opt.flat_param.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone())
+    opt.step(presummed=(list(unet.parameters()), unet._grad_sumsq))
+    n_pre = float(opt.grad_norm())
+    p_pre = opt.flat_param.clone()
+    opt.flat_param.copy_(state[0]); opt.exp_avg.copy_(state[1]); opt.exp_avg_sq.copy_(state[2]); opt._step -= 1
+    for p in opt._pstep:
+        opt._pstep[p] -= 1
+    opt.step()                               # the same update with the norm from a pass over the whole flat gradient buffer
+    n_full = float(opt.grad_norm())
+    assert abs(n_pre - want_all) <= 1e-5 * want_all and abs(n_full - want_all) <= 1e-5 * want_all, (n_pre, n_full, want_all)
+    torch.testing.assert_close(p_pre, opt.flat_param, rtol=1e-6, atol=1e-9)
+    # train_step: uses it, and invalidates it
+    opt.zero_grad(lazy_modules=(unet,))
+    da.train_step(unet, enc, sched, opt, **kw)
+    assert not unet.grad_sumsq_valid and float(opt.grad_norm()) > 0
+
+
 def test_segmented_backward_equals_the_monolithic_one():
     """dfh_unet_backward_begin / _next / _finish (the pieces behind the overlapped gradient all-reduce): the ranges handed
     out are disjoint, cover every written float of the packed gradient arena exactly once, and the master gradients equal

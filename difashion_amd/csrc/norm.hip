@@ -461,7 +461,9 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
   a.C = a.C0 + a.C1;
   DFH_REQUIRE(a.C % 8 == 0 && a.C0 % 8 == 0 && a.C1 % 8 == 0, "channels must be multiples of 8");
   DFH_REQUIRE(a.G > 0 && a.G <= 64 && a.C % a.G == 0, "bad group count");
-  DFH_REQUIRE(a.C / 8 <= 1024, "too many channels");
+  // the statistics / apply kernels run one thread per 8 channels in blocks of at most 512 threads (their launch bounds): 4096 channels,
+  // 3.2 x the widest tensor of the SD U-Nets (1280 + 1280 concatenated = 2560)
+  DFH_REQUIRE(a.C <= 4096, "GroupNorm over more than 4096 channels is not supported");
   DFH_REQUIRE((a.partial != nullptr || a.pre != nullptr) && (a.out != nullptr || a.out8 != nullptr) && a.src0 != nullptr, "null pointer");
   if (a.out8) DFH_REQUIRE(a.C1 == 0 && !a.silu && a.q_mul > 0.f && !a.stats_out, "e4m3 GroupNorm output: one source, no SiLU, a positive scale");
   DFH_REQUIRE(a.C1 == 0 || a.src1 != nullptr, "second source missing");

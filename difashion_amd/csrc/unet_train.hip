@@ -762,14 +762,20 @@ int dfh_unet::backward_finish(float* const* master_grads, int count, hipStream_t
     else tab_unpack.add(g, TAB_UNPACK_CONV, (long)op.dst, op.N, op.K, op.ldw, overwrite, op.col_off, 0, op.cin_pad, (long)op.N * op.K * 9);
   }
   if (!grad_sumsq_out) return tab_unpack.launch(grad32, grad16, s);
+  // the partials / ticket scratch are sized and zeroed when the output is registered (dfh_unet_grad_sumsq); the partial buffer only
+  // grows here if the un-pack table does (more gradients requested than at registration) -- behind a sync of the stream that may still
+  // read the old one, never on the steady-state path
   if (tab_unpack.blocks > sq_cap) {
-    if (sq_partials) (void)hipFree(sq_partials);
+    if (sq_partials) { (void)hipStreamSynchronize(s); (void)hipFree(sq_partials); }
     sq_partials = nullptr; sq_cap = 0;
-    if (hipMalloc((void**)&sq_partials, (size_t)tab_unpack.blocks * sizeof(float)) != hipSuccess) { dfh::set_error("hipMalloc of the norm partials failed"); return -1; }
-    sq_cap = tab_unpack.blocks;
+    const size_t want = std::max<size_t>(tab_unpack.blocks, 4096);
+    if (hipMalloc((void**)&sq_partials, want * sizeof(float)) != hipSuccess) { dfh::set_error("hipMalloc of the norm partials failed"); return -1; }
+    sq_cap = want;
   }
   if (!sq_scratch) {
-    if (hipMalloc((void**)&sq_scratch, 257 * sizeof(float)) != hipSuccess || hipMemset(sq_scratch, 0, 257 * sizeof(float)) != hipSuccess) {
+    // stream-ordered zeroing: the ticket counter must be zero before table_sq_reduce_kernel on s touches it (a synchronous hipMemset on the
+    // NULL stream is not ordered against a non-blocking stream)
+    if (hipMalloc((void**)&sq_scratch, 257 * sizeof(float)) != hipSuccess || hipMemsetAsync(sq_scratch, 0, 257 * sizeof(float), s) != hipSuccess) {
       dfh::set_error("hipMalloc of the norm scratch failed"); return -1;
     }
   }
@@ -866,7 +872,18 @@ int dfh_unet_pack_train(dfh_unet* u, const float* const* master_params, int coun
 
 int dfh_unet_grad_sumsq(dfh_unet* u, float* out) {
   DFH_REQUIRE(u, "null argument");
-  u->grad_sumsq_out = out;
+  u->grad_sumsq_out = out;          // null un-registers: the un-pack then writes no norm (and keeps no pointer into caller memory)
+  if (out && !u->sq_scratch) {      // ticket counter + block partials: allocated and zeroed HERE, outside any step
+    if (hipMalloc((void**)&u->sq_scratch, 257 * sizeof(float)) != hipSuccess || hipMemset(u->sq_scratch, 0, 257 * sizeof(float)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
+      dfh::set_error("hipMalloc of the norm scratch failed"); return -1;
+    }
+  }
+  if (out && !u->sq_partials) {
+    const size_t want = 1 << 16;    // blocks of the un-pack table of the SD-1.5 walk: ~21 k; the step re-checks
+    if (hipMalloc((void**)&u->sq_partials, want * sizeof(float)) != hipSuccess) { dfh::set_error("hipMalloc of the norm partials failed"); return -1; }
+    u->sq_cap = want;
+  }
   return 0;
 }
 

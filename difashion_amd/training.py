@@ -435,7 +435,10 @@ def train_step(unet, fashion_encoder, scheduler, optimizer: FusedAdamW, *, lr_sc
     from .pipeline import train_forward
     loss = train_forward(unet, fashion_encoder, scheduler, **batch)
     loss.backward()
-    wire = getattr(unet, "grad_wire_dtype", "fp32")       # "bf16": half the bytes per xGMI link, fp32 accumulation
+    # the U-Net's backward left sum(g^2) of its gradients behind its un-pack; read its validity NOW, before the exchange of the ranges
+    # outside the U-Net edits other slices of the shared flat gradient buffer (views share one version counter)
+    sumsq_valid = bool(getattr(unet, "grad_sumsq_valid", False))
+    wire = getattr(unet, "grad_wire_dtype", "fp32")       # "bf16" (opt-in): half the bytes per xGMI link, fp32 accumulation
     if getattr(unet, "grads_synced", False):
         # the U-Net averaged its gradients inside backward (overlapped with the walk): reduce what lies outside it
         for lo, hi in optimizer.ranges_excluding(unet):
@@ -449,7 +452,7 @@ def train_step(unet, fashion_encoder, scheduler, optimizer: FusedAdamW, *, lr_sc
     # the U-Net's backward left sum(g^2) of its gradients behind its un-pack: valid if nothing wrote them since (they were averaged over the
     # ranks INSIDE the backward, or there is nothing to average)
     pres = None
-    if getattr(unet, "grad_sumsq_valid", False) and (getattr(unet, "grads_synced", False) or not _dist.active()):
+    if sumsq_valid and (getattr(unet, "grads_synced", False) or not _dist.active()):
         pres = (list(unet.parameters()), unet._grad_sumsq)
     unet.grad_sumsq_valid = False
     optimizer.step(ema=ema_unet if fuse_ema else None, presummed=pres)

@@ -331,7 +331,8 @@ class UNet2DConditionModel(nn.Module):
         self.grad_sumsq_valid = False
         if os.environ.get("DFH_TRAIN_UNPACK_NORM", "1") != "0":
             self._grad_sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
-            _lib.call("dfh_unet_grad_sumsq", ctx, _lib.ptr(self._grad_sumsq))
+        # ALWAYS (re-)registered, null included: the native side must never keep a pointer into a tensor this module has dropped
+        _lib.call("dfh_unet_grad_sumsq", ctx, _lib.ptr(self._grad_sumsq) if self._grad_sumsq is not None else None)
 
     def _signature(self, params):
         return tuple((p.data_ptr(), p._version) for p in params) + (_lib.weight_epoch(),)
@@ -476,19 +477,45 @@ class UNet2DConditionModel(nn.Module):
             _lib.call("dfh_unet_backward", self._ctx, _lib.ptr(d_out), _lib.ptr(d_sample) if need_dsample else None, arr,
                       len(plist), overwrite, _lib.stream_ptr())
         # sum(g^2) of the gradients as they now stand (valid until something else writes them; consumed by training.train_step)
-        self.grad_sumsq_valid = self._grad_sumsq is not None and all(p.requires_grad and p.grad is not None for p in plist)
+        ok = self._grad_sumsq is not None and all(p.requires_grad and p.grad is not None for p in plist)
+        self.grad_sumsq_valid = ok
+        if ok:                            # validity is CHECKABLE: any in-place edit of a gradient (un-scaling, a manual clip) bumps its version
+            self._grad_sumsq_stamp = tuple((p.grad.data_ptr(), p.grad._version) for p in plist)
         return d_sample
 
     # data-parallel: gradients averaged over the ranks INSIDE backward (DDP semantics; set False around the non-final
     # micro-batches of a gradient-accumulation step, like DDP.no_sync(), and reduce once with dist.all_reduce_gradients)
     sync_grads_in_backward = True
     grads_synced = False
-    grad_sumsq_valid = False
     _grad_sumsq = None
+    _grad_sumsq_ok = False
+    _grad_sumsq_stamp = None
+
+    @property
+    def grad_sumsq_valid(self) -> bool:
+        """True while ``_grad_sumsq`` (left behind by the backward's gradient un-pack) still describes ``.grad`` of every parameter:
+        set by the backward, and withdrawn as soon as any gradient tensor was replaced or edited in place since (its ``_version`` /
+        ``data_ptr`` moved: loss-scale un-scaling, ``clip_grad_norm_``, ``grad.mul_``) -- the optimizer then sums the squares itself."""
+        if not self._grad_sumsq_ok or self._grad_sumsq is None or self._grad_sumsq_stamp is None:
+            return False
+        named = dict(self.named_parameters())
+        plist = [named[n] for n in self._names]
+        if len(plist) != len(self._grad_sumsq_stamp):
+            return False
+        return all(p.grad is not None and (p.grad.data_ptr(), p.grad._version) == st for p, st in zip(plist, self._grad_sumsq_stamp))
+
+    @grad_sumsq_valid.setter
+    def grad_sumsq_valid(self, v: bool):
+        self._grad_sumsq_ok = bool(v)
+        if not v:
+            self._grad_sumsq_stamp = None
+
     grad_bucket_bytes = 256 << 20         # few, large buckets: xGMI rings are per-link bound, not latency bound
-    # wire format of the gradient exchange: "bf16" (default: half the bytes per xGMI link, fp32 accumulation in rank order,
-    # dist.exchange_bf16) or "fp32" (one RCCL all-reduce per range).  Nothing is exchanged in a single-process run.
-    grad_wire_dtype = "bf16"
+    # wire format of the gradient exchange: "fp32" (default: one RCCL all-reduce per range -- what the reference's DDP does,
+    # train.py:611,699) or "bf16" (EXPLICIT opt-in: half the bytes per xGMI link, fp32 accumulation in rank order, dist.exchange_bf16;
+    # every gradient is rounded to bf16 on the wire -- tests/rccl_single_rank_worker.py measures the two-step parameter update moving
+    # by 3.2e-2 relative under it).  Nothing is exchanged in a single-process run.
+    grad_wire_dtype = "fp32"
     measure_comm = False                  # record how long the compute stream waits for the gradient exchange (bench.py --mode train)
     _comm_events = None
 

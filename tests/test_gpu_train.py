@@ -530,6 +530,12 @@ def test_unpack_leaves_the_gradient_norm_and_the_optimizer_uses_it():
     opt.zero_grad(lazy_modules=(unet,))
     da.train_step(unet, enc, sched, opt, **kw)
     assert not unet.grad_sumsq_valid and float(opt.grad_norm()) > 0
+    # validity is checked, not trusted: an in-place edit of any gradient between backward and step (loss-scale un-scaling, a manual
+    # clip) withdraws it, and the optimizer then sums the squares itself
+    train_forward(unet, enc, sched, **kw).backward()
+    assert unet.grad_sumsq_valid
+    next(iter(unet.parameters())).grad.mul_(0.5)
+    assert not unet.grad_sumsq_valid
 
 
 def test_segmented_backward_equals_the_monolithic_one():

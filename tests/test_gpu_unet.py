@@ -356,6 +356,8 @@ def test_fp8_linears_vs_oracle(name, cfg):
         y16b = m(x.to(DEV), t, e.to(DEV)).sample
     e16, e8, d = rel_err(y16.cpu(), ref), rel_err(y8.cpu(), ref), rel_err(y8, y16)
     print(name, f"bf16 vs oracle {e16:.2e}, fp8 vs oracle {e8:.2e}, fp8 vs bf16 {d:.2e}")
+    # fp8-vs-bf16 spread measured with all nine linears per block in e4m3 (round 4, gpurun d_tests.log): tiny 4.74e-2, tiny_sd2 4.63e-2
+    # (3.1e-2 / 3.0e-2 with the round-3 set of four) -- hence 5.5e-2 here, not the 5e-2 of the four-linear docstring above
     assert e8 <= 6e-2 and d <= 5.5e-2 and d > 0.0
     assert torch.equal(y16, y16b)
 

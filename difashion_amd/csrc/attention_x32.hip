@@ -77,7 +77,13 @@ template <int D, int QB, int MINW, bool PROF = false>
 __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs a) {
   constexpr int NBUF = 2;                                  // K / V^T tile buffers in LDS
   using G = X32Geom<D>;
-  constexpr int KS = G::KS, DB = G::DB, DCH = G::DCH, NCH = G::NCH, KROW = G::KROW, NKI = G::NKI, NVI = G::NVI;
+  constexpr int KS = G::KS, DCH = G::DCH, NCH = G::NCH, KROW = G::KROW, NKI = G::NKI, NVI = G::NVI;
+  // LSUM (head dims that are whole 32-row blocks of O^T, d = 64: SD-2-base): the ones row of V^T would open a block of its own -- a third
+  // of the P.V MFMAs and 16 accumulator registers per query block for ONE useful row (the instantiation spilled 13 VGPRs).  The softmax
+  // denominator is summed on the VALU instead: one v_dot2_f32_bf16 per packed pair of probabilities against (1, 1), i.e. the sum of the
+  // ROUNDED probabilities the MFMA multiplies, exactly what the ones row delivers; each lane half sums the keys it holds.
+  constexpr bool LSUM = D % 32 == 0;
+  constexpr int DB = LSUM ? D / 32 : G::DB;
   constexpr int WQ = QB * 32;                              // queries per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -217,6 +223,17 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
 
   f32x16_t o[DB][QB];
   float m_run[QB];
+  float l_acc[QB];                                           // LSUM: this lane half's part of the softmax denominator
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v_t;
+  auto den = [&](int qb) -> float {                          // the denominator as this lane sees it (the caller combines the halves)
+    if constexpr (LSUM) return l_acc[qb];
+    else return o[D / 32][qb][G::L_REG];
+  };
+  auto den_total = [&](int qb) -> float {
+    const float lv = den(qb), lo = lane_xor32(lv);
+    if constexpr (LSUM) return lv + lo;                      // the two halves hold different keys of the query
+    else return hi == G::L_HI ? lv : lo;                     // lanes of half L_HI hold it; the other half holds a zero row of O^T
+  };
   const int ntiles = (a.Nk + KVT - 1) / KVT;
   const int tail_valid = a.Nk - (ntiles - 1) * KVT;          // valid keys of the last tile (KVT when Nk % 64 == 0)
   const int nfast = a.Nk / KVT - 1;                          // tiles whose successor is a full tile
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
         for (int r = 0; r < 16; ++r) o[db][qb][r] = 0.f;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      m_run[qb] = 0.f;
+      m_run[qb] = 0.f; l_acc[qb] = 0.f;
       if (hi == G::PAD_HI) qf[qb][G::PAD_KS].x = pack2bf(0.0f, MASK_Q);
     }
     bool poison = false;
@@ -324,6 +341,7 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
               for (int db = 0; db < DB; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[db][qb][r] *= alpha;
+              l_acc[qb] *= alpha;
             }
             if (hi == G::PAD_HI) qf[qb][G::PAD_KS].x = pack2bf(-m_new, MASK_Q);
           }
@@ -336,8 +354,12 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-          for (int r = 0; r < 16; r += 2)
+          for (int r = 0; r < 16; r += 2) {
             pw[kb][qb][r >> 1] = pack2bf(__builtin_amdgcn_exp2f(s[kb][qb][r]), __builtin_amdgcn_exp2f(s[kb][qb][r + 1]));
+            if constexpr (LSUM)
+              l_acc[qb] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v_t, pw[kb][qb][r >> 1]), __builtin_bit_cast(bf16x2v_t, 0x3f803f80u),
+                                                          l_acc[qb], false);
+          }
       mark(2);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -363,15 +385,13 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
         bool big = false;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
-          const float lv = o[D / 32][qb][G::L_REG];
+          const float lv = den(qb);
           big |= !(lv <= 16777216.0f);               // 2^24; also true for NaN
         }
         if (__any(big)) {
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb) {
-            const float lv = o[D / 32][qb][G::L_REG];
-            const float lo = lane_xor32(lv);
-            const float l = hi == G::L_HI ? lv : lo;
+            const float l = den_total(qb);
             poison |= !(l < 1.2676506e30f);          // 2^100: an exp may already have overflowed
             // exponent of l as an integer-valued float, kept a multiple of the bf16 spacing of the new m
             float m_new = m_run[qb] + (l > 2.0f ? floorf(__builtin_amdgcn_logf(l)) : 0.0f);      // v_log_f32 = log2
@@ -383,6 +403,7 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
             for (int db = 0; db < DB; ++db)
 #pragma unroll
               for (int r = 0; r < 16; ++r) o[db][qb][r] *= alpha;
+            l_acc[qb] *= alpha;
             if (hi == G::PAD_HI) qf[qb][G::PAD_KS].x = pack2bf(-m_new, MASK_Q);
           }
         }
@@ -418,9 +439,7 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
   const float qmul = attn_qmul(a, b);
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    const float lv = o[D / 32][qb][G::L_REG];
-    const float lo = lane_xor32(lv);
-    const float l = hi == G::L_HI ? lv : lo;
+    const float l = den_total(qb);
     const float inv = qmul / l;
     const int q = q0 + qb * 32 + ql;
     if (q >= a.Nq) continue;

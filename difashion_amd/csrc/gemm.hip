@@ -48,7 +48,10 @@ template <int BM, int BN, int WM, int WN, int NSTAGE, bool LEAN = false, bool WE
 // second launch-bound = waves per SIMD the register allocation must leave room for: the eight-wave 128-row tiles run TWO workgroups
 // per CU (4 waves per SIMD, <= 128 VGPRs); without the bound the allocator settles at 130 and silently halves the occupancy
 // (+35 % on every 32x32 / 16x16-level conv, measured)
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) void gemm_bf16_kernel(const GemmArgs a) {
+// (only where TWO workgroups fit the CU's LDS: the 4-stage ring of the same tile is 144 KB = one workgroup per CU = 2 waves per SIMD,
+// and under the 128-VGPR bound it spilled 20 registers into its k-loop for an occupancy it can never have)
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128 && 2 * NSTAGE * (BM + BN) * BK * 2 <= 160 * 1024) ? 4 : (WM * WN == 8 ? 2 : 1))
+void gemm_bf16_kernel(const GemmArgs a) {
   constexpr int NWV = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;       // per-wave output tile
   constexpr int FM = TM / 16, FN = TN / 16;       // 16x16 fragments per wave
@@ -206,53 +209,59 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8 && BM == 128) ? 4 : 1) v
     }
   };
 
-  // LEAN staging: per-piece source pointers (the zero page with a zero stride for rows beyond M / N).  One or two plain segments of
-  // whole 64-channel slices: the W columns of the two are contiguous, the A pointers are re-based once, where the first segment ends
-  // (the [GEGLU output | h2] operand of the folded ff.net.2 . proj_out linear)
-  const bf16_t* lp_a[IA]; const bf16_t* lp_w[IB];
-  unsigned ls_a[IA], ls_w[IB];
-  int lean_left = 0x7fffffff;                        // k-steps left in the segment the A pointers walk
+  // LEAN staging: per-piece 32-bit BYTE OFFSETS from two block-uniform (SGPR) bases -- the A segment being walked and the W plane -- so a
+  // piece costs one VGPR, not a 64-bit pointer plus a stride (the pointer form spilled 12-20 VGPRs of the eight-wave 128 x 160 tile into
+  // its k-loop under the 128-VGPR bound of two workgroups per CU).  Rows beyond M / N are CLAMPED to the last valid row instead of
+  // being pointed at the zero page: they produce finite garbage in accumulator rows / columns that no epilogue stores (every store
+  // path tests m < M and n < N; statistics are only written for rows < M on whole column tiles).  The launcher checks that both operands
+  // span less than 4 GB.  One or two plain segments of whole 64-channel slices: the W columns of the two are contiguous, the A base is
+  // switched once, where the first segment ends (the [GEGLU output | h2] operand of the folded ff.net.2 . proj_out linear)
+  unsigned lo_a[IA], lo_w[IB];
+  const bf16_t* abase = psrc0;
+  unsigned a_step = BK * 2, w_step = BK * 2;         // bytes per k-step (uniform)
+  int lean_left = 0x7fffffff;                        // k-steps left in the segment the A offsets walk
   if (LEAN) {
     const int steps0 = a.p_c[0] / BK;
     const bool in0 = ks_begin < steps0 || a.nplain < 2;
     const unsigned ka = (unsigned)(in0 ? ks_begin : ks_begin - steps0) * BK + (unsigned)sslot * 8;
     const unsigned k0 = (unsigned)ks_begin * BK + (unsigned)sslot * 8;
     if (in0 && a.nplain == 2) lean_left = steps0 - ks_begin;
+    abase = in0 ? psrc0 : psrc1;
+    const unsigned pc = (unsigned)(in0 ? a.p_c[0] : a.p_c[1]);
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-      const bool ok = a_pix[i] >= 0;
-      lp_a[i] = ok ? (in0 ? psrc0 + ((size_t)(unsigned)a_pix[i] * (unsigned)a.p_c[0] + ka)
-                          : psrc1 + ((size_t)(unsigned)a_pix[i] * (unsigned)a.p_c[1] + ka)) : a.zero;
-      ls_a[i] = ok ? BK : 0;
+      const unsigned row = (unsigned)min(m0 + (i * NWV + wave) * 8 + srow, a.M - 1);
+      lo_a[i] = (row * pc + ka) * 2u;
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-      const bool ok = w_row[i] >= 0;
-      lp_w[i] = ok ? Wb + ((size_t)(unsigned)w_row[i] + k0) : a.zero;
-      ls_w[i] = ok ? BK : 0;
-      if (a.w_blocked && ok) {                         // [N / 16][ldw / 64][16][64]: the next k-step of a row is 2 KB further on
-        const int n = n0 + (i * NWV + wave) * 8 + srow;
-        lp_w[i] = Wb + (((size_t)(n >> 4) * (unsigned)(a.ldw >> 6) + (unsigned)ks_begin) * 1024u + (unsigned)((n & 15) * 64 + sslot * 8));
-        ls_w[i] = 1024;
-      }
+      const int n = min(n0 + (i * NWV + wave) * 8 + srow, a.N - 1);
+      lo_w[i] = ((unsigned)n * (unsigned)a.ldw + k0) * 2u;
+      if (a.w_blocked)                                 // [N / 16][ldw / 64][16][64]: the next k-step of a row is 2 KB further on
+        lo_w[i] = (((unsigned)(n >> 4) * (unsigned)(a.ldw >> 6) + (unsigned)ks_begin) * 1024u + (unsigned)((n & 15) * 64 + sslot * 8)) * 2u;
     }
+    if (a.w_blocked) w_step = 2048;
   }
+  asm volatile("" : "+s"(abase));
   auto issue_lean = [&](int buf) {
     unsigned char* As = smem + buf * STAGE + wave * 1024;
     unsigned char* Bs = As + A_BYTES;
     if (lean_left == 0) {                            // block-uniform: the second segment starts here
+      abase = psrc1;
 #pragma unroll
-      for (int i = 0; i < IA; ++i)
-        if (a_pix[i] >= 0) lp_a[i] = psrc1 + ((size_t)(unsigned)a_pix[i] * (unsigned)a.p_c[1] + (unsigned)sslot * 8);
+      for (int i = 0; i < IA; ++i) {
+        const unsigned row = (unsigned)min(m0 + (i * NWV + wave) * 8 + srow, a.M - 1);
+        lo_a[i] = (row * (unsigned)a.p_c[1] + (unsigned)sslot * 8) * 2u;
+      }
       lean_left = 0x7fffffff;
     }
     --lean_left;
 #pragma unroll
-    for (int i = 0; i < IA; ++i) { glds(lp_a[i], As + i * NWV * 1024); lp_a[i] += ls_a[i]; }
+    for (int i = 0; i < IA; ++i) { glds((const bf16_t*)((const char*)abase + lo_a[i]), As + i * NWV * 1024); lo_a[i] += a_step; }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
       if (i * NWV + wave >= PB) continue;             // wave-uniform
-      glds(lp_w[i], Bs + i * NWV * 1024); lp_w[i] += ls_w[i];
+      glds((const bf16_t*)((const char*)Wb + lo_w[i]), Bs + i * NWV * 1024); lo_w[i] += w_step;
     }
   };
 
@@ -767,6 +776,9 @@ bool lean_plain(const GemmArgs& a) {
   // 0-3 % at two workgroups per CU -- the LDS-DMA issue itself (~100 cycles per 1-KB piece), not its address arithmetic,
   // is what paces the loop
   if (a.ntaps != 0 || a.nplain < 1 || a.p_c[0] % BK != 0 || a.p_c[0] <= 0) return false;
+  // 32-bit byte offsets from the segment / weight-plane bases inside the kernel
+  const double amax = (double)a.M * std::max(a.p_c[0], a.nplain > 1 ? a.p_c[1] : 0) * 2.0, wmax = (double)a.N * a.ldw * 2.0;
+  if (amax >= 4.0e9 || wmax >= 4.0e9) return false;
   return a.nplain == 1 || (a.p_c[1] % BK == 0 && a.p_c[1] > 0);
 }
 

@@ -70,27 +70,27 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
   const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
   const int tile = xcd_remap(blockIdx.x, ntm * ntn);
   const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+  int m0_ = m0, n0_ = n0;
   const int nk = a.K / KB8;
   const bool hi_wave = wave < PW_REM;
 
   // ---- staging: piece p = i * 4 + wave holds tile rows p*16 + lane/4; slot s of row r holds source chunk s ^ ((r >> 2) & 3)
   const int srow = lane >> 2;
   const int schunk = (lane & 3) ^ ((srow >> 2) & 3);
-  const uint8_t* lp_a[IA]; const uint8_t* lp_w[IW];
-  unsigned ls_a[IA], ls_w[IW];
+  // 32-bit byte offsets from the two SGPR bases (rows beyond M / N clamped to the last valid row: their accumulator rows / columns are
+  // never stored) -- as 64-bit pointers + strides the seven pieces cost 21 VGPRs and the 256 x 160 transposed-output tile spilled
+  unsigned lo_a[IA], lo_w[IW];
+  const uint8_t* Ab = a.A; const uint8_t* Wb8 = a.W;
+  asm volatile("" : "+s"(Ab), "+s"(Wb8));
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
-    const int m = m0 + (i * 4 + wave) * 16 + srow;
-    const bool ok = m < a.M;
-    lp_a[i] = ok ? a.A + ((size_t)m * a.lda + schunk * 16) : a.zero;
-    ls_a[i] = ok ? KB8 : 0;
+    const int m = min(m0 + (i * 4 + wave) * 16 + srow, a.M - 1);
+    lo_a[i] = (unsigned)m * (unsigned)a.lda + (unsigned)schunk * 16u;
   }
 #pragma unroll
   for (int i = 0; i < IW; ++i) {
-    const int n = n0 + (i * 4 + wave) * 16 + srow;
-    const bool ok = n < a.N && i * 4 + wave < PW;
-    lp_w[i] = ok ? a.W + ((size_t)n * a.K + schunk * 16) : a.zero;
-    ls_w[i] = ok ? KB8 : 0;
+    const int n = min(n0 + (i * 4 + wave) * 16 + srow, a.N - 1);
+    lo_w[i] = (unsigned)n * (unsigned)a.K + (unsigned)schunk * 16u;
   }
   // MX scales: lanes 0 .. 16 PB - 1 of every wave fetch 4 bytes each = rows 4 j .. 4 j + 3 of the wave's PB * 32 rows, k-half lane / (8 PB)
   // (sx is [K / 32][M]: the bytes of one k-block are contiguous over the rows); one LDS-DMA instruction per wave and k-step
@@ -108,11 +108,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
     unsigned char* As = smem + buf * STAGE + wave * 1024;
     unsigned char* Ws = As + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < IA; ++i) { glds(lp_a[i], As + i * 4096); lp_a[i] += ls_a[i]; }
+    for (int i = 0; i < IA; ++i) { glds(Ab + lo_a[i], As + i * 4096); lo_a[i] += KB8; }
 #pragma unroll
     for (int i = 0; i < IW; ++i) {
       if (i * 4 + wave >= PW) continue;                      // wave-uniform
-      glds(lp_w[i], Ws + i * 4096); lp_w[i] += ls_w[i];
+      glds(Wb8 + lo_w[i], Ws + i * 4096); lo_w[i] += KB8;
     }
     if (MX) {
       if (s_lane)
@@ -185,6 +185,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
   // ---------------------------------------------------------------- epilogue
   // lane (pixel ql, half kh) holds of block (ci, pj): channels ci*32 + 8 (r >> 2) + 4 kh + (r & 3), r = 0..15
   __syncthreads();                                           // pipeline buffers free: per-wave staging regions below
+  // the tile origin is re-read through an opaque copy: everything the epilogue derives from it (row / column indices, output addresses,
+  // the per-row activation scale) is then computed HERE -- hoisted above the k-loop those values stayed live across it beside the 160
+  // accumulator registers and were spilled (13 VGPRs of the transposed-output tile)
+  asm volatile("" : "+s"(m0_), "+s"(n0_));
   const bool geglu = a.act == ACT_GEGLU;
   const bool out8 = a.out_mode == OUT_FP8_MX;
   constexpr int RS = BN * 2 + 16;                            // byte stride of a wave's staged 32-row block (bf16 rows; e4m3 rows use half of it)
@@ -195,39 +199,44 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
   float* swl = (float*)(smem + 4 * 32 * RS);
   float* bl = swl + BN;
   for (int c = tid; c < BN; c += 256) {
-    const int n = n0 + c;
+    const int n = n0_ + c;
     swl[c] = n < a.N ? a.sW[n] : 0.f;
     bl[c] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
   }
   __syncthreads();
 #pragma unroll
   for (int pj = 0; pj < PB; ++pj) {
-    const int m = m0 + wave * PB * 32 + pj * 32 + ql;
+    const int m = m0_ + wave * PB * 32 + pj * 32 + ql;
     const bool m_ok = m < a.M;
     const float sa = m_ok ? (a.sA ? a.sA[m / a.sa_div] : 1.0f) * a.sa_mul : 0.f;
     if constexpr (TOUT) {                                    // attention V^T: out[b][n][mm]
       float am = 0.f;
       const int b = m_ok ? m / a.rows_per_b : 0, mm = m - b * a.rows_per_b;
-      const int m_first = m0 + wave * PB * 32 + pj * 32;
+      const int m_first = m0_ + wave * PB * 32 + pj * 32;
       // whole 32-row blocks inside one image: the block is staged TRANSPOSED through the wave's LDS region and leaves as 16-byte
       // pieces along the pixel axis (10 store instructions per lane instead of 80 two-byte ones)
-      if (a.rows_per_b % 32 == 0 && m_first + 32 <= a.M && a.ld_out % 8 == 0 && n0 + BN <= a.N) {
+      if (a.rows_per_b % 32 == 0 && m_first + 32 <= a.M && a.ld_out % 8 == 0 && n0_ + BN <= a.N) {
 #pragma unroll
-        for (int ci = 0; ci < NCI; ++ci)
+        for (int ci = 0; ci < NCI; ++ci) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int c = ci * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
-            float v = acc[ci][pj][r] * sa * swl[c];
-            if (a.bias) v += bl[c];
-            const bf16_t o = f2bf(v);
-            am = fmaxf(am, fabsf(bf2f(o)));
-            *(bf16_t*)(stage + c * 64 + ql * 2) = o;         // [BN columns][32 pixels]
+          for (int g = 0; g < 4; ++g) {                      // four consecutive channels per (block, g): one 16-byte read of the scale / bias slices
+            const int c = ci * 32 + 8 * g + 4 * kh;
+            const float4 sw4 = *(const float4*)(swl + c), b4 = *(const float4*)(bl + c);
+            const float sw[4] = {sw4.x, sw4.y, sw4.z, sw4.w}, bb4[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const bf16_t o = f2bf(fmaf(acc[ci][pj][4 * g + j] * sa, sw[j], bb4[j]));      // bl is zero-filled without a bias
+              am = fmaxf(am, fabsf(bf2f(o)));
+              *(bf16_t*)(stage + (c + j) * 64 + ql * 2) = o;  // [BN columns][32 pixels]
+            }
           }
+          asm volatile("" ::: "memory");                      // one block's reads and stores at a time: no 80-deep hoist of the slice reads
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int bb = m_first / a.rows_per_b, mm0 = m_first - bb * a.rows_per_b;
         for (int q = lane; q < BN * 4; q += 64) {
           const int c = q >> 2, part = q & 3;
-          *(uint4*)((bf16_t*)a.out + ((long)bb * a.N + n0 + c) * a.ld_out + mm0 + part * 8) = *(const uint4*)(stage + c * 64 + part * 16);
+          *(uint4*)((bf16_t*)a.out + ((long)bb * a.N + n0_ + c) * a.ld_out + mm0 + part * 8) = *(const uint4*)(stage + c * 64 + part * 16);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       } else
@@ -236,10 +245,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
         for (int ci = 0; ci < NCI; ++ci)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int n = n0 + ci * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+            const int n = n0_ + ci * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
             if (n < a.N) {
-              float v = acc[ci][pj][r] * sa * swl[n - n0];
-              if (a.bias) v += bl[n - n0];
+              float v = acc[ci][pj][r] * sa * swl[n - n0_];
+              if (a.bias) v += bl[n - n0_];
               const bf16_t o = f2bf(v);
               am = fmaxf(am, fabsf(bf2f(o)));
               ((bf16_t*)a.out)[((long)b * a.N + n) * a.ld_out + mm] = o;
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
             for (int g = 0; g < 2; ++g)
               *(unsigned*)(stage + ql * RS + c * 32 + h * 16 + 8 * g + 4 * kh) =
                   pack4_fp8(hv[2 * c + h][4 * g] * inv, hv[2 * c + h][4 * g + 1] * inv, hv[2 * c + h][4 * g + 2] * inv, hv[2 * c + h][4 * g + 3] * inv);
-          const int kb = (n0 >> 6) + c;                      // 32-unit block index along the hidden axis
+          const int kb = (n0_ >> 6) + c;                      // 32-unit block index along the hidden axis
           if (kh == 0 && m_ok && (kb << 6) < a.N) a.out_sx[(size_t)kb * a.M + m] = (uint8_t)e;
         }
       }
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
         float v[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int col = ci * 32 + 8 * g + 4 * kh, n = n0 + col;
+          const int col = ci * 32 + 8 * g + 4 * kh, n = n0_ + col;
           const float4 sw4 = *(const float4*)(swl + col), b4 = *(const float4*)(bl + col);
           v[4 * g] = acc[ci][pj][4 * g] * sa * sw4.x + b4.x; v[4 * g + 1] = acc[ci][pj][4 * g + 1] * sa * sw4.y + b4.y;
           v[4 * g + 2] = acc[ci][pj][4 * g + 2] * sa * sw4.z + b4.z; v[4 * g + 3] = acc[ci][pj][4 * g + 3] * sa * sw4.w + b4.w;
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
 #pragma unroll
           for (int g = 0; g < 4; ++g)
             *(unsigned*)(stage + ql * RS + ci * 32 + 8 * g + 4 * kh) = pack4_fp8(v[4 * g] * inv, v[4 * g + 1] * inv, v[4 * g + 2] * inv, v[4 * g + 3] * inv);
-          const int kb = (n0 >> 5) + ci;
+          const int kb = (n0_ >> 5) + ci;
           if (kh == 0 && m_ok && (kb << 5) < a.N) a.out_sx[(size_t)kb * a.M + m] = (uint8_t)e;
         }
       }
@@ -347,12 +356,12 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
     // the wave's own 32-row block -> full rows, 16 bytes per lane (LDS accesses of one wave complete in order)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int ocols = geglu ? BN / 2 : BN;                   // output columns of this tile
-    const int obase = geglu ? (n0 >> 1) : n0, olim = geglu ? (a.N >> 1) : a.N;
+    const int obase = geglu ? (n0_ >> 1) : n0_, olim = geglu ? (a.N >> 1) : a.N;
     if (!out8) {
       const int cpr = ocols / 8;
       for (int c = lane; c < 32 * cpr; c += 64) {
         const int row = c / cpr, cc = c - row * cpr;
-        const int mr = m0 + wave * PB * 32 + pj * 32 + row, oc = obase + cc * 8;
+        const int mr = m0_ + wave * PB * 32 + pj * 32 + row, oc = obase + cc * 8;
         if (mr < a.M && oc < olim)
           *(uint4*)((bf16_t*)a.out + (long)mr * a.ld_out + oc) = *(const uint4*)(stage + row * RS + cc * 16);
       }
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(const Fp8GemmArgs a) {
       const int cpr = ocols / 16;
       for (int c = lane; c < 32 * cpr; c += 64) {
         const int row = c / cpr, cc = c - row * cpr;
-        const int mr = m0 + wave * PB * 32 + pj * 32 + row, oc = obase + cc * 16;
+        const int mr = m0_ + wave * PB * 32 + pj * 32 + row, oc = obase + cc * 16;
         if (mr < a.M && oc < olim)
           *(uint4*)((uint8_t*)a.out + (long)mr * a.ld_out + oc) = *(const uint4*)(stage + row * RS + cc * 16);
       }
@@ -537,6 +546,7 @@ int gemm_fp8_launch(Fp8GemmArgs a, hipStream_t stream) {
   DFH_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "empty fp8 GEMM");
   DFH_REQUIRE(a.K % KB8 == 0 && a.lda % 16 == 0 && a.lda >= a.K, "fp8 GEMM: K must be a multiple of 64, the row stride of A a multiple of 16");
   DFH_REQUIRE(a.N % 8 == 0, "fp8 GEMM: N must be a multiple of 8");
+  DFH_REQUIRE((double)a.M * a.lda < 4.0e9 && (double)a.N * a.K < 4.0e9, "fp8 GEMM: operands must be smaller than 4 GB (32-bit staging offsets)");
   DFH_REQUIRE(a.A && a.W && a.sW && a.zero && a.out, "fp8 GEMM: null operand");
   DFH_REQUIRE(a.out_mode == OUT_BF16 || a.out_mode == OUT_BF16_T || out8, "fp8 GEMM: bf16, transposed bf16 or e4m3 + E8M0 outputs");
   DFH_REQUIRE(a.act == ACT_NONE || geglu, "fp8 GEMM: no activation or GEGLU");
@@ -558,7 +568,10 @@ int gemm_fp8_launch(Fp8GemmArgs a, hipStream_t stream) {
   const bool big = tiles256 >= 384;
   if (a.out_mode == OUT_BF16_T) {
     DFH_REQUIRE(!mx, "fp8 GEMM: the transposed output takes per-row activation scales (no E8M0 block scales)");
-    if (bn == 160) return big ? launch_fp8<2, 160, false, true>(a, stream) : launch_fp8<1, 160, false, true>(a, stream);
+    // 160-wide transposed tiles always on 128 rows: the 256 x 160 instantiation holds 160 accumulator registers through a transposed
+    // staging epilogue and spilled 8-13 VGPRs whichever way it was written; the V projection is a K = C launch (13 GFLOP) whose time does
+    // not depend on the row tile
+    if (bn == 160) return launch_fp8<1, 160, false, true>(a, stream);
     return big ? launch_fp8<2, 128, false, true>(a, stream) : launch_fp8<1, 128, false, true>(a, stream);
   }
   if (bn == 160) {

@@ -23,16 +23,20 @@ DFH_DEVICE void wide_epilogue(const GemmArgs& a, f32x4_t (&acc)[BM / 2 / 16][BN 
   static_assert((64 * CPR) % (NWV * 64) == 0, "whole chunks per thread");
   // Residual rows are fetched one pass AHEAD (the loads of pass q+1 fly while pass q is rounded and stored): read inside the
   // pass they cost EPI dependent global-load latencies per pass -- 14 of the 37 us of a 65536 x 320 x 320 linear.
+  // ONE register set: chunk e of pass q + 1 is requested at the top of chunk e of pass q, right after that chunk's value has been copied
+  // out -- a second set (all of pass q + 1 requested before pass q is processed) cost 20 more VGPRs next to the 160 accumulator registers
+  // of the 256 x 320 tile and spilled 6-26 of them.
   uint4 rnext[EPI];
+  auto fetch_one = [&](int q, int e) {
+    const int c = tid + e * NWV * 64;
+    const int row = c / CPR, cchunk = c - row * CPR;
+    const int m = m0 + q * 64 + row, n = n0 + cchunk * 8;
+    rnext[e] = make_uint4(0u, 0u, 0u, 0u);
+    if (m < a.M && n < a.N) rnext[e] = *(const uint4*)(a.resid + (long)m * a.ld_res + n);
+  };
   auto fetch_resid = [&](int q) {
 #pragma unroll
-    for (int e = 0; e < EPI; ++e) {
-      const int c = tid + e * NWV * 64;
-      const int row = c / CPR, cchunk = c - row * CPR;
-      const int m = m0 + q * 64 + row, n = n0 + cchunk * 8;
-      rnext[e] = make_uint4(0u, 0u, 0u, 0u);
-      if (m < a.M && n < a.N) rnext[e] = *(const uint4*)(a.resid + (long)m * a.ld_res + n);
-    }
+    for (int e = 0; e < EPI; ++e) fetch_one(q, e);
   };
   const bool has_resid = a.resid != nullptr && a.act != ACT_GEGLU;
   if (has_resid) fetch_resid(0);
@@ -102,15 +106,13 @@ DFH_DEVICE void wide_epilogue(const GemmArgs& a, f32x4_t (&acc)[BM / 2 / 16][BN 
       }
       continue;
     }
-    uint4 rcur[EPI];
-#pragma unroll
-    for (int e = 0; e < EPI; ++e) rcur[e] = rnext[e];
-    if (has_resid && q + 1 < BM / 64) fetch_resid(q + 1);
 #pragma unroll
     for (int e = 0; e < EPI; ++e) {
       const int c = tid + e * NWV * 64;
       const int row = c / CPR, cchunk = c - row * CPR;
       const int m = m0 + q * 64 + row, n = n0 + cchunk * 8;
+      const uint4 rcur = rnext[e];
+      if (has_resid && q + 1 < BM / 64) fetch_one(q + 1, e);
       if (m >= a.M || n >= a.N) continue;
       float v[8];
       {
@@ -144,7 +146,7 @@ DFH_DEVICE void wide_epilogue(const GemmArgs& a, f32x4_t (&acc)[BM / 2 / 16][BN 
       }
       if (has_resid) {
         float f[8];
-        unpack8(rcur[e], f);
+        unpack8(rcur, f);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += f[r];
       }

@@ -360,9 +360,12 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GnArgs a) {
 // of that span (gamma / beta / group index live in registers) and walks pixels; the slab stays in registers as packed bf16
 // (2 VGPRs per unit), the statistics are reduced in a fixed order through LDS (two-pass variance), one read, one write.
 //   threads = PPB pixel lanes x UPPB units per pixel (UPPB = GQ * cpg / 4), thread -> (pp = tid / UPPB, j = tid % UPPB)
-template <int UNITS>
-__global__ __launch_bounds__(1024) void gn_mid_kernel(const GnArgs a, const int gq, const int ppb) {
-  __shared__ float red[1024];
+//   MAXT: largest block the instantiation is launched with.  More than 16 units per thread (64+ VGPRs of slab plus as many load addresses
+//   in flight) do not fit the 128 VGPRs of a 1024-thread block (the 24- / 32-unit variants spilled 22 / 72 registers): those run with at
+//   most 512 threads (256 VGPRs), the launcher picks the geometry accordingly.
+template <int UNITS, int MAXT = 1024>
+__global__ __launch_bounds__(MAXT) void gn_mid_kernel(const GnArgs a, const int gq, const int ppb) {
+  __shared__ float red[MAXT];
   __shared__ float colsum[2][256];
   const int tid = threadIdx.x, b = blockIdx.y;
   const int cpg = a.C / a.G, upp = cpg >> 2, uppb = gq * upp;
@@ -506,7 +509,10 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
         if (a.G % gq || (long)a.B * (a.G / gq) < 128 || gq * upp > 256) continue;
         const int uppb = gq * upp;
         int threads = 256;
-        while (threads < 1024 && (a.HW + threads / uppb - 1) / (threads / uppb) > 24) threads *= 2;
+        auto units_at = [&](int t) { return t / uppb < 1 ? 1 << 30 : (a.HW + t / uppb - 1) / (t / uppb); };
+        while (threads < 1024 && units_at(threads) > 24) threads *= 2;
+        // 1024-thread blocks hold at most 16 units per thread in registers (128 VGPRs); 17..32 units run as 512-thread blocks
+        if (threads == 1024 && units_at(1024) > 16) threads = 512;
         const int ppb = threads / uppb;
         if (ppb < 1) continue;
         const int units = (a.HW + ppb - 1) / ppb;
@@ -517,8 +523,8 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
         if (units <= 4) hipLaunchKernelGGL(gn_mid_kernel<4>, grid, block, 0, stream, a, gq, ppb);
         else if (units <= 8) hipLaunchKernelGGL(gn_mid_kernel<8>, grid, block, 0, stream, a, gq, ppb);
         else if (units <= 16) hipLaunchKernelGGL(gn_mid_kernel<16>, grid, block, 0, stream, a, gq, ppb);
-        else if (units <= 24) hipLaunchKernelGGL(gn_mid_kernel<24>, grid, block, 0, stream, a, gq, ppb);
-        else hipLaunchKernelGGL(gn_mid_kernel<32>, grid, block, 0, stream, a, gq, ppb);
+        else if (units <= 24) hipLaunchKernelGGL((gn_mid_kernel<24, 512>), grid, block, 0, stream, a, gq, ppb);      // threads <= 512 here
+        else hipLaunchKernelGGL((gn_mid_kernel<32, 512>), grid, block, 0, stream, a, gq, ppb);
         return check_launch("gn_mid_kernel");
       }
     }

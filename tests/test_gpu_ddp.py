@@ -69,6 +69,27 @@ def test_bench_launches_its_own_ranks():
     assert rec["rccl_ranks"] == (2 if TWO_GPUS else None)
 
 
+def test_bench_train_mode_launches_its_own_ranks():
+    """`python bench.py --mode train --gpus 2` with NO launcher environment (the training twin of the test above): two fresh ranks, the
+    gradient exchange inside the backward (fp32 wire: the default), one JSON line whose multi-rank fields let a slow rank or an exposed
+    exchange be read off the one record -- per-rank ms_per_step min / max and comm_exposed_ms (max) / comm_exposed_ms_min."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DFH_DIST_BACKEND="nccl" if TWO_GPUS else "gloo", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "2", "--steps", "1", "--warmup", "1", "--outfits", "1",
+           "--no-cpu-baseline", "--no-profile"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    print(out.stdout[-2000:], out.stderr[-2000:])
+    assert out.returncode == 0
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 1 and rec["value"] > 0 and rec["unit"] == "items/s" and rec["grad_wire"] == "fp32"
+    assert rec["comm_exposed_ms"] is not None and rec["comm_exposed_ms_min"] is not None and rec["comm_exposed_ms"] >= rec["comm_exposed_ms_min"] >= 0
+    assert 0 < rec["rank_ms_per_step"]["min"] <= rec["rank_ms_per_step"]["max"] <= rec["ms_per_step"] * 1.05
+    assert rec["collective_backend"] == ("nccl" if TWO_GPUS else "gloo")
+
+
 def test_rccl_branch_runs_in_a_world_of_one():
     """The "nccl" (RCCL) branch of the data-parallel step on the box's one GPU: a process group of ONE rank with
     DFH_DIST_SINGLE_RANK=1 (difashion_amd.dist.active) sends every collective of the step through RCCL on its side stream --

@@ -189,6 +189,9 @@ SIGNATURES = {
     "dfh_quantize_rows_fp8": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
     "dfh_layernorm_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "dfh_gemm_fp8": (_i, [C.POINTER(Fp8GemmDesc), _vp]),
+    "dfh_mlp_fused_image_bytes": (_sz, []),
+    "dfh_mlp_fused_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "dfh_mlp_fused": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _i, _vp]),
     "dfh_groupnorm_fp8": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "dfh_attention_fp8out": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "dfh_amax_slabs": (_i, [_vp, C.c_long, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
@@ -215,7 +218,7 @@ _NO_STATUS = {"dfh_abi_version", "dfh_census_count", "dfh_unet_num_params", "dfh
               "dfh_vae_param_ndim", "dfh_vae_param_dim"}
 
 _lib = None
-ABI_VERSION = 5          # == DFH_ABI_VERSION of include/difashion_hip.h (checked when the library is loaded)
+ABI_VERSION = 6          # == DFH_ABI_VERSION of include/difashion_hip.h (checked when the library is loaded)
 
 
 def build(force: bool = False) -> str:
@@ -237,12 +240,17 @@ def raw():
             raise DfhError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU / PyTorch fallback for the compute path)")
         lib = C.CDLL(LIB_PATH)
+        # DFH_LIB (a same-box A/B probe against ANOTHER build, e.g. last round's): entry points that build does not have are left
+        # unbound and its ABI number is not checked -- the probe only drives calls both builds share.  Never on the product path.
+        probe = bool(os.environ.get("DFH_LIB"))
         for name, (res, args) in SIGNATURES.items():
+            if probe and not hasattr(lib, name):
+                continue
             fn = getattr(lib, name)       # AttributeError here = header/library drift
             fn.restype = res
             fn.argtypes = args
         got = lib.dfh_abi_version()
-        if got != ABI_VERSION:
+        if got != ABI_VERSION and not probe:
             raise DfhError(f"{LIB_PATH} reports ABI {got}, this Python side binds ABI {ABI_VERSION} (include/difashion_hip.h "
                            "DFH_ABI_VERSION): rebuild the library (`python -c 'import __graft_entry__ as g; g.build()'`)")
         _lib = lib

@@ -11,6 +11,7 @@
 #include "dfh_common.h"
 #include "elementwise.h"
 #include "gemm.h"
+#include "mlp_fused.h"
 #include "norm.h"
 #include "wgrad.h"
 #include "bwd_elementwise.h"
@@ -31,7 +32,7 @@ static long g_census[CK_COUNT] = {0};
 void census(int id) { if (id >= 0 && id < CK_COUNT) ++g_census[id]; }
 static const char* const kCensusNames[CK_COUNT] = {"gemm_wide", "gemm_8wave", "gemm_lean", "gemm_other", "gemm_row", "splitk_reduce",
     "splitk_fused", "gstat_written", "gn_pre", "gn_stats", "gn_small", "gn_mid", "layernorm", "ln_folded", "attention_x32", "attention_16",
-    "gemm_fp8", "text_cached", "conv_phase", "conv_wino", "gemm_rows_geglu", "attention_fp8"};
+    "gemm_fp8", "text_cached", "conv_phase", "conv_wino", "gemm_rows_geglu", "attention_fp8", "mlp_fused", "gn_folded"};
 
 struct ProfRec { hipEvent_t e0, e1; int cls; double flops, bytes; };
 static std::vector<ProfRec> g_recs;
@@ -430,6 +431,17 @@ int dfh_gemm_fp8(const dfh_gemm_fp8_desc* d, void* stream) {
   g.resid = (const bf16_t*)d->resid; g.ld_res = d->ld_res; g.act = d->act; g.out = d->out; g.ld_out = d->ld_out; g.out_mode = d->out_mode;
   g.out_sx = (uint8_t*)d->out_sx; g.rows_per_b = d->rows_per_b; g.amax = d->amax; g.zero = (const uint8_t*)d->zero_page;
   return dfh::gemm_fp8_launch(g, (hipStream_t)stream);
+}
+size_t dfh_mlp_fused_image_bytes(void) { return dfh::mlp_fused_image_bytes(); }
+int dfh_mlp_fused_pack(const void* w1, const float* s1, const float* b1, const void* w2p, void* img, void* stream) {
+  return dfh::mlp_pack_launch((const bf16_t*)w1, s1, b1, (const bf16_t*)w2p, img, (hipStream_t)stream);
+}
+int dfh_mlp_fused(const void* x, const void* resid, const void* img, const float* ln_stat, int ln_parts, int ln_cnt, float ln_eps,
+                  const float* bias, void* out, int M, void* stream) {
+  MlpArgs a; std::memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)x; a.resid = (const bf16_t*)resid; a.img = (const unsigned char*)img; a.ln_stat = ln_stat; a.ln_parts = ln_parts;
+  a.ln_cnt = ln_cnt; a.ln_eps = ln_eps; a.bias = bias; a.out = (bf16_t*)out; a.M = M;
+  return dfh::mlp_fused_launch(a, (hipStream_t)stream);
 }
 int dfh_groupnorm_fp8(const void* src, int batch, int HW, int C, int groups, float eps, float q_mul, void* q, float* partial, void* stream) {
   GnArgs a; std::memset(&a, 0, sizeof(a));

@@ -284,6 +284,89 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
       };
       mark(0);
 
+      // ---- four query blocks per wave, ONE wave per SIMD (QB = 4, steady-state tiles): nothing else on the SIMD can fill the matrix pipe
+      //      while this wave runs its exponentials, so the tile is software-pipelined INSIDE the wave, in source order and pinned there
+      //      by scheduling barriers: every MFMA of a product is followed by a slice of the exponentials of the PREVIOUS score block --
+      //      S(kb 0) | S(kb 1) + exp of the first key half of block 0 | P.V(block 0, keys 0-15) + the second half | P.V(block 0, keys
+      //      16-31) + exp(block 1, first half) | P.V(block 1, 0-15) + exp(block 1, second half) | P.V(block 1, 16-31).  An MFMA occupies
+      //      the pipe for 32 cycles after a 4-cycle issue; the VALU instructions behind it issue in its shadow.  Each K / V^T fragment
+      //      read feeds FOUR MFMAs (14 reads per 56 MFMAs; the two-block kernel: 14 per 28).
+      if constexpr (QB == 4 && !PRE) {
+        f32x16_t s[2][QB];
+        uint32_t pw[2][QB][8];
+        // unit u of score block kb: query block u & 3, register pair u >> 2 -- units 0..15 are the keys of the first 16-key MFMA (m2 = 0)
+        auto exp_unit = [&](int kb, int u) {
+          const int qb = u & 3, pi = u >> 2;
+          pw[kb][qb][pi] = pack2bf(__builtin_amdgcn_exp2f(s[kb][qb][2 * pi]), __builtin_amdgcn_exp2f(s[kb][qb][2 * pi + 1]));
+          if constexpr (LSUM)
+            l_acc[qb] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v_t, pw[kb][qb][pi]), __builtin_bit_cast(bf16x2v_t, 0x3f803f80u), l_acc[qb], false);
+        };
+        auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
+        // S of score block kb, with `units` exponential units of block ekb (from u0 on) spread behind its MFMAs
+        auto s_block = [&](int kb, int ekb, int u0, int units) {
+          bf16x8_t kf[KS];
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8_t*)(Ks + kb * 32 * KROW + k_off[ks]);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+              // scores in VGPRs (the exponentials read them), the Q fragments -- read-only B operands, 48 registers -- from the AGPR half.
+              // No VALU instruction reads a score block before at least four further MFMAs have issued behind the one that completed
+              // it (the pipe is serial: 32 cycles each), so the XDL-write -> VALU-read wait states the compiler cannot see are covered.
+              if (ks == 0)
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s[kb][qb]) : "v"(kf[ks]), "a"(__builtin_bit_cast(bf16x8_t, qf[qb][ks])));
+              else
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s[kb][qb]) : "v"(kf[ks]), "a"(__builtin_bit_cast(bf16x8_t, qf[qb][ks])));
+              if (units > 0) {
+                fence();
+                const int from = ((ks * QB + qb) * units) / (KS * QB), upto = ((ks * QB + qb + 1) * units) / (KS * QB);
+#pragma unroll
+                for (int u = from; u < upto; ++u) exp_unit(ekb, u0 + u);
+                fence();
+              }
+            }
+        };
+        // P.V of (score block kb, 16-key half m2), with `units` exponential units of block ekb (from u0 on) behind its MFMAs
+        auto pv_half = [&](int kb, int m2, int ekb, int u0, int units) {
+          bf16x8_t vf[DB];
+#pragma unroll
+          for (int db = 0; db < DB; ++db) vf[db] = *(const bf16x8_t*)(Vs + v_row[db] + (((kb * 4 + m2 * 2 + hi) ^ v_sw[db]) << 4));
+#pragma unroll
+          for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+              const uint4 pv = uint4{pw[kb][qb][4 * m2], pw[kb][qb][4 * m2 + 1], pw[kb][qb][4 * m2 + 2], pw[kb][qb][4 * m2 + 3]};
+              // the O^T accumulators (128 registers) are pinned in the AGPR half of the register file: the VALU never touches them inside
+              // the loop (one denominator register per query block aside), while S^T -- which the exponentials read -- stays in VGPRs.
+              // The builtin leaves that choice to one per-function switch; with both accumulator sets in VGPRs the allocator shuffled
+              // ~300 v_accvgpr_read / write / mov per tile through the VALU this pipeline is built to keep free.
+              asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[db][qb]) : "v"(vf[db]), "v"(__builtin_bit_cast(bf16x8_t, pv)));
+              if (units > 0) {
+                fence();
+                const int from = ((db * QB + qb) * units) / (DB * QB), upto = ((db * QB + qb + 1) * units) / (DB * QB);
+#pragma unroll
+                for (int u = from; u < upto; ++u) exp_unit(ekb, u0 + u);
+                fence();
+              }
+            }
+        };
+        fence();
+        s_block(0, 0, 0, 0);
+        fence();
+        s_block(1, 0, 0, 16);
+        mark(1);
+        pv_half(0, 0, 0, 16, 16);
+        pv_half(0, 1, 1, 0, 16);
+        mark(2);
+        pv_half(1, 0, 1, 16, 16);
+        pv_half(1, 1, 0, 0, 0);
+        fence();
+        // the compiler's hazard recogniser does not look inside inline asm: a VALU read of an accumulator (the denominator check below)
+        // needs 18 wait states behind the 16-pass MFMA that wrote it
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+        mark(3);
+      } else {
       // ---- S^T = K . Q'^T - m : [kb] 32 keys x [qb] 32 queries
       f32x16_t s[2][QB];
 #pragma unroll
@@ -375,6 +458,7 @@ __global__ __launch_bounds__(256, MINW) void attention_x32_kernel(const AttnArgs
             }
           }
       mark(3);
+      }
       if (more) {
         store_tile((t + 1) & 1);                     // the other buffer: last read one barrier ago
         // a ragged last tile changes the mask column of the buffer it lands in (buffers 0 / 1 were initialised for tiles 0 / 1)
@@ -836,7 +920,13 @@ int attention_x32_launch(const AttnArgs& a, hipStream_t stream) {
   }
 #endif
   switch (a.D) {
-    case 40: return launch_x32<40, 2, 2>(a, stream);
+    case 40: {
+      // DFH_ATTN_QB4: 1 = four query blocks per wave, one wave per SIMD, in-wave software pipeline (see the kernel) for launches with at
+      // least 512 queries; 0 = the two-block kernel at two workgroups per CU
+      static const int qb4 = [] { const char* e = getenv("DFH_ATTN_QB4"); return e ? atoi(e) : 0; }();
+      if (qb4 && a.Nq >= 512 && a.Nk >= 128) return launch_x32<40, 4, 1>(a, stream);
+      return launch_x32<40, 2, 2>(a, stream);
+    }
     case 64: {
       static const int qb64 = [] { const char* e = getenv("DFH_ATTN_QB64"); return e ? atoi(e) : 2; }();     // probe knob
       return qb64 == 1 ? launch_x32<64, 1, 2>(a, stream) : launch_x32<64, 2, 2>(a, stream);

@@ -13,6 +13,7 @@
 #include "dfh_common.h"
 #include "elementwise.h"
 #include "gemm.h"
+#include "mlp_fused.h"
 #include "norm.h"
 #include "packtab.h"
 #include "bwd_elementwise.h"
@@ -58,6 +59,9 @@ struct AttL {
   // pout . ff2b + poutb -- proj_out(ff2(f) + ff2b + h2) + poutb as written, minus one launch, one bf16 rounding and one round trip
   // of a [tokens][C] tensor per transformer block
   Fold fffp;
+  // C = 320 (the 64x64 level): the whole feed-forward + proj_out as ONE kernel (mlp_fused.hip); its weight image (fragment-major LDS
+  // image of fff1 and fffp, 2.7 MB) in the fold region
+  size_t mlp_img = 0; bool has_mlp = false;
   Vec nw, nb, pinb, l1w, l1b, o1b, l2w, l2b, o2b, l3w, l3b, ff1b, ff2b, poutb;
   Mat pin, qk, v, o1, q2, o2, ff1, ff2, pout;
   std::string pre; Mat pint, qkvt, o1t, q2t, o2t, ff1t, ff2t, poutt;
@@ -310,6 +314,10 @@ struct dfh_unet {
     a.fv = a.fqkv; a.fv.N = C; a.fv.w += (size_t)2 * C * C; a.fv.s += 2 * C; a.fv.b += 2 * C;
     a.fq2 = fold_alloc(C, C); a.fff1 = fold_alloc(8 * C, C);
     a.fffp = fold_alloc(C, 5 * C);
+    if (dfh::mlp_fused_eligible(C, 128)) {
+      a.has_mlp = true; a.mlp_img = fold16;
+      fold16 += (dfh::mlp_fused_image_bytes() / 2 + 127) & ~(size_t)127;
+    }
   }
 
   void build_conv(const std::string& pre, int cout, int cin, ConvL& c) {
@@ -562,6 +570,9 @@ struct dfh_unet {
                            hipMemcpyDeviceToDevice, s) != hipSuccess) { dfh::set_error("hipMemcpy2DAsync failed"); return -2; }
       if (int rc = dfh::matvec_bias_launch(arena16 + a->pout.off, C, arena32 + a->ff2b.off, arena32 + a->poutb.off,
                                            fold_v() + a->fffp.b, C, C, s)) return rc;
+      if (a->has_mlp)      // the fused feed-forward's weight image from the two folded matrices just derived (mlp_fused.hip)
+        if (int rc = dfh::mlp_pack_launch(fold_w() + a->fff1.w, fold_v() + a->fff1.s, fold_v() + a->fff1.b, fold_w() + a->fffp.w,
+                                          fold_w() + a->mlp_img, s)) return rc;
     }
     fold_valid = true; fold_dirty = false;
     return 0;
@@ -987,6 +998,18 @@ struct dfh_unet {
         return out;
       }
       Tensor ff = talloc(H, W, 4 * C);
+      // the whole feed-forward + proj_out in one kernel where the X tile fits the register file (C = 320: the 64x64 level); needs the row
+      // statistics of h2 from its producer like every folded-LayerNorm consumer.  DFH_MLP_FUSED=0: the two-launch walk (A/B)
+      static const bool mlp_off = [] { const char* e = getenv("DFH_MLP_FUSED"); return e && e[0] == '0'; }();
+      if (fold && !mlp_off && a.has_mlp && bn > 0 && C % bn == 0 && dfh::mlp_fused_eligible(C, M)) {
+        MlpArgs ma; std::memset(&ma, 0, sizeof(ma));
+        ma.x = h2.p; ma.resid = x.p; ma.img = (const unsigned char*)(u->fold_w() + a.mlp_img);
+        ma.ln_stat = st; ma.ln_parts = C / bn; ma.ln_cnt = bn; ma.ln_eps = 1e-5f;
+        ma.bias = u->fold_v() + a.fffp.b; ma.out = out.p; ma.M = M;
+        if (!rc) rc = dfh::mlp_fused_launch(ma, s);
+        temp.off = mark;
+        return out;
+      }
       if (!try_folded({folded(h2.p, M, a.fff1, st, bn, ACT_GEGLU, ff.p, OUT_BF16, -1, 0)})) {
         if (f8) { layernorm8(h2.p, a.l3w, a.l3b, n8, s8, M, C); linear8(n8, s8, M, a.ff18, &a.ff1b, ACT_GEGLU, ff.p); }
         else {

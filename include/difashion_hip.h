@@ -29,7 +29,7 @@ extern "C" {
 /* Bumped whenever an entry point, a struct layout or the meaning of an argument changes (round 4: 4).  The Python host side
  * (difashion_amd/_lib.py ABI_VERSION) refuses a library that reports another number: a stale .so next to new Python, or the reverse,
  * fails at load time instead of at a symbol lookup or silently. */
-#define DFH_ABI_VERSION 5
+#define DFH_ABI_VERSION 6
 #define DFH_MAX_BLOCKS 4
 
 /* ------------------------------------------------------------------ library */
@@ -343,6 +343,17 @@ typedef struct dfh_gemm_fp8_desc {
 int dfh_quantize_rows_fp8(const void* x, int ldx, void* q, float* scale, int R, int K, void* stream);
 int dfh_layernorm_fp8(const void* x, const float* gamma, const float* beta, void* q, float* scale, int M, int C, float eps, void* stream);
 int dfh_gemm_fp8(const dfh_gemm_fp8_desc* d, void* stream);
+/* Fused GEGLU feed-forward + proj_out of a transformer block at C = 320 (csrc/mlp_fused.hip; replaces the ff.net.0 / ff.net.2 / proj_out
+ * launches of diffusers BasicTransformerBlock.ff + Transformer2DModel.proj_out at the 64x64 level, reference call site
+ * DiFashion/models/difashion.py:518-523):  out = [pout . ff2 | pout] . [GEGLU(LN3(x) . W1^T + b1) | x] + bias + resid.
+ *   dfh_mlp_fused_pack : builds the layer's weight image (dfh_mlp_fused_image_bytes() bytes) from the LayerNorm-folded GEGLU projection
+ *                        w1 ([8 C][C] bf16, rows packed 16 values | 16 gates; s1 / b1 its fold vectors, dfh_ln_fold) and w2p = [C][5 C]
+ *   dfh_mlp_fused      : x / resid / out [M][320] bf16, M a multiple of 128; ln_stat = per-row statistics of x ([ln_parts][M][2]: mean
+ *                        and centred sum of squares per column tile of ln_cnt columns, as dfh_gemm's row statistics) */
+size_t dfh_mlp_fused_image_bytes(void);
+int dfh_mlp_fused_pack(const void* w1, const float* s1, const float* b1, const void* w2p, void* img, void* stream);
+int dfh_mlp_fused(const void* x, const void* resid, const void* img, const float* ln_stat, int ln_parts, int ln_cnt, float ln_eps,
+                  const float* bias, void* out, int M, void* stream);
 int dfh_groupnorm_fp8(const void* src, int batch, int HW, int C, int groups, float eps, float q_mul, void* q, float* partial, void* stream);
 int dfh_attention_fp8out(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O8, int ldo, const float* v_amax,
                          int batch, int heads, int head_dim, int Nq, int Nk, float scale, void* stream);

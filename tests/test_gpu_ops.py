@@ -1085,3 +1085,56 @@ def test_gemm_fp8_transposed_output():
     out, xd, wd = _fp8_gemm(x, w, out_mode=1, rows_per_b=rows)
     ref = (xd @ wd.T).view(B, rows, N).transpose(1, 2)
     gu.assert_close_bf16(out, ref, "fp8 transposed")
+
+
+@pytest.mark.parametrize("M,parts,offset", [(128, 2, 0.0), (512, 2, 3.0), (1024, 5, 0.0), (384, 1, 0.0)])
+def test_mlp_fused_matches_torch(M, parts, offset):
+    """dfh_mlp_fused (csrc/mlp_fused.hip): the GEGLU feed-forward + proj_out of a C = 320 transformer block in one kernel,
+    out = proj_out(ff.net.2(GEGLU(ff.net.0(LN3(x)))) + x) + resid, against fp32 torch on the same bf16 operands -- and against the
+    two-launch walk it replaces (folded-LayerNorm GEGLU projection, then the [hidden | x] linear).  Row statistics come in the producer's
+    per-column-tile record layout (1, 2 or 5 tiles per row); rows with a common offset (mean >> std) included.  Both intermediate roundings
+    of the unfused walk are kept (hidden units to bf16; the output once), so the two paths agree to bf16 accumulation-order noise."""
+    import ctypes
+    C = 320
+    x = bf(rnd(M, C, seed=71) + offset)
+    resid = bf(rnd(M, C, seed=72))
+    gamma, beta = 1.0 + 0.2 * rnd(C, seed=73), 0.3 * rnd(C, seed=74)
+    wg, bg = rnd(8 * C, C, seed=75, scale=0.05), rnd(8 * C, seed=76, scale=0.3)          # ff.net.0.proj: rows [values | gates]
+    w2, b2 = rnd(C, 4 * C, seed=77, scale=0.03), rnd(C, seed=78, scale=0.3)                # ff.net.2
+    wo, bo = rnd(C, C, seed=79, scale=0.05), rnd(C, seed=80, scale=0.3)                    # proj_out
+    # packed (16 values | 16 gates) GEGLU rows, LayerNorm folded in
+    wp = torch.empty((8 * C, C), dtype=torch.bfloat16, device=DEV)
+    bp = torch.empty(8 * C, dtype=torch.float32, device=DEV)
+    _lib.call("dfh_pack_matrix", _lib.ptr(wg), _lib.ptr(wp), 8 * C, C, C, 0, 0, 1, gu.stream())
+    _lib.call("dfh_pack_vector", _lib.ptr(bg), _lib.ptr(bp), 8 * C, 0, 1, 0, gu.stream())
+    wf = torch.empty_like(wp)
+    s1, b1 = torch.empty(8 * C, device=DEV), torch.empty(8 * C, device=DEV)
+    _lib.call("dfh_ln_fold", _lib.ptr(wp), C, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bp), _lib.ptr(wf), _lib.ptr(s1), _lib.ptr(b1), 8 * C, C, gu.stream())
+    # [pout . ff2 | pout] and its bias, as unet_model.h derives them (fp32 product, one rounding)
+    w2p = bf(torch.cat([wo.float() @ bf(w2).float(), bf(wo).float()], dim=1)).contiguous()
+    w2p[:, 4 * C:] = bf(wo)
+    bias = (bf(wo).float() @ b2 + bo).contiguous()
+    # row statistics of x in the producer's layout: [parts][M][2] = (mean, centred sum of squares) per column tile
+    cnt = C // parts
+    xp = x.float().view(M, parts, cnt).transpose(0, 1)
+    mean_t = xp.mean(-1)
+    st = torch.stack([mean_t, ((xp - mean_t[..., None]) ** 2).sum(-1)], dim=-1).contiguous()
+    img = torch.empty(_lib.raw().dfh_mlp_fused_image_bytes(), dtype=torch.uint8, device=DEV)
+    _lib.call("dfh_mlp_fused_pack", _lib.ptr(wf), _lib.ptr(s1), _lib.ptr(b1), _lib.ptr(w2p), _lib.ptr(img), gu.stream())
+    out = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.call("dfh_mlp_fused", _lib.ptr(x), _lib.ptr(resid), _lib.ptr(img), _lib.ptr(st), parts, cnt, 1e-5, _lib.ptr(bias), _lib.ptr(out), M, gu.stream())
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    # fp32 torch on the same operands
+    ln = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
+    hh = ln @ bf(wg).float().T + bg
+    av, gate = hh.chunk(2, -1)
+    hid = bf(av * F.gelu(gate)).float()
+    ref = torch.cat([hid, x.float()], dim=1) @ w2p.float().T + bias + resid.float()
+    gu.assert_close_bf16(out, ref, "fused mlp vs torch")
+    # the two-launch walk on the same operands
+    dd = gu.gemm_desc(M=M, N=8 * C, W=wf, ldw=C, a0=x, a0_c=C, bias=b1, act=4)
+    _lib.call("dfh_gemm_ln", ctypes.byref(dd), None, None, _lib.ptr(st), parts, cnt, 1e-5, _lib.ptr(s1), gu.stream())
+    two = gu.gemm(M=M, N=C, W=w2p, ldw=5 * C, a0=dd.keep_out, a0_c=4 * C, a1=x, a1_c=C, bias=bias, resid=resid)
+    torch.cuda.synchronize()
+    assert gu.rel_err(out, two) < 6e-3, gu.rel_err(out, two)

@@ -305,6 +305,39 @@ def test_unet_sd15_full_size_batch16_matches_oracle():
     assert cen8["gemm_lean"] + cen8["gemm_8wave"] + cen8["gemm_row"] < cen["gemm_lean"] + cen["gemm_8wave"] + cen["gemm_row"], (cen, cen8)
 
 
+@pytest.mark.timeout(2400)
+def test_unet_sd15_full_size_batch64_matches_oracle_rows():
+    """The reference's OWN inference call (DiFashion/inf4eval.py:521-524: 4 outfits per fashion_generation call in GOR mode) makes the
+    U-Net batch 4 outfits x 4 items x 4 guidance branches = 64.  One full-size SD-1.5 forward at that batch: the rows of a U-Net batch
+    never interact, so the fp32 oracle is evaluated on four of the 64 rows (first, last, two inside; their own timesteps) and every one
+    must hold the stated tolerance (<= 3e-2 relative L2); the census shows which tiles the launch heuristics pick at this batch (the
+    deep levels finally have 4x the pixel rows: fewer split-K launches than at batch 16)."""
+    from difashion_amd import _lib
+    cfg = unet_ref.SD15
+    params = unet_ref.init_params(cfg, seed=0)
+    x, e = inputs(cfg, 64, 777)
+    t = torch.tensor([981, 741, 501, 21]).repeat_interleave(16)
+    rows = [0, 21, 42, 63]
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(params, cfg, x[rows], t[rows], e[rows])
+    m = hip_unet(cfg, params, max_batch=64)
+    del params
+    xd, td, ed = x.to(DEV), t.to(DEV), e.to(DEV)
+    with torch.no_grad():
+        m(xd, td, ed)
+        torch.cuda.synchronize()
+        _lib.census_reset()
+        out = m(xd, td, ed).sample
+        torch.cuda.synchronize()
+    cen = _lib.census()
+    errs = [rel_err(out[r:r + 1].cpu(), ref[i:i + 1]) for i, r in enumerate(rows)]
+    print("sd15 B=64 rows", rows, [f"{v:.2e}" for v in errs])
+    print("census B=64", {k: v for k, v in cen.items() if v})
+    assert torch.isfinite(out).all()
+    assert all(v <= TOL for v in errs), errs
+    assert cen["gemm_wide"] + cen["gemm_row"] > 0 and cen["attention_x32"] > 0 and cen["ln_folded"] >= 45, cen
+
+
 @pytest.mark.timeout(900)
 def test_unet_sd2base_full_size_matches_oracle():
     """SD-2-base shape (865.9 M parameters: linear projections, 1024-wide text states, head dim 64 at every level), B=1."""

@@ -30,6 +30,8 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef const __attribute__((address_space(1))) u32x4_t* gptr16_t;      // 16-byte global loads (explicit address space: no flat loads)
 
 constexpr int MC = 320, MHID = 4 * MC;
 constexpr int NCHUNK = MHID / 32;            // 40 chunks of 32 hidden units
@@ -41,7 +43,7 @@ constexpr int G3_SLICES = 5, G3_BYTES = CT * 4 * 1024;              // h2 segmen
 constexpr long G3_OFF = (long)NCHUNK * CHUNK_BYTES;
 constexpr long IMG_BYTES = G3_OFF + (long)G3_SLICES * G3_BYTES;
 static_assert(W1_BYTES == G3_BYTES, "the h2 slices go through the W1 ring");
-constexpr int LDS_W1 = 0, LDS_W2 = 2 * W1_BYTES, LDS_VEC = LDS_W2 + 2 * W2_BYTES, LDS_TOTAL = LDS_VEC + 2 * VEC_BYTES;      // 124928
+constexpr int LDS_W1 = 0, LDS_W2 = 2 * W1_BYTES, LDS_VEC = LDS_W2 + 2 * W2_BYTES, LDS_DUMP = LDS_VEC + 2 * VEC_BYTES, LDS_TOTAL = LDS_DUMP + 4 * 1024;      // 129024
 // k-position p of a 16-deep k-step of the second GEMM <-> hidden unit (inside its 16-unit tile) the GEGLU leaves there
 __device__ __constant__ const int kPerm[16] = {0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15};
 
@@ -155,29 +157,40 @@ DFH_DEVICE void geglu_slice(MlpState& st, const unsigned char* smem, int vec_lan
 template <int KIND, int PAR, bool PREV, int Q>
 DFH_DEVICE void mlp_iter(MlpState& st, const unsigned char* smem, const unsigned char* img, long dma_w1, long dma_w2, int wave, int lane) {
   constexpr int PP = 1 - PAR;
-  constexpr int WIN = 8;                                    // fragment reads in flight
+  constexpr int WIN = 6;                                    // fragment reads in flight
   const unsigned char* fl = smem + lane * 16;               // this lane's 16 bytes of every fragment block
+  const unsigned lane16 = (unsigned)lane * 16u;             // unsigned 32-bit lane offset: scalar base + VGPR offset addressing of the staging loads
   const int vec_lane = (lane >> 5) * 32;
   auto g1_off = [&](int i) {                                // fragment of MFMA i of this iteration's 40
     if (KIND == 0) return LDS_W1 + PAR * W1_BYTES + ((i & 1) * KS1 + (i >> 1)) * 1024;          // (tile i & 1, k-step i >> 1)
     return LDS_W1 + PAR * W1_BYTES + ((i % CT) * 4 + i / CT) * 1024;                             // (row tile i % 10, k-step i / 10 of the slice)
   };
   auto g2_off = [&](int j) { return LDS_W2 + PP * W2_BYTES + j * 1024; };                        // (tile j / 10, row tile j % 10)
-  // request one LDS-DMA piece: k-th of this wave in this iteration
-  auto dma_piece = [&](int k) {
-    const int p1 = wave + 4 * k;                            // W1 ring: pieces 0..39
-    if (k < 10) {
-      if (dma_w1 >= 0)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + dma_w1 + (long)p1 * 1024 + lane * 16),
-                                         (__attribute__((address_space(3))) void*)(smem + LDS_W1 + PP * W1_BYTES + p1 * 1024), 16, 0, 0);
-    } else {
-      const int p2 = wave + 4 * (k - 10);                   // W2 + vectors: pieces 0..20
-      if (dma_w2 >= 0 && p2 < 21) {
-        const int dst = p2 < 20 ? LDS_W2 + PAR * W2_BYTES + p2 * 1024 : LDS_VEC + PAR * VEC_BYTES;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + dma_w2 + (long)p2 * 1024 + lane * 16),
-                                         (__attribute__((address_space(3))) void*)(smem + dst), 16, 0, 0);
-      }
-    }
+  // The weight stream: piece k (0..15) of this wave in this iteration -- pieces 0..9 belong to the W1 ring (image pieces wave + 4 k of the
+  // NEXT chunk's first-GEMM slices -> slot 1 - PAR), 10..15 to the current chunk's W2 + vector set (pieces wave + 4 (k - 10) < 21 ->
+  // slot PAR).  Staged through REGISTERS (global_load_dwordx4 early, ds_write_b128 sixteen MFMAs later), not by LDS-DMA: a
+  // global_load_lds piece holds its issuing wave for ~250 cycles (profiles/DESIGN_LOG: "costs its issuing wave ~250 cycles per KiB"),
+  // and with one wave per SIMD nothing else can issue meanwhile -- sixteen pieces per iteration were 4000 of its 5900 cycles (measured
+  // with the LDS-DMA form: 277 us per launch; profiles/r05/mlp_fused_steps.txt).
+  // (no branches: an iteration with nothing to stage for a piece reads image offset 0 and writes the wave's 1-KB dump region)
+  auto piece_off = [&](int k) -> long {
+    if (k < 10) return (dma_w1 >= 0 ? dma_w1 : 0) + (long)(wave + 4 * k) * 1024;
+    const int p2 = wave + 4 * (k - 10);
+    return (dma_w2 >= 0 && p2 < 21) ? dma_w2 + (long)p2 * 1024 : 0;
+  };
+  auto piece_dst = [&](int k) -> int {
+    if (k < 10) return dma_w1 >= 0 ? LDS_W1 + PP * W1_BYTES + (wave + 4 * k) * 1024 : LDS_DUMP + wave * 1024;
+    const int p2 = wave + 4 * (k - 10);
+    if (!(dma_w2 >= 0 && p2 < 21)) return LDS_DUMP + wave * 1024;
+    return p2 < 20 ? LDS_W2 + PAR * W2_BYTES + p2 * 1024 : LDS_VEC + PAR * VEC_BYTES;
+  };
+  u32x4_t sg[8];
+  // staging load of piece k: the piece's image address is wave-uniform -- pinned in SGPRs (opaque to reassociation) so that the load is
+  // `global_load_dwordx4 v, v_lane16, s[base]` and no 64-bit per-lane address is built, kept or spilled
+  auto stage_ld = [&](int k) -> u32x4_t {
+    const unsigned char* base = img + piece_off(k);
+    asm volatile("" : "+s"(base));
+    return *(gptr16_t)(base + lane16);
   };
   bf16x8_t fr[WIN];
 #pragma unroll
@@ -199,7 +212,12 @@ DFH_DEVICE void mlp_iter(MlpState& st, const unsigned char* smem, const unsigned
     if (i + WIN < 40) fr[i % WIN] = *(const bf16x8_t*)(fl + g1_off(i + WIN));
     else if (PREV) fr[i % WIN] = *(const bf16x8_t*)(fl + g2_off(i + WIN - 40));
     if (PREV) geglu_slice<PP>(st, smem, vec_lane, i / 5, i % 5);
-    if (i < 16) dma_piece(i);
+    // pieces 0..7: requested behind MFMAs 0..7, written to LDS behind MFMAs 16..23; pieces 8..15: requested there, written behind 32..39
+    if (i < 8) sg[i] = stage_ld(i);
+    else if (i >= 16 && i < 24) {
+      *(u32x4_t*)(const_cast<unsigned char*>(fl) + piece_dst(i - 16)) = sg[i - 16];
+      sg[i - 16] = stage_ld(i - 8);
+    } else if (i >= 32) *(u32x4_t*)(const_cast<unsigned char*>(fl) + piece_dst(i - 24)) = sg[i - 32];
     fence();
   }
   if (PREV) {
@@ -210,13 +228,13 @@ DFH_DEVICE void mlp_iter(MlpState& st, const unsigned char* smem, const unsigned
       const int t2 = j / CT, ct = j % CT;
       const uint4 hb = uint4{st.hreg[t2][0], st.hreg[t2][1], st.hreg[t2][2], st.hreg[t2][3]};
       asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(st.d2[ct]) : "v"(fr[(40 + j) % WIN]), "v"(__builtin_bit_cast(bf16x8_t, hb)));
-      fence();
+        fence();
       if (j + WIN < 20) fr[(40 + j) % WIN] = *(const bf16x8_t*)(fl + g2_off(j + WIN));
       fence();
     }
   }
-  // every piece this wave requested has landed, then every wave's: the next iteration reads them
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // every piece this wave staged is written, then every wave's: the next iteration reads them
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
@@ -228,17 +246,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpArgs a) {
   const int ql = lane & 31, h = lane >> 5;
   const int m = blockIdx.x * 128 + wave * 32 + ql;          // this lane's token (the launcher guarantees M % 128 == 0)
   const unsigned char* img = a.img;
-  asm volatile("" : "+s"(img));
 
   MlpState st;
   st.gk = gelu_consts();
   // first pieces of the weight stream: W1 of chunk 0 -> W1 slot 0 (the first iteration requests chunk 1 and W2 / vectors of chunk 0)
 #pragma unroll
-  for (int k = 0; k < 10; ++k) {
-    const int p1 = wave + 4 * k;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + (long)p1 * 1024 + lane * 16),
-                                     (__attribute__((address_space(3))) void*)(smem + LDS_W1 + p1 * 1024), 16, 0, 0);
-  }
+  for (int k = 0; k < 10; ++k)
+    *(u32x4_t*)(smem + LDS_W1 + (wave + 4 * k) * 1024 + lane * 16) = *(gptr16_t)(img + (long)(wave + 4 * k) * 1024 + lane * 16);
   // X fragments: token m, k = 16 ks + 8 h .. + 7
   {
     const bf16_t* xr = a.x + (long)m * MC + 8 * h;
@@ -277,13 +291,23 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpArgs a) {
 
   // ---- epilogue: out[m][n] = D2 + bias[n] + resid[m][n], n = 32 ct + 8 j + 4 h + r
   // (the compiler does not see the XDL writes of the inline-asm MFMAs: 18 wait states before the accumulators are read)
-  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-  const long row = (long)m * MC;
+  // ... and the wait is tied to the ten accumulator tuples as operands: their AGPR -> VGPR copies are plain register moves that the
+  // register allocator otherwise places right behind the last MFMA of each tuple (the last-written tile came out 15 % wrong)
+  asm volatile("s_nop 15\n\ts_nop 7"
+               : "+a"(st.d2[0]), "+a"(st.d2[1]), "+a"(st.d2[2]), "+a"(st.d2[3]), "+a"(st.d2[4]), "+a"(st.d2[5]), "+a"(st.d2[6]), "+a"(st.d2[7]),
+                 "+a"(st.d2[8]), "+a"(st.d2[9])
+               :: "memory");
+  // the token index is re-derived through an opaque copy of the thread id: the per-lane output / residual addresses are then computed
+  // HERE instead of being kept in six VGPRs across the whole kernel (they were spilled to scratch)
+  int tid2 = threadIdx.x;
+  asm volatile("" : "+v"(tid2));
+  const int m2 = blockIdx.x * 128 + (tid2 >> 6) * 32 + (tid2 & 31), h2 = (tid2 >> 5) & 1;
+  const long row = (long)m2 * MC;
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int n = 32 * ct + 8 * j + 4 * h;
+      const int n = 32 * ct + 8 * j + 4 * h2;
       const float4 b4 = *(const float4*)(a.bias + n);
       const uint2 rr = *(const uint2*)(a.resid + row + n);
       const float v0 = st.d2[ct][4 * j] + b4.x + __uint_as_float(rr.x << 16), v1 = st.d2[ct][4 * j + 1] + b4.y + __uint_as_float(rr.x & 0xffff0000u);

@@ -1007,6 +1007,7 @@ struct dfh_unet {
         ma.ln_stat = st; ma.ln_parts = C / bn; ma.ln_cnt = bn; ma.ln_eps = 1e-5f;
         ma.bias = u->fold_v() + a.fffp.b; ma.out = out.p; ma.M = M;
         if (!rc) rc = dfh::mlp_fused_launch(ma, s);
+        dfh::census(dfh::CK_LN_FOLDED);                  // LayerNorm 3 is consumed folded here too
         temp.off = mark;
         return out;
       }

@@ -322,6 +322,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpArgs a) {
 namespace dfh {
 
 size_t mlp_fused_image_bytes() { return (size_t)IMG_BYTES; }
+int mlp_fused_form() {
+  static const int form = [] { const char* e = getenv("DFH_MLP_FUSED"); return e ? atoi(e) : 2; }();
+  return form;
+}
 bool mlp_fused_eligible(int C, long M) { return C == MC && M > 0 && M % 128 == 0; }
 
 int mlp_pack_launch(const bf16_t* w1, const float* s1, const float* b1, const bf16_t* w2p, void* img, hipStream_t stream) {

@@ -62,6 +62,9 @@ struct AttL {
   // C = 320 (the 64x64 level): the whole feed-forward + proj_out as ONE kernel (mlp_fused.hip); its weight image (fragment-major LDS
   // image of fff1 and fffp, 2.7 MB) in the fold region
   size_t mlp_img = 0; bool has_mlp = false;
+  // ... and its four K = N = C projections (proj_in, attn1.to_out, attn2.to_q folded, attn2.to_out) as register-resident token linears
+  // (mlp_fused2.hip token_linear_kernel): their weight images in the fold region
+  size_t tl_pin = 0, tl_o1 = 0, tl_q2 = 0, tl_o2 = 0; bool has_tl = false;
   Vec nw, nb, pinb, l1w, l1b, o1b, l2w, l2b, o2b, l3w, l3b, ff1b, ff2b, poutb;
   Mat pin, qk, v, o1, q2, o2, ff1, ff2, pout;
   std::string pre; Mat pint, qkvt, o1t, q2t, o2t, ff1t, ff2t, poutt;
@@ -318,6 +321,10 @@ struct dfh_unet {
       a.has_mlp = true; a.mlp_img = fold16;
       fold16 += (dfh::mlp_fused_image_bytes() / 2 + 127) & ~(size_t)127;
     }
+    if (dfh::token_linear_eligible(C, C, 128)) {
+      a.has_tl = true;
+      for (size_t* o : {&a.tl_pin, &a.tl_o1, &a.tl_q2, &a.tl_o2}) { *o = fold16; fold16 += (dfh::token_linear_image_bytes() / 2 + 127) & ~(size_t)127; }
+    }
   }
 
   void build_conv(const std::string& pre, int cout, int cin, ConvL& c) {
@@ -534,6 +541,15 @@ struct dfh_unet {
                                          fold_w() + dst[i]->w, fold_v() + dst[i]->s, fold_v() + dst[i]->b, src[i]->N, src[i]->K, s)) return rc;
       }
     }
+    for (AttL* a : all_att()) {
+      static const bool tl_on = [] { const char* e = getenv("DFH_TOKEN_LINEAR"); return e && e[0] == '1'; }();
+      if (!tl_on || !a->has_tl || (fp8 && a->qk8.on)) continue;
+      const int C = a->C;
+      if (int rc = dfh::token_linear_pack_launch(arena16 + a->pin.off, a->pin.K, fold_w() + a->tl_pin, s)) return rc;
+      if (int rc = dfh::token_linear_pack_launch(arena16 + a->o1.off, a->o1.K, fold_w() + a->tl_o1, s)) return rc;
+      if (int rc = dfh::token_linear_pack_launch(fold_w() + a->fq2.w, C, fold_w() + a->tl_q2, s)) return rc;
+      if (int rc = dfh::token_linear_pack_launch(arena16 + a->o2.off, a->o2.K, fold_w() + a->tl_o2, s)) return rc;
+    }
     {
       std::vector<ResL*> rs;
       for (auto& lv : down_res) for (auto& r : lv) rs.push_back(&r);
@@ -570,9 +586,10 @@ struct dfh_unet {
                            hipMemcpyDeviceToDevice, s) != hipSuccess) { dfh::set_error("hipMemcpy2DAsync failed"); return -2; }
       if (int rc = dfh::matvec_bias_launch(arena16 + a->pout.off, C, arena32 + a->ff2b.off, arena32 + a->poutb.off,
                                            fold_v() + a->fffp.b, C, C, s)) return rc;
-      if (a->has_mlp)      // the fused feed-forward's weight image from the two folded matrices just derived (mlp_fused.hip)
-        if (int rc = dfh::mlp_pack_launch(fold_w() + a->fff1.w, fold_v() + a->fff1.s, fold_v() + a->fff1.b, fold_w() + a->fffp.w,
-                                          fold_w() + a->mlp_img, s)) return rc;
+      if (a->has_mlp && dfh::mlp_fused_form() > 0) {     // the fused feed-forward's weight image from the two folded matrices just derived
+        auto pack = dfh::mlp_fused_form() == 1 ? dfh::mlp_pack_launch : dfh::mlp2_pack_launch;
+        if (int rc = pack(fold_w() + a->fff1.w, fold_v() + a->fff1.s, fold_v() + a->fff1.b, fold_w() + a->fffp.w, fold_w() + a->mlp_img, s)) return rc;
+      }
     }
     fold_valid = true; fold_dirty = false;
     return 0;
@@ -889,6 +906,22 @@ struct dfh_unet {
         dfh::census(dfh::CK_LN_FOLDED);
         return true;
       };
+      // the K = N = C projections of a C = 320 block on the register-resident token-linear kernel (mlp_fused2.hip); DFH_TOKEN_LINEAR=0: dfh_gemm (A/B)
+      // OPT-IN (DFH_TOKEN_LINEAR=1): parity-tested, but measured slower than the tile GEMM here -- 37 / 46 us against 27 / 34 us per launch at
+      // M = 65536, sampling step 15.7 -> 15.9 ms (profiles/r05/token_linear_ab.txt): one workgroup per CU leaves its prologue (row loads,
+      // first weight slice) and epilogue exposed twice per launch, and every 128-token tile re-streams the whole 200-KB matrix
+      static const bool tl_on = [] { const char* e = getenv("DFH_TOKEN_LINEAR"); return e && e[0] == '1'; }();
+      const bool tl = fold && tl_on && a.has_tl && dfh::token_linear_eligible(C, C, M);
+      // x: rows, img: weight image, bias / resid as dfh_gemm; folded: f's s / b' with the current statistics; leaves the output's row statistics in st
+      auto token_linear = [&](const bf16_t* xin, size_t img, const float* bias, const bf16_t* resid, const Fold* f, bf16_t* o, bool stats) {
+        if (rc) return;
+        TokLinArgs t; std::memset(&t, 0, sizeof(t));
+        t.x = xin; t.img = (const unsigned char*)(u->fold_w() + img); t.bias = bias; t.resid = resid; t.out = o; t.M = M;
+        if (f) { t.ln_stat = st; t.ln_parts = C / bn; t.ln_cnt = bn; t.ln_eps = 1e-5f; t.ln_s = u->fold_v() + f->s; t.bias = u->fold_v() + f->b; }
+        if (stats) t.rowstat = st;
+        rc = dfh::token_linear_launch(t, s);
+        if (stats) bn = C;                            // one record per row over all C columns
+      };
       Tensor h0 = talloc(H, W, C);
       uint8_t* a8 = f8x ? (uint8_t*)temp.alloc((size_t)M * C) : nullptr;          // e4m3 operand of proj_in, then of the two to_out
       float* am_self = f8x ? amax_self + (size_t)a.idx * B : nullptr;
@@ -901,7 +934,8 @@ struct dfh_unet {
       } else {
         Tensor gn = talloc(H, W, C);
         groupnorm(x, nullptr, a.nw, a.nb, 1e-6f, 0, gn);
-        linear(gn.p, M, C, a.pin, &a.pinb, ACT_NONE, nullptr, h0.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
+        if (tl) token_linear(gn.p, a.tl_pin, v32(a.pinb), nullptr, nullptr, h0.p, true);
+        else linear(gn.p, M, C, a.pin, &a.pinb, ACT_NONE, nullptr, h0.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
       }
       // --- self attention
       Tensor n1 = talloc(H, W, C);
@@ -953,11 +987,15 @@ struct dfh_unet {
         gemm8(g);
       } else {
         attention(qk.p, 2 * C, qk.p + C, 2 * C, vt, Np, at.p, C, a.heads, N, N, 0, f8attn);
-        linear(at.p, M, C, a.o1, &a.o1b, ACT_NONE, h0.p, h1.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
+        if (tl) token_linear(at.p, a.tl_o1, v32(a.o1b), h0.p, nullptr, h1.p, true);
+        else linear(at.p, M, C, a.o1, &a.o1b, ACT_NONE, h0.p, h1.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
       }
       // --- cross attention over the T text tokens
       const int Tp = (T + 7) & ~7;
-      if (!try_folded({folded(h1.p, M, a.fq2, st, bn, ACT_NONE, qk.p, OUT_BF16, -1, 0)})) {
+      if (tl && bn > 0 && C % bn == 0) {
+        token_linear(h1.p, a.tl_q2, nullptr, nullptr, &a.fq2, qk.p, false);
+        dfh::census(dfh::CK_LN_FOLDED);
+      } else if (!try_folded({folded(h1.p, M, a.fq2, st, bn, ACT_NONE, qk.p, OUT_BF16, -1, 0)})) {
         if (f8) { layernorm8(h1.p, a.l2w, a.l2b, n8, s8, M, C); linear8(n8, s8, M, a.q28, nullptr, ACT_NONE, qk.p); }
         else {
           layernorm(h1.p, a.l2w, a.l2b, n1.p, M, C);
@@ -974,7 +1012,8 @@ struct dfh_unet {
         gemm8(g);
       } else {
         attention(qk.p, C, kx + a.x_off, XT, vxt + (size_t)a.x_off * Tp, Tp, at.p, C, a.heads, N, T, (long)XT * Tp);
-        linear(at.p, M, C, a.o2, &a.o2b, ACT_NONE, h1.p, h2.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
+        if (tl) token_linear(at.p, a.tl_o2, v32(a.o2b), h1.p, nullptr, h2.p, true);
+        else linear(at.p, M, C, a.o2, &a.o2b, ACT_NONE, h1.p, h2.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
       }
       // --- GEGLU feed-forward
       if (f8x) {
@@ -997,16 +1036,27 @@ struct dfh_unet {
         temp.off = mark;
         return out;
       }
+      // statistics of the block's output for the next GroupNorm, written by the fused kernel's epilogue in 128-token chunks (allocated in the
+      // dry run as well: the unfused path plans 256-token chunks through gemm())
+      const int G = u->cfg.norm_num_groups;
+      const bool mlp_gst_ok = a.has_mlp && N % 128 == 0 && C % G == 0 && N / 128 <= (int)GN_MAX_CHUNKS;
+      float* mlp_gst = mlp_gst_ok ? (float*)persist.alloc((size_t)B * G * (N / 128) * 2 * sizeof(float)) : nullptr;
       Tensor ff = talloc(H, W, 4 * C);
       // the whole feed-forward + proj_out in one kernel where the X tile fits the register file (C = 320: the 64x64 level); needs the row
-      // statistics of h2 from its producer like every folded-LayerNorm consumer.  DFH_MLP_FUSED=0: the two-launch walk (A/B)
-      static const bool mlp_off = [] { const char* e = getenv("DFH_MLP_FUSED"); return e && e[0] == '0'; }();
+      // statistics of h2 from its producer like every folded-LayerNorm consumer.  DFH_MLP_FUSED=0: the two-launch walk, 1 / 2: the two forms of the kernel (A/B)
+      const bool mlp_off = dfh::mlp_fused_form() == 0;
       if (fold && !mlp_off && a.has_mlp && bn > 0 && C % bn == 0 && dfh::mlp_fused_eligible(C, M)) {
         MlpArgs ma; std::memset(&ma, 0, sizeof(ma));
         ma.x = h2.p; ma.resid = x.p; ma.img = (const unsigned char*)(u->fold_w() + a.mlp_img);
         ma.ln_stat = st; ma.ln_parts = C / bn; ma.ln_cnt = bn; ma.ln_eps = 1e-5f;
         ma.bias = u->fold_v() + a.fffp.b; ma.out = out.p; ma.M = M;
-        if (!rc) rc = dfh::mlp_fused_launch(ma, s);
+        static const bool pre_off = [] { const char* e = getenv("DFH_GN_PRE"); return e && e[0] == '0'; }();
+        if (dfh::mlp_fused_form() == 2 && mlp_gst && !pre_off) {
+          ma.gstat = mlp_gst; ma.gstat_cpg = C / G; ma.gstat_hw = N;
+          out.gst = mlp_gst; out.gst_cpg = C / G; out.gst_chunks = N / 128;
+          dfh::census(dfh::CK_GSTAT_WRITTEN);
+        }
+        if (!rc) rc = dfh::mlp_fused_form() == 1 ? dfh::mlp_fused_launch(ma, s) : dfh::mlp2_fused_launch(ma, s);
         dfh::census(dfh::CK_LN_FOLDED);                  // LayerNorm 3 is consumed folded here too
         temp.off = mark;
         return out;

@@ -8,6 +8,7 @@ from difashion_amd import _lib
 import gpu_util as gu
 from gpu_util import bf, rnd
 DEV = "cuda"
+FORM = int(os.environ.get("FORM", 2))
 C, M = 320, 256
 
 def run(tag, zero_hidden=False, zero_wp=False, zero_bias1=False, unit_ln=False, offset=0.0, wscale=0.05):
@@ -26,9 +27,9 @@ def run(tag, zero_hidden=False, zero_wp=False, zero_bias1=False, unit_ln=False, 
     xp = x.float().view(M, parts, cnt).transpose(0, 1); mean_t = xp.mean(-1)
     st = torch.stack([mean_t, ((xp - mean_t[..., None]) ** 2).sum(-1)], dim=-1).contiguous()
     img = torch.empty(_lib.raw().dfh_mlp_fused_image_bytes(), dtype=torch.uint8, device=DEV)
-    _lib.call("dfh_mlp_fused_pack", _lib.ptr(wf), _lib.ptr(s1), _lib.ptr(b1), _lib.ptr(w2p), _lib.ptr(img), gu.stream())
+    _lib.call("dfh_mlp_fused_pack", _lib.ptr(wf), _lib.ptr(s1), _lib.ptr(b1), _lib.ptr(w2p), _lib.ptr(img), FORM, gu.stream())
     out = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
-    _lib.call("dfh_mlp_fused", _lib.ptr(x), _lib.ptr(resid), _lib.ptr(img), _lib.ptr(st), parts, cnt, 1e-5, _lib.ptr(bias), _lib.ptr(out), M, gu.stream())
+    _lib.call("dfh_mlp_fused", _lib.ptr(x), _lib.ptr(resid), _lib.ptr(img), _lib.ptr(st), parts, cnt, 1e-5, _lib.ptr(bias), _lib.ptr(out), M, FORM, None, 0, 0, gu.stream())
     torch.cuda.synchronize()
     ln = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
     hh = ln @ bf(wg).float().T + bg

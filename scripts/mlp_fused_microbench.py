@@ -11,6 +11,7 @@ import gpu_util as gu
 from scripts.gemm_microbench import timeit
 
 DEV = "cuda"
+FORM = int(os.environ.get("FORM", 2))
 C = 320
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 x = (torch.randn(M, C, device=DEV)).bfloat16()
@@ -24,10 +25,10 @@ xp = x.float().view(M, parts, cnt).transpose(0, 1)
 mean_t = xp.mean(-1)
 st = torch.stack([mean_t, ((xp - mean_t[..., None]) ** 2).sum(-1)], dim=-1).contiguous()
 img = torch.empty(_lib.raw().dfh_mlp_fused_image_bytes(), dtype=torch.uint8, device=DEV)
-_lib.call("dfh_mlp_fused_pack", _lib.ptr(wf), _lib.ptr(s1), _lib.ptr(b1), _lib.ptr(w2p), _lib.ptr(img), gu.stream())
+_lib.call("dfh_mlp_fused_pack", _lib.ptr(wf), _lib.ptr(s1), _lib.ptr(b1), _lib.ptr(w2p), _lib.ptr(img), FORM, gu.stream())
 out = torch.empty((M, C), dtype=torch.bfloat16, device=DEV)
 sp = gu.stream()
-fused = lambda: _lib.call("dfh_mlp_fused", _lib.ptr(x), _lib.ptr(resid), _lib.ptr(img), _lib.ptr(st), parts, cnt, 1e-5, _lib.ptr(bias), _lib.ptr(out), M, sp)
+fused = lambda: _lib.call("dfh_mlp_fused", _lib.ptr(x), _lib.ptr(resid), _lib.ptr(img), _lib.ptr(st), parts, cnt, 1e-5, _lib.ptr(bias), _lib.ptr(out), M, FORM, None, 0, 0, sp)
 d1 = gu.gemm_desc(M=M, N=8 * C, W=wf, ldw=C, a0=x, a0_c=C, bias=b1, act=4)
 d2 = gu.gemm_desc(M=M, N=C, W=w2p, ldw=5 * C, a0=d1.keep_out, a0_c=4 * C, a1=x, a1_c=C, bias=bias, resid=resid)
 def two():

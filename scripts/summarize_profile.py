@@ -3,6 +3,7 @@
 import csv, glob, os, sys, collections
 
 root = sys.argv[1]
+dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"      # "fp8": the walk of bench.py --dtype fp8 (pmc_traffic_fp8.json)
 
 
 def find(sub, pat):
@@ -53,11 +54,12 @@ def per_kernel(sub):
     return tot, n
 ft, fn = per_kernel("pmc_fetch")
 wt, wn = per_kernel("pmc_write")
-gem = [k for k in ft if k.startswith("gemm_bf16_kernel") or k.startswith("gemm_wide_kernel")]
+# the dominant family as bench.py defines it: every conv3x3 / 1x1 / linear launch of the bf16 classes (the fused feed-forward kernel included)
+gem = [k for k in ft if k.startswith(("gemm_bf16_kernel", "gemm_wide_kernel", "mlp2_fused_kernel", "mlp_fused_kernel"))]
 if gem:
     launches = sum(fn[k] for k in gem)
     fetch_kb = sum(ft[k] for k in gem); write_kb = sum(wt.get(k, 0) for k in gem)
-    out = dict(kernel="gemm_bf16_kernel + gemm_wide_kernel (all tile variants)", launches=launches,
+    out = dict(kernel="gemm_bf16_kernel + gemm_wide_kernel + mlp2_fused_kernel (all tile variants)", dtype=dtype, launches=launches,
                fetch_size_kb_per_launch=fetch_kb / launches, write_size_kb_per_launch=write_kb / max(1, sum(wn.get(k, 0) for k in gem)),
                correction="gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> x2 (MI355X_MICROARCH.md HBM section); WRITE_SIZE uncorrected",
                hbm_bytes_per_launch=(2 * fetch_kb / launches + write_kb / max(1, sum(wn.get(k, 0) for k in gem))) * 1024)
@@ -67,7 +69,14 @@ if gem:
         out["kernel_source_hash"] = bench.kernel_source_hash()      # bench.py reports this summary only for these exact sources
     except Exception as e:
         out["kernel_source_hash"] = None
-    json.dump(out, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
+    # fp8 walk: the e4m3 class beside it, from the same passes (gemm_fp8_kernel launches)
+    f8 = [k for k in ft if k.startswith("gemm_fp8_kernel")]
+    if f8:
+        n8 = sum(fn[k] for k in f8)
+        out["gemm_fp8_kernel"] = dict(launches=n8, fetch_size_kb_per_launch=sum(ft[k] for k in f8) / n8,
+                                      write_size_kb_per_launch=sum(wt.get(k, 0) for k in f8) / max(1, sum(wn.get(k, 0) for k in f8)),
+                                      hbm_bytes_per_launch=(2 * sum(ft[k] for k in f8) / n8 + sum(wt.get(k, 0) for k in f8) / max(1, sum(wn.get(k, 0) for k in f8))) * 1024)
+    json.dump(out, open(os.path.join(root, "pmc_traffic.json" if dtype == "bf16" else f"pmc_traffic_{dtype}.json"), "w"), indent=1)
 
 # ---- derived per-kernel figures: MFMA-busy %, achieved HBM GB/s (FETCH x2 + WRITE over the traced duration)
 mf = find("pmc_mfma", "*counter_collection.csv")

@@ -1087,11 +1087,13 @@ def test_gemm_fp8_transposed_output():
     gu.assert_close_bf16(out, ref, "fp8 transposed")
 
 
+@pytest.mark.parametrize("form", [1, 2])
 @pytest.mark.parametrize("M,parts,offset", [(128, 2, 0.0), (512, 2, 3.0), (1024, 5, 0.0), (384, 1, 0.0)])
-def test_mlp_fused_matches_torch(M, parts, offset):
+def test_mlp_fused_matches_torch(M, parts, offset, form):
     """dfh_mlp_fused (csrc/mlp_fused.hip): the GEGLU feed-forward + proj_out of a C = 320 transformer block in one kernel,
     out = proj_out(ff.net.2(GEGLU(ff.net.0(LN3(x)))) + x) + resid, against fp32 torch on the same bf16 operands -- and against the
-    two-launch walk it replaces (folded-LayerNorm GEGLU projection, then the [hidden | x] linear).  Row statistics come in the producer's
+    two-launch walk it replaces (folded-LayerNorm GEGLU projection, then the [hidden | x] linear), in both forms of the kernel (32-token
+    waves on the 32x32x16 MFMA, one per SIMD; 16-token waves on the 16x16x32 MFMA, two per SIMD: the walk's default).  Row statistics come in the producer's
     per-column-tile record layout (1, 2 or 5 tiles per row); rows with a common offset (mean >> std) included.  Both intermediate roundings
     of the unfused walk are kept (hidden units to bf16; the output once), so the two paths agree to bf16 accumulation-order noise."""
     import ctypes
@@ -1120,11 +1122,19 @@ def test_mlp_fused_matches_torch(M, parts, offset):
     mean_t = xp.mean(-1)
     st = torch.stack([mean_t, ((xp - mean_t[..., None]) ** 2).sum(-1)], dim=-1).contiguous()
     img = torch.empty(_lib.raw().dfh_mlp_fused_image_bytes(), dtype=torch.uint8, device=DEV)
-    _lib.call("dfh_mlp_fused_pack", _lib.ptr(wf), _lib.ptr(s1), _lib.ptr(b1), _lib.ptr(w2p), _lib.ptr(img), gu.stream())
+    _lib.call("dfh_mlp_fused_pack", _lib.ptr(wf), _lib.ptr(s1), _lib.ptr(b1), _lib.ptr(w2p), _lib.ptr(img), form, gu.stream())
     out = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
-    _lib.call("dfh_mlp_fused", _lib.ptr(x), _lib.ptr(resid), _lib.ptr(img), _lib.ptr(st), parts, cnt, 1e-5, _lib.ptr(bias), _lib.ptr(out), M, gu.stream())
+    # output statistics for a GroupNorm(32) consumer (form 2): images of 128 tokens -> one chunk each
+    G, hw = 32, 128
+    gst = torch.full((M // hw, G, hw // 128, 2), float("nan"), device=DEV) if form == 2 else None
+    _lib.call("dfh_mlp_fused", _lib.ptr(x), _lib.ptr(resid), _lib.ptr(img), _lib.ptr(st), parts, cnt, 1e-5, _lib.ptr(bias), _lib.ptr(out), M, form,
+              _lib.ptr(gst), C // G, hw, gu.stream())
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all()
+    if gst is not None:                       # sums of the ROUNDED outputs, fixed order: tight tolerance
+        og = out.float().view(M // hw, hw, G, C // G)
+        torch.testing.assert_close(gst[:, :, 0, 0], og.sum((1, 3)), rtol=1e-5, atol=1e-3)
+        torch.testing.assert_close(gst[:, :, 0, 1], (og ** 2).sum((1, 3)), rtol=1e-5, atol=1e-3)
     # fp32 torch on the same operands
     ln = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
     hh = ln @ bf(wg).float().T + bg
@@ -1138,3 +1148,41 @@ def test_mlp_fused_matches_torch(M, parts, offset):
     two = gu.gemm(M=M, N=C, W=w2p, ldw=5 * C, a0=dd.keep_out, a0_c=4 * C, a1=x, a1_c=C, bias=bias, resid=resid)
     torch.cuda.synchronize()
     assert gu.rel_err(out, two) < 6e-3, gu.rel_err(out, two)
+
+
+@pytest.mark.parametrize("M,resid,folded", [(128, False, False), (640, True, False), (1024, True, True), (384, False, True)])
+def test_token_linear_matches_torch(M, resid, folded):
+    """dfh_token_linear (csrc/mlp_fused2.hip): the K = N = 320 projections of the 64x64-level transformer blocks with the rows held in
+    registers -- plain (+ bias, + residual) and as a folded-LayerNorm consumer -- against fp32 torch on the same bf16 operands and against
+    dfh_gemm; the per-row statistics it leaves for the NEXT folded consumer (one record per row over all 320 columns) against torch on its
+    own rounded output, and fed back into a second, folded call (producer -> consumer chain as the walk uses it)."""
+    import ctypes
+    C = 320
+    x = bf(rnd(M, C, seed=81) + 1.5)
+    res = bf(rnd(M, C, seed=82) * 2.0) if resid else None
+    w = bf(rnd(C, C, seed=83, scale=0.05))
+    bias = rnd(C, seed=84, scale=0.3)
+    img = torch.empty(_lib.raw().dfh_token_linear_image_bytes(), dtype=torch.uint8, device=DEV)
+    out = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    rs = torch.full((M, 2), float("nan"), device=DEV)
+    if not folded:
+        _lib.call("dfh_token_linear_pack", _lib.ptr(w), C, _lib.ptr(img), gu.stream())
+        _lib.call("dfh_token_linear", _lib.ptr(x), _lib.ptr(img), _lib.ptr(bias), _lib.ptr(res), None, 0, 0, 0.0, None, _lib.ptr(rs), _lib.ptr(out), M, gu.stream())
+        ref = x.float() @ w.float().T + bias + (res.float() if resid else 0)
+    else:
+        gamma, beta = 1.0 + 0.2 * rnd(C, seed=85), 0.3 * rnd(C, seed=86)
+        wf = torch.empty_like(w); s1, b1 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        _lib.call("dfh_ln_fold", _lib.ptr(w), C, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bias), _lib.ptr(wf), _lib.ptr(s1), _lib.ptr(b1), C, C, gu.stream())
+        mean = x.float().mean(-1)
+        st = torch.stack([mean, ((x.float() - mean[:, None]) ** 2).sum(-1)], dim=-1).contiguous()       # one record per row
+        _lib.call("dfh_token_linear_pack", _lib.ptr(wf), C, _lib.ptr(img), gu.stream())
+        _lib.call("dfh_token_linear", _lib.ptr(x), _lib.ptr(img), _lib.ptr(b1), _lib.ptr(res), _lib.ptr(st), 1, C, 1e-5, _lib.ptr(s1), _lib.ptr(rs), _lib.ptr(out), M, gu.stream())
+        ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) @ w.float().T + bias + (res.float() if resid else 0)
+    torch.cuda.synchronize()
+    gu.assert_close_bf16(out, ref, "token linear")
+    o = out.float()
+    torch.testing.assert_close(rs[:, 0], o.mean(-1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rs[:, 1], ((o - o.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=1e-4, atol=1e-4)
+    if not folded:
+        plain = gu.gemm(M=M, N=C, W=w, ldw=C, a0=x, a0_c=C, bias=bias, resid=res)
+        assert gu.rel_err(out, plain) < 4e-3

@@ -189,9 +189,6 @@ SIGNATURES = {
     "dfh_quantize_rows_fp8": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
     "dfh_layernorm_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "dfh_gemm_fp8": (_i, [C.POINTER(Fp8GemmDesc), _vp]),
-    "dfh_token_linear_image_bytes": (_sz, []),
-    "dfh_token_linear_pack": (_i, [_vp, _i, _vp, _vp]),
-    "dfh_token_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
     "dfh_mlp_fused_image_bytes": (_sz, []),
     "dfh_mlp_fused_pack": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "dfh_mlp_fused": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp]),

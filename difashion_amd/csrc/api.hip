@@ -434,29 +434,27 @@ int dfh_gemm_fp8(const dfh_gemm_fp8_desc* d, void* stream) {
 }
 size_t dfh_mlp_fused_image_bytes(void) { return dfh::mlp_fused_image_bytes(); }
 int dfh_mlp_fused_pack(const void* w1, const float* s1, const float* b1, const void* w2p, void* img, int form, void* stream) {
-  DFH_REQUIRE(form == 1 || form == 2, "fused MLP: form 1 or 2");
-  return (form == 1 ? dfh::mlp_pack_launch : dfh::mlp2_pack_launch)((const bf16_t*)w1, s1, b1, (const bf16_t*)w2p, img, (hipStream_t)stream);
+#ifdef DFH_PROBES
+  if (form == 1) return dfh::mlp_pack_launch((const bf16_t*)w1, s1, b1, (const bf16_t*)w2p, img, (hipStream_t)stream);
+#endif
+  DFH_REQUIRE(form == 2, "fused MLP: form 2 (form 1 is a probe kernel: scripts/probes)");
+  return dfh::mlp2_pack_launch((const bf16_t*)w1, s1, b1, (const bf16_t*)w2p, img, (hipStream_t)stream);
 }
 int dfh_mlp_fused(const void* x, const void* resid, const void* img, const float* ln_stat, int ln_parts, int ln_cnt, float ln_eps,
                   const float* bias, void* out, int M, int form, float* gstat, int gstat_cpg, int gstat_hw, void* stream) {
+#ifndef DFH_PROBES
+  DFH_REQUIRE(form == 2, "fused MLP: form 2 (form 1 is a probe kernel: scripts/probes)");
+#endif
   DFH_REQUIRE(form == 1 || form == 2, "fused MLP: form 1 or 2");
   DFH_REQUIRE(gstat == nullptr || form == 2, "fused MLP: output statistics are written by form 2 only");
   MlpArgs a; std::memset(&a, 0, sizeof(a));
   a.gstat = gstat; a.gstat_cpg = gstat_cpg; a.gstat_hw = gstat_hw;
   a.x = (const bf16_t*)x; a.resid = (const bf16_t*)resid; a.img = (const unsigned char*)img; a.ln_stat = ln_stat; a.ln_parts = ln_parts;
   a.ln_cnt = ln_cnt; a.ln_eps = ln_eps; a.bias = bias; a.out = (bf16_t*)out; a.M = M;
-  return form == 1 ? dfh::mlp_fused_launch(a, (hipStream_t)stream) : dfh::mlp2_fused_launch(a, (hipStream_t)stream);
-}
-size_t dfh_token_linear_image_bytes(void) { return dfh::token_linear_image_bytes(); }
-int dfh_token_linear_pack(const void* W, int ldw, void* img, void* stream) {
-  return dfh::token_linear_pack_launch((const bf16_t*)W, ldw, img, (hipStream_t)stream);
-}
-int dfh_token_linear(const void* x, const void* img, const float* bias, const void* resid, const float* ln_stat, int ln_parts, int ln_cnt,
-                     float ln_eps, const float* ln_s, float* rowstat, void* out, int M, void* stream) {
-  TokLinArgs a; std::memset(&a, 0, sizeof(a));
-  a.x = (const bf16_t*)x; a.img = (const unsigned char*)img; a.bias = bias; a.resid = (const bf16_t*)resid; a.ln_stat = ln_stat;
-  a.ln_parts = ln_parts; a.ln_cnt = ln_cnt; a.ln_eps = ln_eps; a.ln_s = ln_s; a.rowstat = rowstat; a.out = (bf16_t*)out; a.M = M;
-  return dfh::token_linear_launch(a, (hipStream_t)stream);
+#ifdef DFH_PROBES
+  if (form == 1) return dfh::mlp_fused_launch(a, (hipStream_t)stream);
+#endif
+  return dfh::mlp2_fused_launch(a, (hipStream_t)stream);
 }
 int dfh_groupnorm_fp8(const void* src, int batch, int HW, int C, int groups, float eps, float q_mul, void* q, float* partial, void* stream) {
   GnArgs a; std::memset(&a, 0, sizeof(a));

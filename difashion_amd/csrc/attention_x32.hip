@@ -911,7 +911,9 @@ int attention_x32_launch(const AttnArgs& a, hipStream_t stream) {
       }
       if (variant == 1) return launch_x32<40, 1, 3>(a, stream);      // experiments: one 32-query block per wave at 3 / 4 waves per SIMD
       if (variant == 2) return launch_x32<40, 1, 4>(a, stream);
-      if (variant == 3) return launch_x32<40, 4, 1>(a, stream);      // four blocks per wave, ONE wave per SIMD: 14 fragment reads per 56 MFMAs, but nothing to overlap the exponentials with: 524 vs 458 us
+      // four blocks per wave, ONE wave per SIMD: 14 fragment reads per 56 MFMAs.  Round 2, plain order: 524 vs 458 us; round 5, with the in-wave
+      // software pipeline of the steady-state tiles (see the kernel): 506 vs 473 us -- a wave does not overlap its own MFMAs with its own VALU issue
+      if (variant == 3 && a.Nq >= 512 && a.Nk >= 128) return launch_x32<40, 4, 1>(a, stream);
       break;
     case 80:
       if (variant == 1) return launch_x32<80, 1, 3>(a, stream);
@@ -920,13 +922,7 @@ int attention_x32_launch(const AttnArgs& a, hipStream_t stream) {
   }
 #endif
   switch (a.D) {
-    case 40: {
-      // DFH_ATTN_QB4: 1 = four query blocks per wave, one wave per SIMD, in-wave software pipeline (see the kernel) for launches with at
-      // least 512 queries; 0 = the two-block kernel at two workgroups per CU
-      static const int qb4 = [] { const char* e = getenv("DFH_ATTN_QB4"); return e ? atoi(e) : 0; }();
-      if (qb4 && a.Nq >= 512 && a.Nk >= 128) return launch_x32<40, 4, 1>(a, stream);
-      return launch_x32<40, 2, 2>(a, stream);
-    }
+    case 40: return launch_x32<40, 2, 2>(a, stream);
     case 64: {
       static const int qb64 = [] { const char* e = getenv("DFH_ATTN_QB64"); return e ? atoi(e) : 2; }();     // probe knob
       return qb64 == 1 ? launch_x32<64, 1, 2>(a, stream) : launch_x32<64, 2, 2>(a, stream);

@@ -23,6 +23,9 @@
 #include "gemm.h"
 #include "gemm_kiter.h"
 #include "gemm_wide_epilogue.h"
+#ifdef DFH_PROBES
+#include "token_linear.h"
+#endif
 
 #include <algorithm>
 #include <cstdlib>
@@ -971,6 +974,12 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
   for (int i = 0; i < a.nplain; ++i) DFH_REQUIRE(a.p_c[i] % 8 == 0, "segment length must be a multiple of 8");
   DFH_REQUIRE(a.zero != nullptr, "zero page missing");
   if (a.rows_per_b <= 0) a.rows_per_b = a.M;
+#ifdef DFH_PROBES
+  if (force_tile == 30) {           // probe kernel: the launch as a register-resident token linear (scripts/probes/kernels/token_linear.hip)
+    if (rowstat_bn && a.rowstat) *rowstat_bn = a.N;
+    return token_linear_from_gemm(a, stream);
+  }
+#endif
   a.ksteps = gemm_count_ksteps(a);
   int tile;
   int split = gemm_pick_split(a, &tile);

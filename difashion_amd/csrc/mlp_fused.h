@@ -16,31 +16,16 @@ struct MlpArgs {
   float* gstat; int gstat_cpg, gstat_hw;
 };
 
-// K = N = 320 token linear on the fused-MLP machinery (mlp_fused2.hip token_linear_kernel)
-struct TokLinArgs {
-  const bf16_t* x;              // [M][320] bf16 rows
-  const unsigned char* img;     // weight image (token_linear_pack_launch)
-  const float* bias;            // [320] or null (b' for a folded-LayerNorm consumer)
-  const bf16_t* resid;          // optional [M][320]
-  const float* ln_stat; int ln_parts, ln_cnt; float ln_eps; const float* ln_s;      // folded-LayerNorm consumer (gemm.h), optional
-  float* rowstat;               // optional: [M][2] = (mean, centred sum of squares) of each ROUNDED output row over its 320 columns
-  bf16_t* out;                  // [M][320]
-  int M;
-};
-
 namespace dfh {
-size_t token_linear_image_bytes();
-bool token_linear_eligible(int N, int K, long M);
-int token_linear_pack_launch(const bf16_t* W, int ldw, void* img, hipStream_t stream);
-int token_linear_launch(const TokLinArgs& a, hipStream_t stream);
 size_t mlp_fused_image_bytes();
 bool mlp_fused_eligible(int C, long M);
 // w1 / s1 / b1: the LayerNorm-folded GEGLU projection ([8 C][C] bf16, packed rows) and its fold vectors; w2p: [C][5 C] = [pout . ff2 | pout]
 int mlp_pack_launch(const bf16_t* w1, const float* s1, const float* b1, const bf16_t* w2p, void* img, hipStream_t stream);
 int mlp_fused_launch(const MlpArgs& a, hipStream_t stream);
-// second form (mlp_fused2.hip): eight waves of 16 tokens, two per SIMD; same arguments, its own image layout (same size)
+// the kernel (mlp_fused2.hip): eight waves of 16 tokens, two per SIMD.  (mlp_pack_launch / mlp_fused_launch above: the first form, four waves
+// of 32 tokens -- scripts/probes/kernels/mlp_fused_v1.hip, probe builds only; same arguments, its own image layout of the same size)
 int mlp2_pack_launch(const bf16_t* w1, const float* s1, const float* b1, const bf16_t* w2p, void* img, hipStream_t stream);
 int mlp2_fused_launch(const MlpArgs& a, hipStream_t stream);
-// which form the walk uses: DFH_MLP_FUSED = 0 (the two-launch walk), 1 (32-token waves), 2 (16-token waves, default)
+// which path the walk uses: DFH_MLP_FUSED = 0 (the two-launch walk, A/B), 2 (the kernel, default), 1 (the first form: probe builds only)
 int mlp_fused_form();
 }  // namespace dfh

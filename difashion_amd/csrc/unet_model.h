@@ -14,6 +14,9 @@
 #include "elementwise.h"
 #include "gemm.h"
 #include "mlp_fused.h"
+#ifdef DFH_PROBES
+#include "token_linear.h"
+#endif
 #include "norm.h"
 #include "packtab.h"
 #include "bwd_elementwise.h"
@@ -321,10 +324,12 @@ struct dfh_unet {
       a.has_mlp = true; a.mlp_img = fold16;
       fold16 += (dfh::mlp_fused_image_bytes() / 2 + 127) & ~(size_t)127;
     }
+#ifdef DFH_PROBES
     if (dfh::token_linear_eligible(C, C, 128)) {
       a.has_tl = true;
       for (size_t* o : {&a.tl_pin, &a.tl_o1, &a.tl_q2, &a.tl_o2}) { *o = fold16; fold16 += (dfh::token_linear_image_bytes() / 2 + 127) & ~(size_t)127; }
     }
+#endif
   }
 
   void build_conv(const std::string& pre, int cout, int cin, ConvL& c) {
@@ -541,6 +546,7 @@ struct dfh_unet {
                                          fold_w() + dst[i]->w, fold_v() + dst[i]->s, fold_v() + dst[i]->b, src[i]->N, src[i]->K, s)) return rc;
       }
     }
+#ifdef DFH_PROBES
     for (AttL* a : all_att()) {
       static const bool tl_on = [] { const char* e = getenv("DFH_TOKEN_LINEAR"); return e && e[0] == '1'; }();
       if (!tl_on || !a->has_tl || (fp8 && a->qk8.on)) continue;
@@ -550,6 +556,7 @@ struct dfh_unet {
       if (int rc = dfh::token_linear_pack_launch(fold_w() + a->fq2.w, C, fold_w() + a->tl_q2, s)) return rc;
       if (int rc = dfh::token_linear_pack_launch(arena16 + a->o2.off, a->o2.K, fold_w() + a->tl_o2, s)) return rc;
     }
+#endif
     {
       std::vector<ResL*> rs;
       for (auto& lv : down_res) for (auto& r : lv) rs.push_back(&r);
@@ -587,7 +594,11 @@ struct dfh_unet {
       if (int rc = dfh::matvec_bias_launch(arena16 + a->pout.off, C, arena32 + a->ff2b.off, arena32 + a->poutb.off,
                                            fold_v() + a->fffp.b, C, C, s)) return rc;
       if (a->has_mlp && dfh::mlp_fused_form() > 0) {     // the fused feed-forward's weight image from the two folded matrices just derived
+#ifdef DFH_PROBES
         auto pack = dfh::mlp_fused_form() == 1 ? dfh::mlp_pack_launch : dfh::mlp2_pack_launch;
+#else
+        auto pack = dfh::mlp2_pack_launch;
+#endif
         if (int rc = pack(fold_w() + a->fff1.w, fold_v() + a->fff1.s, fold_v() + a->fff1.b, fold_w() + a->fffp.w, fold_w() + a->mlp_img, s)) return rc;
       }
     }
@@ -907,12 +918,13 @@ struct dfh_unet {
         return true;
       };
       // the K = N = C projections of a C = 320 block on the register-resident token-linear kernel (mlp_fused2.hip); DFH_TOKEN_LINEAR=0: dfh_gemm (A/B)
-      // OPT-IN (DFH_TOKEN_LINEAR=1): parity-tested, but measured slower than the tile GEMM here -- 37 / 46 us against 27 / 34 us per launch at
-      // M = 65536, sampling step 15.7 -> 15.9 ms (profiles/r05/token_linear_ab.txt): one workgroup per CU leaves its prologue (row loads,
-      // first weight slice) and epilogue exposed twice per launch, and every 128-token tile re-streams the whole 200-KB matrix
+      // PROBE builds only (DFH_TOKEN_LINEAR=1 with the probe library): the K = N = C projections on the register-resident token-linear kernel
+      // (scripts/probes/kernels/token_linear.hip).  Parity-tested, measured slower than the tile GEMM here -- 37 / 46 us against 27 / 34 us per
+      // launch at M = 65536, sampling step 15.7 -> 15.9 ms (profiles/r05/token_linear_ab.txt): one workgroup per CU leaves its prologue (row
+      // loads, first weight slice) and epilogue exposed twice per launch, and every 128-token tile re-streams the whole 200-KB matrix
+#ifdef DFH_PROBES
       static const bool tl_on = [] { const char* e = getenv("DFH_TOKEN_LINEAR"); return e && e[0] == '1'; }();
       const bool tl = fold && tl_on && a.has_tl && dfh::token_linear_eligible(C, C, M);
-      // x: rows, img: weight image, bias / resid as dfh_gemm; folded: f's s / b' with the current statistics; leaves the output's row statistics in st
       auto token_linear = [&](const bf16_t* xin, size_t img, const float* bias, const bf16_t* resid, const Fold* f, bf16_t* o, bool stats) {
         if (rc) return;
         TokLinArgs t; std::memset(&t, 0, sizeof(t));
@@ -922,6 +934,10 @@ struct dfh_unet {
         rc = dfh::token_linear_launch(t, s);
         if (stats) bn = C;                            // one record per row over all C columns
       };
+#else
+      constexpr bool tl = false;
+      auto token_linear = [](const bf16_t*, size_t, const float*, const bf16_t*, const Fold*, bf16_t*, bool) {};
+#endif
       Tensor h0 = talloc(H, W, C);
       uint8_t* a8 = f8x ? (uint8_t*)temp.alloc((size_t)M * C) : nullptr;          // e4m3 operand of proj_in, then of the two to_out
       float* am_self = f8x ? amax_self + (size_t)a.idx * B : nullptr;
@@ -1056,7 +1072,10 @@ struct dfh_unet {
           out.gst = mlp_gst; out.gst_cpg = C / G; out.gst_chunks = N / 128;
           dfh::census(dfh::CK_GSTAT_WRITTEN);
         }
-        if (!rc) rc = dfh::mlp_fused_form() == 1 ? dfh::mlp_fused_launch(ma, s) : dfh::mlp2_fused_launch(ma, s);
+#ifdef DFH_PROBES
+        if (!rc && dfh::mlp_fused_form() == 1) rc = dfh::mlp_fused_launch(ma, s); else
+#endif
+        if (!rc) rc = dfh::mlp2_fused_launch(ma, s);
         dfh::census(dfh::CK_LN_FOLDED);                  // LayerNorm 3 is consumed folded here too
         temp.off = mark;
         return out;

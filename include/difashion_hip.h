@@ -351,23 +351,13 @@ int dfh_gemm_fp8(const dfh_gemm_fp8_desc* d, void* stream);
  *   dfh_mlp_fused      : x / resid / out [M][320] bf16, M a multiple of 128; ln_stat = per-row statistics of x ([ln_parts][M][2]: mean
  *                        and centred sum of squares per column tile of ln_cnt columns, as dfh_gemm's row statistics) */
 size_t dfh_mlp_fused_image_bytes(void);
-/* form: 1 = four waves of 32 tokens (v_mfma_f32_32x32x16_bf16, one wave per SIMD), 2 = eight waves of 16 tokens (v_mfma_f32_16x16x32_bf16, two
- * per SIMD: the walk's default); an image packed for one form is only valid for that form */
+/* form: 2 = the kernel (eight waves of 16 tokens on v_mfma_f32_16x16x32_bf16, two per SIMD).  1 = its first form (four waves of 32 tokens, one per
+ * SIMD) exists in the probe library only (scripts/probes); an image packed for one form is only valid for that form */
 int dfh_mlp_fused_pack(const void* w1, const float* s1, const float* b1, const void* w2p, void* img, int form, void* stream);
 /* gstat (form 2, may be NULL): GroupNorm statistics of out for its consumer, [image][320 / gstat_cpg][gstat_hw / 128][2] = (sum, sum of squares) of
  * the bf16-rounded outputs per (image of gstat_hw tokens, group of gstat_cpg channels, 128-token chunk) */
 int dfh_mlp_fused(const void* x, const void* resid, const void* img, const float* ln_stat, int ln_parts, int ln_cnt, float ln_eps,
                   const float* bias, void* out, int M, int form, float* gstat, int gstat_cpg, int gstat_hw, void* stream);
-/* K = N = 320 token linear on the fused-MLP machinery (csrc/mlp_fused2.hip token_linear_kernel): out = x . W^T (+ bias) (+ resid), the rows held in
- * registers, the weights as a fragment-major image (dfh_token_linear_pack; dfh_token_linear_image_bytes() bytes).  Replaces dfh_gemm for the
- * proj_in / to_out / cross-attention-query projections of the 64x64-level transformer blocks (diffusers Transformer2DModel.proj_in,
- * Attention.to_out[0], Attention.to_q; reference call site DiFashion/models/difashion.py:518-523).  Optional: a folded-LayerNorm consumer
- * (ln_stat / ln_parts / ln_cnt / ln_eps / ln_s as dfh_gemm_ln, bias = b'), a residual, and rowstat [M][2] = (mean, centred sum of squares)
- * of every rounded output row over its 320 columns (ONE record per row: consumers pass ln_parts = 1, ln_cnt = 320).  M a multiple of 128. */
-size_t dfh_token_linear_image_bytes(void);
-int dfh_token_linear_pack(const void* W, int ldw, void* img, void* stream);
-int dfh_token_linear(const void* x, const void* img, const float* bias, const void* resid, const float* ln_stat, int ln_parts, int ln_cnt,
-                     float ln_eps, const float* ln_s, float* rowstat, void* out, int M, void* stream);
 int dfh_groupnorm_fp8(const void* src, int batch, int HW, int C, int groups, float eps, float q_mul, void* q, float* partial, void* stream);
 int dfh_attention_fp8out(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O8, int ldo, const float* v_amax,
                          int batch, int heads, int head_dim, int Nq, int Nk, float scale, void* stream);

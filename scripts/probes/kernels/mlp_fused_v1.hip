@@ -1,3 +1,7 @@
+// PROBE kernel: the FIRST form of the fused feed-forward (four waves of 32 tokens, one per SIMD).  Lost its A/B against the second form
+// (difashion_amd/csrc/mlp_fused2.hip): 265 vs 239 us per launch in isolation, equal inside the step (profiles/r05/mlp_fused_forms_*.txt).  Kept as the
+// measurement of what ONE wave per SIMD can overlap (nothing: an iteration cost the sum of its MFMA and its other issue cycles).
+//
 // The GEGLU feed-forward of a transformer block as ONE kernel (C = 320: the 64x64 level of the SD U-Nets):
 //
 //     out = proj_out( ff.net.2( GEGLU( ff.net.0( LayerNorm3(x) ) ) ) + x ) + resid
@@ -321,12 +325,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(const MlpArgs a) {
 
 namespace dfh {
 
-size_t mlp_fused_image_bytes() { return (size_t)IMG_BYTES; }
-int mlp_fused_form() {
-  static const int form = [] { const char* e = getenv("DFH_MLP_FUSED"); return e ? atoi(e) : 2; }();
-  return form;
-}
-bool mlp_fused_eligible(int C, long M) { return C == MC && M > 0 && M % 128 == 0; }
 
 int mlp_pack_launch(const bf16_t* w1, const float* s1, const float* b1, const bf16_t* w2p, void* img, hipStream_t stream) {
   DFH_REQUIRE(w1 && s1 && b1 && w2p && img, "null argument");

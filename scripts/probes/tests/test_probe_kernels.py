@@ -96,3 +96,42 @@ def test_geglu_persistent_rows_kernel_is_bit_identical(M, C, fold, monkeypatch):
     assert torch.equal(out, one), "persistent kernel differs from the one-tile-per-workgroup kernel"
     a, gate = h.chunk(2, -1)
     gu.assert_close_bf16(out, a * F.gelu(gate), "geglu rows", rel=8e-3 if fold else 6e-3)
+
+
+@pytest.mark.parametrize("M,resid,folded", [(128, False, False), (640, True, False), (1024, True, True), (384, False, True)])
+def test_token_linear_matches_torch(M, resid, folded):
+    """token_linear.hip (tile id 30 of dfh_gemm / dfh_gemm_ln): the K = N = 320 projections of the 64x64-level transformer blocks with the
+    rows held in registers -- plain (+ bias, + residual) and as a folded-LayerNorm consumer -- against fp32 torch on the same bf16 operands
+    and against the tile GEMM; the per-row statistics it leaves for the next folded consumer (ONE record per row over all 320 columns)
+    against torch on its own rounded output."""
+    import ctypes
+    C = 320
+    x = bf(rnd(M, C, seed=81) + 1.5)
+    res = bf(rnd(M, C, seed=82) * 2.0) if resid else None
+    w = bf(rnd(C, C, seed=83, scale=0.05))
+    bias = rnd(C, seed=84, scale=0.3)
+    rs = torch.full((M, 2), float("nan"), device=DEV)
+    bn = ctypes.c_int(0)
+    if not folded:
+        d = gu.gemm_desc(M=M, N=C, W=w, ldw=C, a0=x, a0_c=C, bias=bias, resid=res, force_tile=30)
+        _lib.call("dfh_gemm_ln", ctypes.byref(d), _lib.ptr(rs), ctypes.byref(bn), None, 0, 0, 0.0, None, gu.stream())
+        ref = x.float() @ w.float().T + bias + (res.float() if resid else 0)
+    else:
+        gamma, beta = 1.0 + 0.2 * rnd(C, seed=85), 0.3 * rnd(C, seed=86)
+        wf = torch.empty_like(w); s1, b1 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        _lib.call("dfh_ln_fold", _lib.ptr(w), C, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bias), _lib.ptr(wf), _lib.ptr(s1), _lib.ptr(b1), C, C, gu.stream())
+        mean = x.float().mean(-1)
+        st = torch.stack([mean, ((x.float() - mean[:, None]) ** 2).sum(-1)], dim=-1).contiguous()       # one record per row
+        d = gu.gemm_desc(M=M, N=C, W=wf, ldw=C, a0=x, a0_c=C, bias=b1, resid=res, force_tile=30)
+        _lib.call("dfh_gemm_ln", ctypes.byref(d), _lib.ptr(rs), ctypes.byref(bn), _lib.ptr(st), 1, C, 1e-5, _lib.ptr(s1), gu.stream())
+        ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) @ w.float().T + bias + (res.float() if resid else 0)
+    torch.cuda.synchronize()
+    out = d.keep_out
+    assert bn.value == C
+    gu.assert_close_bf16(out, ref, "token linear")
+    o = out.float()
+    torch.testing.assert_close(rs[:, 0], o.mean(-1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rs[:, 1], ((o - o.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=1e-4, atol=1e-4)
+    if not folded:
+        plain = gu.gemm(M=M, N=C, W=w, ldw=C, a0=x, a0_c=C, bias=bias, resid=res)
+        assert gu.rel_err(out, plain) < 4e-3

@@ -3,6 +3,8 @@ references on identical (bf16-rounded) operands.  Tolerances are stated per test
 import ctypes as C
 import math
 
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -1097,6 +1099,8 @@ def test_mlp_fused_matches_torch(M, parts, offset, form):
     per-column-tile record layout (1, 2 or 5 tiles per row); rows with a common offset (mean >> std) included.  Both intermediate roundings
     of the unfused walk are kept (hidden units to bf16; the output once), so the two paths agree to bf16 accumulation-order noise."""
     import ctypes
+    if form == 1 and "probes" not in os.environ.get("DFH_LIB", ""):
+        pytest.skip("form 1 is a probe kernel (scripts/probes): needs DFH_LIB=<probe library>")
     C = 320
     x = bf(rnd(M, C, seed=71) + offset)
     resid = bf(rnd(M, C, seed=72))
@@ -1148,41 +1152,3 @@ def test_mlp_fused_matches_torch(M, parts, offset, form):
     two = gu.gemm(M=M, N=C, W=w2p, ldw=5 * C, a0=dd.keep_out, a0_c=4 * C, a1=x, a1_c=C, bias=bias, resid=resid)
     torch.cuda.synchronize()
     assert gu.rel_err(out, two) < 6e-3, gu.rel_err(out, two)
-
-
-@pytest.mark.parametrize("M,resid,folded", [(128, False, False), (640, True, False), (1024, True, True), (384, False, True)])
-def test_token_linear_matches_torch(M, resid, folded):
-    """dfh_token_linear (csrc/mlp_fused2.hip): the K = N = 320 projections of the 64x64-level transformer blocks with the rows held in
-    registers -- plain (+ bias, + residual) and as a folded-LayerNorm consumer -- against fp32 torch on the same bf16 operands and against
-    dfh_gemm; the per-row statistics it leaves for the NEXT folded consumer (one record per row over all 320 columns) against torch on its
-    own rounded output, and fed back into a second, folded call (producer -> consumer chain as the walk uses it)."""
-    import ctypes
-    C = 320
-    x = bf(rnd(M, C, seed=81) + 1.5)
-    res = bf(rnd(M, C, seed=82) * 2.0) if resid else None
-    w = bf(rnd(C, C, seed=83, scale=0.05))
-    bias = rnd(C, seed=84, scale=0.3)
-    img = torch.empty(_lib.raw().dfh_token_linear_image_bytes(), dtype=torch.uint8, device=DEV)
-    out = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
-    rs = torch.full((M, 2), float("nan"), device=DEV)
-    if not folded:
-        _lib.call("dfh_token_linear_pack", _lib.ptr(w), C, _lib.ptr(img), gu.stream())
-        _lib.call("dfh_token_linear", _lib.ptr(x), _lib.ptr(img), _lib.ptr(bias), _lib.ptr(res), None, 0, 0, 0.0, None, _lib.ptr(rs), _lib.ptr(out), M, gu.stream())
-        ref = x.float() @ w.float().T + bias + (res.float() if resid else 0)
-    else:
-        gamma, beta = 1.0 + 0.2 * rnd(C, seed=85), 0.3 * rnd(C, seed=86)
-        wf = torch.empty_like(w); s1, b1 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
-        _lib.call("dfh_ln_fold", _lib.ptr(w), C, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(bias), _lib.ptr(wf), _lib.ptr(s1), _lib.ptr(b1), C, C, gu.stream())
-        mean = x.float().mean(-1)
-        st = torch.stack([mean, ((x.float() - mean[:, None]) ** 2).sum(-1)], dim=-1).contiguous()       # one record per row
-        _lib.call("dfh_token_linear_pack", _lib.ptr(wf), C, _lib.ptr(img), gu.stream())
-        _lib.call("dfh_token_linear", _lib.ptr(x), _lib.ptr(img), _lib.ptr(b1), _lib.ptr(res), _lib.ptr(st), 1, C, 1e-5, _lib.ptr(s1), _lib.ptr(rs), _lib.ptr(out), M, gu.stream())
-        ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) @ w.float().T + bias + (res.float() if resid else 0)
-    torch.cuda.synchronize()
-    gu.assert_close_bf16(out, ref, "token linear")
-    o = out.float()
-    torch.testing.assert_close(rs[:, 0], o.mean(-1), rtol=1e-5, atol=1e-5)
-    torch.testing.assert_close(rs[:, 1], ((o - o.mean(-1, keepdim=True)) ** 2).sum(-1), rtol=1e-4, atol=1e-4)
-    if not folded:
-        plain = gu.gemm(M=M, N=C, W=w, ldw=C, a0=x, a0_c=C, bias=bias, resid=res)
-        assert gu.rel_err(out, plain) < 4e-3

@@ -11,11 +11,12 @@ struct WgradArgs {
   const bf16_t* zero;
   int M, N;
   float* dW; int ldw;            // fp32 [N][ldw] in the PACKED weight layout, accumulated (+=)
-  float* partial; size_t partial_cap;   // fp32 slabs [msplit][N][ktot] when the pixels are split (wgrad_partial_floats)
+  float* partial; size_t partial_cap;   // fp32 slab slots of 160 x 160 floats, one per partial piece (wgrad_partial_floats)
   int ktot;                      // filled by the launcher: total K of the call
   int overwrite;                 // 1: dW = ... instead of += (the caller guarantees this launch is the only writer)
   float* dbias;                  // optional fp32 [N]: += column sums of dY (bias gradient), fused into the same pass
-  int msplit;                    // 0 = heuristic
+  int msplit;                    // 0 = heuristic; n > 0: n equal pixel slices of every tile; -n: whole tiles in full rounds of 512 blocks, the rest in n slices
+  int whole;                     // filled by the launcher: the first `whole` tiles are not sliced (wgrad.hip)
   int xblocks;                   // filled by the launcher: n-tiles x kcol-chunks
   // one PHASE PLANE of a nearest-2x upsample + 3x3 conv (gemm.h GemmArgs::phase2x): ntaps = 4, stride 1 over the SOURCE image, segment s =
   // the 3x3-tap position (tap_py + (s >> 1), tap_px + (s & 1)); dY = the plane's rows of the output gradient (gathered phase-major);

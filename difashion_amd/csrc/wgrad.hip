@@ -52,51 +52,45 @@ DFH_DEVICE int fdiv(int x, int d, float inv) {
   return q;
 }
 
-// POW2: Hout and Wout are powers of two (every level of the U-Net): pixel decode by shifts instead of divisions
+// One output tile of the launch: bx = n-tile + ntn * chunk.  Conv chunks are enumerated channel-major (chunk = channel_chunk * 9 + tap): a
+// contiguous chunk range -- what one XCD gets when there is a single m-slice -- then re-reads ONE 160-channel slice of the activation under
+// nine shifts (L2-resident) instead of all channels.
+struct WgTile { int n0, chunk, seg, c0, wcol, seglen; };
+DFH_DEVICE WgTile wg_tile(const WgradArgs& a, int bx) {
+  WgTile t;
+  const int ntn = (a.N + TN - 1) / TN;
+  t.n0 = (bx % ntn) * TN;
+  t.chunk = bx / ntn;
+  int base, kc = t.chunk;
+  const int cchunks = (a.conv_c + TK - 1) / TK;
+  if (kc < a.ntaps * cchunks) {
+    t.seg = kc % a.ntaps; kc /= a.ntaps; t.seglen = a.conv_c; base = t.seg * a.conv_c;
+  } else {
+    kc -= a.ntaps * cchunks; t.seg = a.ntaps; base = a.ntaps * a.conv_c; t.seglen = a.p_c[0];
+    const int n0c = (t.seglen + TK - 1) / TK;
+    if (a.nplain > 1 && kc >= n0c) { kc -= n0c; base += t.seglen; t.seglen = a.p_c[1]; t.seg = a.ntaps + 1; }
+  }
+  t.c0 = kc * TK; t.wcol = base + t.c0;
+  return t;
+}
+// fp32 slabs are TILE-LOCAL: slot [40 kcol quads][160 n] float4, so that the 16 lanes of an MFMA column group store 256 contiguous bytes
+constexpr int SLOT_FLOATS = TN * TK;
+
+// One PIECE of the launch: rows [m_begin, m_end) of output tile bx, accumulated over the pixels and stored either into the fp32 slab slot
+// `slab` or (slab == nullptr) straight into dW.  POW2: Hout and Wout are powers of two (every level of the U-Net): pixel decode by shifts.
 template <bool POW2>
-__global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+DFH_DEVICE void wgrad_piece(const WgradArgs& a, unsigned char* smem, const int bx, const int m_begin, const int m_end, float* slab) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = lane & 15, fg = lane >> 4;
   const int wave_n = wave & 1, wave_k = wave >> 1;
-
-  // ---- block -> (x = n-tile + ntn * chunk, z = m-slice), XCD-aware.  Workgroups go round-robin over the 8 XCDs
-  // (linear id % 8), each with its own L2.  Blocks of one m-slice read the SAME rows of dY and A, so a whole slice is
-  // placed on one XCD (its re-reads become L2 hits instead of 8 fabric fetches); with a single slice the x range is cut
-  // into 8 contiguous chunk ranges instead (an A chunk is then fetched by one XCD only).
-  const int ntn = (a.N + TN - 1) / TN;
-  const int X = a.xblocks;
-  int bx, bz;
-  {
-    const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
-    if ((a.msplit & 7) == 0) { const int zi = j / X; bx = j - zi * X; bz = zi * 8 + xcd; }
-    else if (a.msplit == 1 && (X & 7) == 0) { bx = xcd * (X >> 3) + j; bz = 0; }
-    else { bz = id / X; bx = id - bz * X; }
-  }
-  const int n0 = (bx % ntn) * TN;
-  const int chunk = bx / ntn;
-  // locate the chunk: (segment, channel offset, packed column).  Conv chunks are enumerated channel-major
-  // (chunk = channel_chunk * 9 + tap): a contiguous chunk range -- what one XCD gets when there is a single m-slice --
-  // then re-reads ONE 160-channel slice of the activation under nine shifts (L2-resident) instead of all channels.
-  int seg, base, kc = chunk, seglen;
-  const int cchunks = (a.conv_c + TK - 1) / TK;
-  if (kc < a.ntaps * cchunks) {
-    seg = kc % a.ntaps; kc /= a.ntaps; seglen = a.conv_c; base = seg * a.conv_c;
-  } else {
-    kc -= a.ntaps * cchunks; seg = a.ntaps; base = a.ntaps * a.conv_c; seglen = a.p_c[0];
-    const int n0c = (seglen + TK - 1) / TK;
-    if (a.nplain > 1 && kc >= n0c) { kc -= n0c; base += seglen; seglen = a.p_c[1]; seg = a.ntaps + 1; }
-  }
-  const int c0 = kc * TK, wcol = base + c0;
+  const WgTile tl = wg_tile(a, bx);
+  const int n0 = tl.n0, chunk = tl.chunk, seg = tl.seg, c0 = tl.c0, wcol = tl.wcol, seglen = tl.seglen;
   const bool conv = seg < a.ntaps;
   // tap2 (phase plane (py, px) of an upsample conv, wgrad.h): the four segments are the 3x3-tap positions (py + (s >> 1), px + (s & 1))
   const int ky = conv ? (a.tap2 ? a.tap_py + (seg >> 1) : seg / 3) : 0, kx = conv ? (a.tap2 ? a.tap_px + (seg & 1) : seg - (seg / 3) * 3) : 0;
   const bf16_t* psrc = conv ? a.conv_src : (seg == a.ntaps ? a.p_src[0] : a.p_src[1]);
   const int pc = seglen;
-
-  const int m_per = (((a.M + a.msplit - 1) / a.msplit) + BM - 1) / BM * BM;
-  const int m_begin = bz * m_per, m_end = min(a.M, m_begin + m_per);
   const int nsteps = m_end > m_begin ? (m_end - m_begin + BM - 1) / BM : 0;
 
   const int HWo = a.Hout * a.Wout;
@@ -228,9 +222,21 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradArgs a) {
       if (n < a.N) atomicAdd(a.dbias + n, accb[nf][0]);      // N x msplit atomics per layer: negligible
     }
   }
-  // a lane ends with 4 consecutive packed columns of one output channel: one 16-byte access.  A single m-slice adds
-  // straight into dW (each element belongs to exactly one block); several slices write fp32 slabs that
-  // wgrad_reduce_kernel sums in a fixed order (deterministic; scalar fp32 atomics cap out near 70 G/s on this part)
+  // a lane ends with 4 consecutive packed columns of one output channel: one 16-byte access.  A piece that covers all the pixels of its
+  // tile adds straight into dW (each element belongs to exactly one piece); the others write fp32 slab slots that wgrad_reduce_kernel
+  // sums in a fixed order (deterministic; scalar fp32 atomics cap out near 70 G/s on this part)
+  if (slab) {
+#pragma unroll
+    for (int nf = 0; nf < 5; ++nf) {
+      const int nl = wave_n * 80 + nf * 16 + L;
+#pragma unroll
+      for (int kf = 0; kf < 5; ++kf) {
+        const int kq = wave_k * 20 + kf * 4 + fg;          // padding rows / columns hold exact zeros (zero-page loads)
+        *(float4*)(slab + ((long)kq * TN + nl) * 4) = float4{acc[kf][nf][0], acc[kf][nf][1], acc[kf][nf][2], acc[kf][nf][3]};
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int nf = 0; nf < 5; ++nf) {
     const int n = n0 + wave_n * 80 + nf * 16 + L;
@@ -240,33 +246,54 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradArgs a) {
       const int kcol = wave_k * 80 + kf * 16 + fg * 4;
       if (c0 + kcol >= seglen) continue;               // segment lengths are multiples of 8: all four or none
       const float4 v = float4{acc[kf][nf][0], acc[kf][nf][1], acc[kf][nf][2], acc[kf][nf][3]};
-      if (a.msplit > 1) {
-        *(float4*)(a.partial + ((long)bz * a.N + n) * a.ktot + wcol + kcol) = v;
-      } else {
-        float4* dst = (float4*)(a.dW + (long)n * a.ldw + wcol + kcol);
-        if (a.overwrite) { *dst = v; continue; }
-        float4 o = *dst;
-        o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
-        *dst = o;
-      }
+      float4* dst = (float4*)(a.dW + (long)n * a.ldw + wcol + kcol);
+      if (a.overwrite) { *dst = v; continue; }
+      float4 o = *dst;
+      o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+      *dst = o;
     }
   }
 }
 
-// dW[n][k] += sum_z slab[z][n][k]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int N, int ktot,
-                                                           int ldw, int msplit, int overwrite) {
-  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  const long total = (long)N * ktot;
-  if (i >= total) return;
-  const int n = (int)(i / ktot), k = (int)(i - (long)n * ktot);
-  float4 s = *(const float4*)(partial + i);
-  for (int z = 1; z < msplit; ++z) {
-    const float4 p = *(const float4*)(partial + (long)z * total + i);
+// The launch as a grid of pieces: the first a.whole tiles (0 or a multiple of 512, the chip's block slots) as one block each over all the
+// pixels, the remaining tiles as a.msplit equal pixel slices each.  XCD-aware within both groups: workgroups go round-robin over the 8 XCDs
+// (linear id % 8), each with its own L2, and blocks of one m-slice read the SAME rows of dY and A, so the blocks an XCD receives are a
+// CONTIGUOUS range of the (slice, tile) order -- one or two slices sweep through an L2 together, for any slice count (round 5: the count
+// used to be 1 or a multiple of 8, which left e.g. 36 tiles x 8 slices = 288 of the 512 slots filled), and with one slice an XCD gets a
+// contiguous chunk range (one 160-channel slice of the activation under nine shifts).  The whole / tail split is for the deep levels, where
+// there are a few more tiles than slots but few pixels (576 tiles x 64..256 stages = 1.125 rounds of whole-tile blocks: the last 64 tiles
+// go as 8 slices each, 512 short blocks, 1.125 rounds of WORK).  A stream-K decomposition of the same launches (persistent workgroups over
+// tile-major stage ranges) measured slower on every shape but one: its workgroups sweep different pixel rows at the same time, so nothing
+// is shared through L2 (profiles/r05/wgrad_plan_sweep_streamk.txt, wgrad_streamk_experiment.patch).
+template <bool POW2>
+__global__ __launch_bounds__(256, 2) void gemm_wgrad_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int id = blockIdx.x, nblk = a.whole, first = 0, X = a.whole, ms = 1;
+  if (id >= a.whole) { id -= a.whole; nblk = gridDim.x - a.whole; first = a.whole; X = a.xblocks - a.whole; ms = a.msplit; }
+  const int xcd = id & 7, j = id >> 3;                            // a.whole is a multiple of 8: id % 8 is still the XCD
+  const int g = xcd * (nblk >> 3) + min(xcd, nblk & 7) + j;       // position in the XCD-contiguous order
+  const int bz = g / X, bx = g - bz * X;
+  const int m_per = (((a.M + ms - 1) / ms) + BM - 1) / BM * BM;
+  const int m_begin = bz * m_per, m_end = min(a.M, m_begin + m_per);
+  wgrad_piece<POW2>(a, smem, first + bx, m_begin, m_end, ms > 1 ? a.partial + ((long)bz * X + bx) * SLOT_FLOATS : nullptr);
+}
+
+// dW tile (+)= sum of the tile's slab slots, in slice order.  grid (sliced tiles, 25): a block covers 8 kcol quads x 32 n of the tile-local
+// slot layout (512-byte reads per quad row, 128-byte writes per output channel).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
+  const int X = a.xblocks - a.whole, bx = blockIdx.x;
+  const WgTile tl = wg_tile(a, a.whole + bx);
+  const int kq = (blockIdx.y % 5) * 8 + (threadIdx.x & 7), nl = (blockIdx.y / 5) * 32 + (threadIdx.x >> 3);
+  const int n = tl.n0 + nl, kcol = kq * 4;
+  if (n >= a.N || tl.c0 + kcol >= tl.seglen) return;
+  const float* src = a.partial + (long)bx * SLOT_FLOATS + ((long)kq * TN + nl) * 4;
+  float4 s = float4{0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < a.msplit; ++z) {
+    const float4 p = *(const float4*)(src + (long)z * X * SLOT_FLOATS);
     s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
   }
-  float4* dst = (float4*)(dW + (long)n * ldw + k);
-  if (overwrite) { *dst = s; return; }
+  float4* dst = (float4*)(a.dW + (long)n * a.ldw + tl.wcol + kcol);
+  if (a.overwrite) { *dst = s; return; }
   float4 o = *dst;
   o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
   *dst = o;
@@ -318,47 +345,60 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 
 namespace dfh {
 
+// Block slots of the chip for this kernel: 256 CUs x 2 resident workgroups.
+constexpr int SLOTS = 512;
+
 static int wgrad_plan(WgradArgs& a) {
   int chunks = a.ntaps * ((a.conv_c + TK - 1) / TK);
   for (int i = 0; i < a.nplain; ++i) chunks += (a.p_c[i] + TK - 1) / TK;
   const int ntn = (a.N + TN - 1) / TN;
   a.ktot = a.ntaps * a.conv_c;
   for (int i = 0; i < a.nplain; ++i) a.ktot += a.p_c[i];
-  if (a.msplit <= 0) {
-    // m-slices come in multiples of 8 (one per XCD, see the kernel) or not at all.  The count is the cheapest candidate of a small cost
-    // model fitted to a sweep over the layer shapes of the step (profiles/r04/wgrad_msplit_sweep.txt): the chip holds 512 blocks at a
-    // time (256 CUs x 2), so the blocks run in rounds of 512 -- a last round of <= 256 blocks has a CU to itself per block and takes
-    // 0.7 of a full one -- at 0.9 PFLOP/s when full, and every slice adds one fp32 slab of the gradient that is written and read back.
-    const int blocks = ntn * chunks;
-    static const bool old_rule = [] { const char* e = getenv("DFH_WGRAD_PLAN"); return e && e[0] == '0'; }();
-    if (old_rule) {
-      int ms = std::min((640 + blocks - 1) / blocks, a.M / 512);
-      ms = blocks >= 384 ? 1 : (ms + 7) / 8 * 8;
-      while (ms > 8 && a.M / ms < 512) ms -= 8;
-      a.msplit = (ms >= 8 && a.M / ms >= 128) ? ms : 1;
-    } else {
-      const double work_us = 2.0 * a.M * a.N * a.ktot / 0.9e15 * 1e6, slab_us = (double)a.N * a.ktot * 8.0 / 5e12 * 1e6;
-      auto cost = [&](int ms) {
-        const int b = blocks * ms, full = b / 512, rem = b % 512;
-        const double rounds = full + (rem == 0 ? 0.0 : rem <= 256 ? 0.7 : 1.0);
-        return work_us / b * 512.0 * rounds + (ms > 1 ? ms * slab_us : 0.0);
-      };
-      int best = 1;
-      double best_c = cost(1);
-      for (int ms = 8; ms <= 64 && a.M / ms >= 512; ms += 8) {
-        const double c = cost(ms);
-        if (c < best_c) { best_c = c; best = ms; }
-      }
-      a.msplit = best;
+  a.xblocks = ntn * chunks;
+  a.whole = 0;
+  const int blocks = a.xblocks;
+  if (a.msplit < 0) {                                   // forced: whole tiles in full rounds, the remainder in -msplit slices
+    a.msplit = -a.msplit; a.whole = blocks / SLOTS * SLOTS;
+    if (a.whole == blocks) { a.whole = 0; a.msplit = 1; }
+    return 0;
+  }
+  if (a.msplit > 0) return 0;
+  // The plan is the cheapest candidate of a small cost model fitted to a sweep over the layer shapes of the step on the MI355X
+  // (profiles/r05/wgrad_plan_sweep.txt; round 4: wgrad_msplit_sweep.txt): the chip holds 512 blocks at a time, so equal blocks run in
+  // rounds of 512 -- a last round of <= 256 blocks has a CU to itself per block and takes 0.8 of a full one; a 32-row stage of a block
+  // takes 0.85 us with the chip full (~0.98 PFLOP/s); a block costs 5 us of pipeline fill and epilogue; a slab slot 0.04 us (100 KB
+  // written and read back).
+  static const int mode = [] { const char* e = getenv("DFH_WGRAD_PLAN"); return e ? atoi(e) : 2; }();     // 1: round-4 candidates (1 or multiples of 8)
+  constexpr double stage_us = 0.85, lone = 0.8, fill_us = 5.0, slot_us = 0.04;
+  auto rounds_of = [&](long b) { const long full = b / SLOTS, rem = b % SLOTS; return full + (rem == 0 ? 0.0 : rem <= SLOTS / 2 ? lone : 1.0); };
+  auto stages_of = [&](int ms) { return (double)(((a.M + ms - 1) / ms + BM - 1) / BM); };
+  auto cost_slices = [&](int tiles, int ms) {
+    const long b = (long)tiles * ms;
+    return rounds_of(b) * (stages_of(ms) * stage_us + fill_us) + (ms > 1 ? (double)b * slot_us : 0.0);
+  };
+  int best = 1, best_whole = 0;
+  double best_c = cost_slices(blocks, 1);
+  for (int ms = (mode == 1 ? 8 : 2); ms <= 64 && a.M / ms >= 512; ms += (mode == 1 ? 8 : 1)) {
+    const double c = cost_slices(blocks, ms);
+    if (c < best_c) { best_c = c; best = ms; }
+  }
+  const int whole = blocks / SLOTS * SLOTS, tail = blocks - whole;
+  if (mode >= 2 && whole > 0 && tail > 0) {
+    const double cw = (whole / SLOTS) * (stages_of(1) * stage_us + fill_us);
+    for (int ms = 2; ms <= 16 && a.M / ms >= 128; ++ms) {
+      const double c = cw + cost_slices(tail, ms);
+      if (c < best_c) { best_c = c; best = ms; best_whole = whole; }
     }
   }
-  a.xblocks = ntn * chunks;
+  a.msplit = best; a.whole = best_whole;
   return 0;
 }
 
+static size_t wgrad_slots(const WgradArgs& a) { return a.msplit > 1 ? (size_t)a.msplit * (a.xblocks - a.whole) : 0; }
+
 size_t wgrad_partial_floats(WgradArgs a) {
   wgrad_plan(a);
-  return a.msplit > 1 ? (size_t)a.msplit * a.N * a.ktot : 0;
+  return wgrad_slots(a) * SLOT_FLOATS;
 }
 
 int wgrad_launch(WgradArgs a, hipStream_t s) {
@@ -369,7 +409,8 @@ int wgrad_launch(WgradArgs a, hipStream_t s) {
   DFH_REQUIRE(a.ntaps + a.nplain >= 1 && a.zero && a.dY && a.dW, "wgrad: missing operand");
   DFH_REQUIRE(a.ldw % 4 == 0 && ((uintptr_t)a.dW & 15) == 0, "wgrad: dW rows must be 16-byte aligned");
   wgrad_plan(a);
-  if (a.msplit > 1 && (a.partial == nullptr || a.partial_cap < (size_t)a.msplit * a.N * a.ktot)) {
+  const size_t need = wgrad_slots(a) * SLOT_FLOATS;
+  if (need && (a.partial == nullptr || a.partial_cap < need)) {
     set_error("wgrad: slab buffer missing or smaller than wgrad_partial_floats()");
     return -1;
   }
@@ -384,13 +425,12 @@ int wgrad_launch(WgradArgs a, hipStream_t s) {
   for (int i = 0; i < a.nplain; ++i) kreal += a.p_c[i];
   ProfScope ps(PC_WGRAD, 2.0 * a.M * a.N * kreal, 2.0 * a.M * (a.N + kreal) + 4.0 * a.N * kreal, s);
   const bool pow2 = a.ntaps == 0 || (((a.Hout & (a.Hout - 1)) | (a.Wout & (a.Wout - 1))) == 0);
-  if (pow2) hipLaunchKernelGGL(gemm_wgrad_kernel<true>, dim3(a.xblocks * a.msplit), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL(gemm_wgrad_kernel<false>, dim3(a.xblocks * a.msplit), dim3(256), lds, s, a);
+  const int grid = a.whole + (a.xblocks - a.whole) * a.msplit;
+  if (pow2) hipLaunchKernelGGL(gemm_wgrad_kernel<true>, dim3(grid), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(gemm_wgrad_kernel<false>, dim3(grid), dim3(256), lds, s, a);
   if (int rc = check_launch("gemm_wgrad_kernel")) return rc;
-  if (a.msplit > 1) {
-    const long quads = (long)a.N * a.ktot / 4;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a.partial, a.dW, a.N, a.ktot, a.ldw,
-                       a.msplit, a.overwrite);
+  if (need) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.xblocks - a.whole, 25), dim3(256), 0, s, a);
     return check_launch("wgrad_reduce_kernel");
   }
   return 0;

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def wgrad(*, M, N, dY, conv_src=None, conv_c=0, batch=0, Hin=0, stride=1, upsample=0, a0=None, a0_c=0, a1=None, a1_c=0,
-          ldw, msplit=0):
+          ldw, msplit=0, into=None):
     d = _lib.GemmDesc()
     if conv_src is not None:
         d.conv_src, d.conv_c, d.conv = conv_src.data_ptr(), conv_c, 1
@@ -26,7 +26,7 @@ def wgrad(*, M, N, dY, conv_src=None, conv_c=0, batch=0, Hin=0, stride=1, upsamp
     d.M, d.N = M, N
     z = gu.zero_page()
     d.zero_page = z.data_ptr()
-    dW = torch.zeros((N, ldw), dtype=torch.float32, device=DEV)
+    dW = torch.zeros((N, ldw), dtype=torch.float32, device=DEV) if into is None else into
     need = _lib.raw().dfh_gemm_wgrad_partial_floats(C.byref(d), msplit)
     part = torch.empty(max(need, 1), dtype=torch.float32, device=DEV)
     d.partial, d.partial_floats = part.data_ptr(), need
@@ -36,12 +36,29 @@ def wgrad(*, M, N, dY, conv_src=None, conv_c=0, batch=0, Hin=0, stride=1, upsamp
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (4096, 160, 64), (77 * 3, 64, 768), (130, 1280, 200), (8, 256, 2048)])
-@pytest.mark.parametrize("msplit", [0, 1, 3])
+@pytest.mark.parametrize("msplit", [0, 1, 3, 7, -4])
 def test_wgrad_linear(M, N, K, msplit):
     a, dy = bf(rnd(M, K, seed=1)), bf(rnd(M, N, seed=2))
     dW = wgrad(M=M, N=N, dY=dy, a0=a, a0_c=K, ldw=K, msplit=msplit)
     ref = dy.float().T @ a.float()
     assert gu.rel_err(dW, ref) < 2e-5, gu.rel_err(dW, ref)      # fp32 accumulate of exact bf16 products
+
+
+@pytest.mark.parametrize("M,N,K,msplit", [(2048, 1280, 11520, -8),      # 576 tiles: 512 whole-tile blocks + the last 64 tiles as 8 pixel slices each
+                                          (256, 1280, 23040, -4),       # 1152 tiles: two full rounds of whole tiles + 128 tiles x 4 slices
+                                          (2048, 1280, 11520, 0),       # conv 1280->1280 at 8x8 without the conv addressing: the plan's own choice
+                                          (9000, 320, 2880, 14), (9000, 320, 2880, 13)])   # slice counts that are not multiples of 8
+def test_wgrad_piece_decompositions(M, N, K, msplit):
+    """The launch as pieces (wgrad.hip): equal pixel slices in the XCD-contiguous block order for ANY slice count, and the whole / tail
+    split (full rounds of whole-tile blocks that add straight into dW, the remaining tiles sliced); the slab reduce must cover exactly the
+    sliced tiles.  Accumulating launch (dW += ...) on top of a non-zero dW, so a piece added twice or never shows; bit-identical reruns."""
+    a, dy = bf(rnd(M, K, seed=21)), bf(rnd(M, N, seed=22))
+    ref = dy.float().T @ a.float()
+    dW = wgrad(M=M, N=N, dY=dy, a0=a, a0_c=K, ldw=K, msplit=msplit)
+    assert gu.rel_err(dW, ref) < 2e-5, gu.rel_err(dW, ref)
+    dW2 = wgrad(M=M, N=N, dY=dy, a0=a, a0_c=K, ldw=K, msplit=msplit, into=dW.clone())
+    assert gu.rel_err(dW2, 2 * ref) < 2e-5
+    assert torch.equal(wgrad(M=M, N=N, dY=dy, a0=a, a0_c=K, ldw=K, msplit=msplit), dW), "the piece order of the slab reduce is fixed: bit-identical reruns"
 
 
 def test_wgrad_two_sources_and_column_offset():
@@ -55,13 +72,14 @@ def test_wgrad_two_sources_and_column_offset():
 
 @pytest.mark.parametrize("cin,cout,H,stride,ups", [(64, 160, 16, 1, 0), (32, 64, 8, 1, 0), (320, 64, 16, 1, 0), (64, 64, 16, 2, 0),
                                                    (64, 128, 8, 1, 1), (8, 64, 16, 1, 0), (128, 128, 2, 1, 0)])
-def test_wgrad_conv3x3(cin, cout, H, stride, ups):
+@pytest.mark.parametrize("msplit", [0, 5, -3])
+def test_wgrad_conv3x3(cin, cout, H, stride, ups, msplit):
     B = 2
     x = bf(rnd(B, cin, H, H, seed=6))
     Ho = H * 2 if ups else H // stride
     dy = bf(rnd(B, cout, Ho, Ho, seed=7))
     dW = wgrad(M=B * Ho * Ho, N=cout, dY=gu.nhwc(dy).view(-1, cout), conv_src=gu.nhwc(x), conv_c=cin, batch=B, Hin=H,
-               stride=stride, upsample=ups, ldw=9 * cin)
+               stride=stride, upsample=ups, ldw=9 * cin, msplit=msplit)
     w = torch.zeros(cout, cin, 3, 3, device=DEV, requires_grad=True)
     xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
     y = F.conv2d(xin, w, None, stride=stride, padding=1)

@@ -138,6 +138,7 @@ SIGNATURES = {
     "dfh_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "dfh_gemm_wgrad": (_i, [C.POINTER(GemmDesc), _vp, _i, _vp, _i, _i, _vp]),
     "dfh_gemm_wgrad_partial_floats": (_sz, [C.POINTER(GemmDesc), _i]),
+    "dfh_gemm_wgrad_plan": (_i, [C.POINTER(GemmDesc), _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dfh_colsum": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "dfh_groupnorm": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     "dfh_gemm_gstat": (_i, [C.POINTER(GemmDesc), _vp, C.POINTER(C.c_int)]),

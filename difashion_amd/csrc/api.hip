@@ -180,6 +180,15 @@ size_t dfh_gemm_wgrad_partial_floats(const dfh_gemm_desc* d, int msplit) {
   return dfh::wgrad_partial_floats(w);
 }
 
+int dfh_gemm_wgrad_plan(const dfh_gemm_desc* d, int msplit, int* tiles, int* whole_tiles, int* slices) {
+  WgradArgs w;
+  DFH_REQUIRE(d && tiles && whole_tiles && slices, "null argument");
+  if (int rc = fill_wgrad(d, nullptr, 8, nullptr, 8, msplit, w)) return rc;
+  dfh::wgrad_plan_only(w);
+  *tiles = w.xblocks; *whole_tiles = w.whole; *slices = w.msplit;
+  return 0;
+}
+
 int dfh_colsum(const void* Y, int ldy, int N, int groups, int rows_per_group, float* out, int ld_out, void* stream) {
   DFH_REQUIRE(Y && out, "null argument");
   return dfh::colsum_launch((const bf16_t*)Y, ldy, N, groups, rows_per_group, out, ld_out, (hipStream_t)stream);

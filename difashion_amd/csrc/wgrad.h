@@ -26,6 +26,7 @@ struct WgradArgs {
 
 namespace dfh {
 int wgrad_launch(WgradArgs a, hipStream_t s);
+void wgrad_plan_only(WgradArgs& a);           // fills xblocks / ktot / whole / msplit as wgrad_launch would
 size_t wgrad_partial_floats(WgradArgs a);   // slab floats the heuristic (or a.msplit) needs; 0 = none
 // out[g][n] += sum_{m in group g} Y[m][n]   (bias gradient: groups = 1; time-embedding gradient: groups = batch)
 int colsum_launch(const bf16_t* Y, int ldy, int N, int groups, int rows_per_group, float* out, int ld_out, hipStream_t s);

@@ -396,6 +396,8 @@ static int wgrad_plan(WgradArgs& a) {
 
 static size_t wgrad_slots(const WgradArgs& a) { return a.msplit > 1 ? (size_t)a.msplit * (a.xblocks - a.whole) : 0; }
 
+void wgrad_plan_only(WgradArgs& a) { wgrad_plan(a); }
+
 size_t wgrad_partial_floats(WgradArgs a) {
   wgrad_plan(a);
   return wgrad_slots(a) * SLOT_FLOATS;

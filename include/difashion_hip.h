@@ -243,10 +243,14 @@ int dfh_gemm(const dfh_gemm_desc* d, void* stream);
 int dfh_gemm_gstat(const dfh_gemm_desc* d, void* stream, int* written);
 /* Weight gradient of the same op (train.py:699 backward): dW[n][k] += sum_m dY[m][n] * A[m][k], where A is the
  * forward operand described by d (conv_src / a0 / a1 segments, M, N, zero_page; W / out / epilogue fields unused).
- * dW: fp32 [N][ldw] in the PACKED weight layout, accumulated with atomics (zero it first).  msplit 0 = heuristic. */
+ * dW: fp32 [N][ldw] in the PACKED weight layout, accumulated (dW += ...; the sum over pixel slices is a fixed-order slab reduce, so
+ * reruns are bit-identical).  msplit: 0 = the launcher's plan; n > 0 = n equal pixel slices of every 160 x 160 output tile;
+ * -n = whole tiles in full rounds of 512 blocks and the remaining tiles in n slices. */
 int dfh_gemm_wgrad(const dfh_gemm_desc* d, const void* dY, int ldy, float* dW, int ldw, int msplit, void* stream);
 /* fp32 slab floats (d->partial / d->partial_floats) that call needs when it splits the pixel range; 0 = none */
 size_t dfh_gemm_wgrad_partial_floats(const dfh_gemm_desc* d, int msplit);
+/* the decomposition that call would launch (host code, no GPU needed): output tiles, how many of them run whole, pixel slices of the rest */
+int dfh_gemm_wgrad_plan(const dfh_gemm_desc* d, int msplit, int* tiles, int* whole_tiles, int* slices);
 /* out[g][n] += sum over the rows of group g of Y[m][n] (bias gradient: groups = 1; time-embedding gradient:
  * groups = batch, rows_per_group = H*W). */
 int dfh_colsum(const void* Y, int ldy, int N, int groups, int rows_per_group, float* out, int ld_out, void* stream);

@@ -425,28 +425,27 @@ def test_bench_gpus_n_launches_its_own_ranks_and_fails_with_them():
 
 
 def test_wgrad_slice_plan_picks_within_a_few_percent_of_the_measured_best():
-    """The m-slice count of the weight-gradient GEMM comes from a cost model (wgrad.hip wgrad_plan) fitted to a sweep on the MI355X over
-    the layer shapes of the training step (profiles/r04/wgrad_msplit_sweep.txt: microseconds per shape and slice count).  The plan is host
-    code: dfh_gemm_wgrad_partial_floats(desc, 0) = slices x N x K floats (0 when it does not split).  For every swept shape the slice
-    count it picks must be one the sweep measured within 8 % of that shape's best time, must keep >= 512 pixel rows per slice, and
-    must be 1 or a multiple of 8 (one slice set per XCD)."""
+    """The decomposition of a weight-gradient launch comes from a cost model (wgrad.hip wgrad_plan) fitted to a sweep on the MI355X over
+    the layer shapes of the training step (profiles/r05/wgrad_plan_sweep.txt: microseconds per shape for n pixel slices of every tile,
+    `ms=n`, and for full rounds of whole tiles + the rest in n slices, `w+n`).  The plan is host code (dfh_gemm_wgrad_plan).  For every
+    swept shape the candidate it picks must be one the sweep measured within 8 % of that shape's best time; slices keep >= 128 pixel
+    rows; whole tiles come in full rounds of 512 blocks; and the slab request matches the plan (one 160 x 160 fp32 slot per sliced piece)."""
     import ctypes as C
-    import re
     from difashion_amd import _lib
     lib = _lib.raw()
-    table, ms = {}, None
-    for line in open(os.path.join(ROOT, "profiles", "r04", "wgrad_msplit_sweep.txt")):
-        if line.startswith("=="):
-            ms = int(line.split()[-1])
-            continue
-        m = re.match(r"(.{24}) M=\s*(\d+) N=\s*(\d+) K=\s*(\d+)\s+([\d.]+) us", line)
-        if m:
-            table.setdefault((m.group(1).strip(), int(m.group(2)), int(m.group(3)), int(m.group(4))), {})[ms] = float(m.group(5))
-    assert len(table) >= 12
+    lines = open(os.path.join(ROOT, "profiles", "r05", "wgrad_plan_sweep.txt")).read().splitlines()
+    head = next(l for l in lines if l.startswith("shape"))
+    cols = head.split("|")[1].split("(us)")[0].split()
     dummy = (C.c_char * 256)()
     ptr = C.addressof(dummy)
-    checked = 0
-    for (name, M, N, K), times in table.items():
+    checked = total_pick = total_best = 0
+    for l in lines:
+        if "|" not in l or l.startswith(("shape", "sum", "TFLOP")):
+            continue
+        name = l[:24].strip()
+        M, N, K, tiles = (int(x) for x in l[24:].split("|")[0].split())
+        vals = [float(x) for x in l.split("|")[1].split("best")[0].split()]
+        times = {c: v for c, v in zip(cols, vals) if v == v and c != "plan"}
         d = _lib.GemmDesc()
         if name.startswith("conv"):
             hw = int(name.split("@")[1])
@@ -455,12 +454,14 @@ def test_wgrad_slice_plan_picks_within_a_few_percent_of_the_measured_best():
         else:
             d.a0, d.a0_c = ptr, K
         d.M, d.N, d.zero_page = M, N, ptr
-        floats = lib.dfh_gemm_wgrad_partial_floats(C.byref(d), 0)
-        assert floats % (N * K) == 0, (name, floats)
-        slices = max(1, floats // (N * K))
-        assert slices == 1 or (slices % 8 == 0 and slices <= 64 and M // slices >= 512), (name, slices)
+        t, w, ms = C.c_int(), C.c_int(), C.c_int()
+        assert lib.dfh_gemm_wgrad_plan(C.byref(d), 0, C.byref(t), C.byref(w), C.byref(ms)) == 0
+        assert t.value == tiles, (name, t.value, tiles)
+        assert w.value % 512 == 0 and w.value < tiles and 1 <= ms.value <= 64 and (ms.value == 1 or M // ms.value >= 128), (name, w.value, ms.value)
+        assert lib.dfh_gemm_wgrad_partial_floats(C.byref(d), 0) == (ms.value * (tiles - w.value) * 160 * 160 if ms.value > 1 else 0)
+        key = f"w+{ms.value}" if w.value else f"ms={ms.value}"
         best = min(times.values())
-        if slices in times:                       # 48 was not swept
-            assert times[slices] <= 1.08 * best, (name, slices, times[slices], best)
-            checked += 1
-    assert checked >= 12
+        if key in times:                          # not every slice count was swept
+            assert times[key] <= 1.08 * best, (name, key, times[key], best)
+            checked += 1; total_pick += times[key]; total_best += best
+    assert checked >= 16 and total_pick <= 1.03 * total_best, (checked, total_pick, total_best)

@@ -53,6 +53,7 @@ class GemmDesc(C.Structure):
         ("zero_page", C.c_void_p),
         ("force_tile", C.c_int), ("force_split", C.c_int), ("force_order", C.c_int),
         ("gstat", C.c_void_p), ("gstat_cpg", C.c_int), ("gstat_hw", C.c_int),
+        ("w_img_stride", C.c_size_t),
     ]
 
 
@@ -138,6 +139,7 @@ SIGNATURES = {
     "dfh_gemm": (_i, [C.POINTER(GemmDesc), _vp]),
     "dfh_gemm_wgrad": (_i, [C.POINTER(GemmDesc), _vp, _i, _vp, _i, _i, _vp]),
     "dfh_gemm_wgrad_partial_floats": (_sz, [C.POINTER(GemmDesc), _i]),
+    "dfh_groupnorm_fold": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, C.c_float, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "dfh_gemm_wgrad_plan": (_i, [C.POINTER(GemmDesc), _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dfh_colsum": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "dfh_groupnorm": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),

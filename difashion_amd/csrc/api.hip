@@ -73,6 +73,7 @@ static int fill_gemm(const dfh_gemm_desc* d, GemmArgs* g) {
   g->M = d->M; g->N = d->N;
   g->bias = d->bias; g->rowvec = d->rowvec; g->rv_ld = d->rv_ld; g->rv_off = d->rv_off;
   g->rows_per_b = d->rows_per_b > 0 ? d->rows_per_b : d->M;
+  g->w_img_bs = (long)d->w_img_stride;
   g->resid = (const bf16_t*)d->resid; g->ld_res = d->ld_res;
   g->act = d->act; g->out = d->out; g->ld_out = d->ld_out; g->out_mode = d->out_mode;
   g->partial = d->partial;
@@ -333,6 +334,14 @@ int dfh_layernorm(const void* x, const float* gamma, const float* beta, void* y,
 }
 
 // LayerNorm folded into the GEMMs around it (gemm.h, lnfold.hip)
+int dfh_groupnorm_fold(const void* x, int B, int HW, int C, int G, const float* gamma, const float* beta, float eps, const float* pre,
+                       int pre_chunks, float* partial, const void* W, int ldw, int N, const float* bias, void* Wimg, float* rv, void* stream) {
+  GnFoldArgs f; std::memset(&f, 0, sizeof(f));
+  f.x = (const bf16_t*)x; f.B = B; f.HW = HW; f.C = C; f.G = G; f.eps = eps; f.gamma = gamma; f.beta = beta; f.pre = pre; f.pre_chunks = pre_chunks;
+  f.partial = partial; f.W = (const bf16_t*)W; f.ldw = ldw; f.N = N; f.bias = bias; f.Wimg = (bf16_t*)Wimg; f.rv = rv;
+  return dfh::groupnorm_fold_launch(f, (hipStream_t)stream);
+}
+
 int dfh_ln_fold(const void* W, int ldw, const float* gamma, const float* beta, const float* bias, void* WF, float* s, float* b, int N, int K,
                 void* stream) {
   return dfh::ln_fold_launch((const bf16_t*)W, ldw, gamma, beta, bias, (bf16_t*)WF, s, b, N, K, (hipStream_t)stream);

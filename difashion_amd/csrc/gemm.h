@@ -50,6 +50,10 @@ struct GemmArgs {
   // (elements).  The sixteen transform-domain GEMMs of a Winograd F(2x2, 3x3) convolution (winograd.hip) in ONE launch: 16 x the tiles of
   // one, so the deep levels fill the chip without split-K.  Single plain segment, bf16 row-major output, gemm_bf16_kernel tiles only.
   int nbatch; long a_bs, w_bs, o_bs;
+  // per-IMAGE weights: rows [i * rows_per_b, (i + 1) * rows_per_b) multiply W + i * w_img_bs (elements) -- a GroupNorm folded into the 1x1
+  // projection that consumes it (norm.hip gn_fold_kernel: W_i = W . gamma . rstd_i per image, the mean / beta terms as the per-image row
+  // vector `rowvec`).  gemm_bf16_kernel tiles only, no split-K, rows_per_b a multiple of the row tile.
+  long w_img_bs;
   // PHASE-DECOMPOSED nearest-2x upsample + 3x3 conv (the up-block upsamplers): output pixel (2y + py, 2x + px) sees only a 2 x 2
   // neighbourhood of the SOURCE image -- rows {y - 1 + py, y + py}, columns likewise -- each with the SUM of the 3x3 taps that land on
   // it, so the conv is four independent 2x2 convs (4/9 of the multiply-adds of the conv over the upsampled image).  phase2x = 1:

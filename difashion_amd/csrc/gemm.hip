@@ -156,7 +156,7 @@ void gemm_bf16_kernel(const GemmArgs a) {
   const bf16_t* psrc0 = a.p_src[0] + bz * a.a_bs;
   const bf16_t* csrc = a.conv_src + (a.phase2x == 2 ? bz * a.a_bs : 0);
   const bf16_t* psrc1 = a.p_src[1];
-  const bf16_t* Wb = a.W + bz * a.w_bs;
+  const bf16_t* Wb = a.W + bz * a.w_bs + (a.w_img_bs ? (long)(m0 / a.rows_per_b) * a.w_img_bs : 0L);
   bf16_t* const outb = (bf16_t*)a.out + bz * a.o_bs;
   asm volatile("" : "+s"(psrc0), "+s"(psrc1), "+s"(Wb));
   auto glds = [&](const bf16_t* src, unsigned char* dst) {
@@ -1026,6 +1026,11 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
                 "folded LayerNorm: single-pass launches without rowvec / residual only (gemm_ln_consumer_ok)");
     DFH_REQUIRE(a.act != ACT_GEGLU || (a.ld_out & 7) == 0, "folded LayerNorm + GEGLU needs 16-byte aligned output rows");
   }
+  if (a.w_img_bs) {
+    split = 1; a.ksplit = 1;
+    DFH_REQUIRE(a.ntaps == 0 && a.nbatch <= 1 && !a.w_blocked && a.rows_per_b % kTiles[tile].bm == 0 && a.M % a.rows_per_b == 0,
+                "per-image weights: plain segments, images of whole row tiles");
+  }
   if (a.w_blocked) DFH_REQUIRE(lean_plain(a) && a.N % 16 == 0 && a.ldw % 64 == 0 && a.N % 160 == 0 && force_tile == 0 && split == 1,
                                "blocked W: LEAN launches (plain 64-multiple segments) on the 128 x 160 / 256 x 320 tiles only");
   if (a.out2) DFH_REQUIRE(split == 1 && a.n_split > 0 && a.n_split % kTiles[tile].bn == 0 && a.out_mode == OUT_BF16 && a.act != ACT_GEGLU &&
@@ -1049,7 +1054,7 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
                  (a.phase2x == 1 ? abytes : planes * abytes) + planes * ((double)a.N * kreal * 2.0 + obytes), stream);
     const bool wide_ok0 = split == 1 && a.out2 == nullptr && a.out_mode == OUT_BF16 && (a.act != ACT_GEGLU || a.N % 160 == 0 || a.N % 128 == 0) && (a.N & 7) == 0 &&
                          (a.ld_out & 7) == 0 && (!a.resid || (a.ld_res & 7) == 0);
-    const bool wide_ok = wide_ok0 && a.nbatch <= 1;       // batched launches: gemm_bf16_kernel tiles only (the 256 x 320 one when pinned)
+    const bool wide_ok = wide_ok0 && a.nbatch <= 1 && !a.w_img_bs;       // batched launches / per-image weights: gemm_bf16_kernel tiles only (the 256 x 320 one when pinned)
     // tile id 21 pins the 256 x 320 tile (launches it cannot take -- fp32 / transposed outputs, GEGLU, N % 8 -- fall back to the
     // heuristic tile, like the forced wide ids); otherwise gemm_big_pick decides
     const bool force_big = force_wide == 16 ||     // id 21
@@ -1063,7 +1068,7 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
                          "pre_out: GEGLU launches with N % 128 == 0, no split-K, no folded LayerNorm");
     const bool bigg = !pre && wide_ok && !force_deep && a.act == ACT_GEGLU && a.N % 32 == 0 && !a.resid && !a.rowvec &&
                       (force_bigg || (!force_wide && force_tile == 0 && force_split == 0 && gemm_big_geglu_pick(a)));
-    const bool big_ok = wide_ok0 && !force_deep && a.act != ACT_GEGLU && !a.ln_stat && (a.nbatch <= 1 || force_big);
+    const bool big_ok = wide_ok0 && !force_deep && a.act != ACT_GEGLU && !a.ln_stat && (a.nbatch <= 1 || force_big) && !a.w_img_bs;
     const bool big = big_ok && (force_big || (!force_wide && force_tile == 0 && force_split == 0 && gemm_big_pick(a)));
     int wide = pre ? 5 : (!wide_ok || force_deep || big || force_big || bigg || force_bigg) ? 0 : (force_wide ? force_wide : ((force_tile == 0 && force_split == 0) ? gemm_wide_pick(a) : 0));
     int ws = 0; bool halo = false;

@@ -36,7 +36,24 @@ struct GnBwdArgs {
   int C, PL, chunks, pix_per_chunk, apix_per_chunk;
 };
 
+// GroupNorm FOLDED into the 1x1 projection that consumes it (transformer entry: norm -> proj_in, difashion.py:249-253 through diffusers
+// Transformer2DModel): y[t][n] = sum_c W[n][c] ((x[t][c] - mean) rstd gamma_c + beta_c) + bias[n]
+//                              = sum_c Wimg[i][n][c] x[t][c] + rv[i][n]         for the pixels t of image i,
+// Wimg[i][n][c] = bf16(W[n][c] gamma_c rstd_{i, g(c)}),  rv[i][n] = bias[n] + sum_c (W[n][c] beta_c - Wimg[i][n][c] mean_{i, g(c)})
+// (the mean term uses the ROUNDED per-image weight, the one the GEMM multiplies x by, so a constant channel cancels exactly).  The
+// normalised tensor is never written: the GEMM reads x itself with per-image weights (GemmArgs::w_img_bs) and rv as its row vector.
+struct GnFoldArgs {
+  const bf16_t* x; int B, HW, C, G; float eps;
+  const float* gamma; const float* beta;
+  const float* pre; int pre_chunks;          // statistics partials of x from its producer ([B][G][pre_chunks][2]) or nullptr:
+  float* partial;                            // ... then gn_stats_kernel sums x into `partial` (>= B * GN_MAX_CHUNKS * G * 2 floats)
+  const bf16_t* W; int ldw; int N; const float* bias;   // the projection: bf16 [N][ldw] (K = C), optional fp32 bias
+  bf16_t* Wimg;                              // out: [B][N][C]
+  float* rv;                                 // out: [B][N]
+};
+
 namespace dfh {
+int groupnorm_fold_launch(GnFoldArgs a, hipStream_t stream);
 int groupnorm_bwd_launch(GnBwdArgs a, hipStream_t stream);
 // LayerNorm backward over rows [M][C]; dx (=|+=); dgamma/dbeta fp32 atomics
 int layernorm_bwd_launch(const bf16_t* x, const bf16_t* dy, const float* gamma, bf16_t* dx, int accumulate, float* dgamma,

@@ -11,6 +11,7 @@
 // octet below C0/8 comes from src0, the rest from src1.
 #include "dfh_common.h"
 #include "norm.h"
+#include <cstring>
 #include <cstdlib>
 
 namespace {
@@ -437,6 +438,54 @@ __global__ __launch_bounds__(MAXT) void gn_mid_kernel(const GnArgs a, const int 
   }
 }
 
+namespace {
+// grid (N / 8, B), 256 threads: the image's group statistics from the partials (as gn_apply_kernel), then eight rows of the projection,
+// two per wave (a lane takes 8-column chunks lane, lane + 64, ...).
+__global__ __launch_bounds__(256) void gn_fold_kernel(const GnFoldArgs a, const float* __restrict__ partial, int chunks) {
+  __shared__ float mean_s[64], rstd_s[64];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int cpg = a.C / a.G;
+  if (tid < a.G) {
+    const float2* src = (const float2*)(partial + ((long)b * a.G + tid) * chunks * 2);
+    float ss = 0.f, qq = 0.f;
+    for (int c = 0; c < chunks; ++c) { ss += src[c].x; qq += src[c].y; }
+    const float n = (float)a.HW * (float)cpg;
+    const float mean = ss / n;
+    const float var = fmaxf(qq / n - mean * mean, 0.f);
+    mean_s[tid] = mean;
+    rstd_s[tid] = rsqrtf(var + a.eps);
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int r = wave; r < 8; r += 4) {
+    const int n = blockIdx.x * 8 + r;
+    if (n >= a.N) break;
+    float acc = 0.f;
+    for (int ch = lane; ch < (a.C >> 3); ch += 64) {
+      float w[8], o[8];
+      unpack8(*(const uint4*)(a.W + (long)n * a.ldw + ch * 8), w);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = ch * 8 + k, g = c / cpg;
+        o[k] = w[k] * a.gamma[c] * rstd_s[g];
+      }
+      const uint4 packed = pack8(o);
+      float wr[8];
+      unpack8(packed, wr);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = ch * 8 + k;
+        acc += w[k] * a.beta[c] - wr[k] * mean_s[c / cpg];
+      }
+      *(uint4*)(a.Wimg + ((long)b * a.N + n) * a.C + ch * 8) = packed;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) a.rv[(long)b * a.N + n] = (a.bias ? a.bias[n] : 0.f) + acc;
+  }
+}
+}  // namespace
+
 namespace dfh {
 
 static void gn_geometry(GnArgs& a, int* block, int* achunks) {
@@ -540,6 +589,33 @@ int groupnorm_launch(GnArgs a, hipStream_t stream) {
   if (int rc = check_launch("gn_stats_kernel")) return rc;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(achunks, a.B), dim3(block), 0, stream, a);
   return check_launch("gn_apply_kernel");
+}
+
+int groupnorm_fold_launch(GnFoldArgs f, hipStream_t stream) {
+  DFH_REQUIRE(f.x && f.gamma && f.beta && f.W && f.Wimg && f.rv && (f.pre || f.partial), "groupnorm fold: null pointer");
+  DFH_REQUIRE(f.C % 8 == 0 && f.G > 0 && f.G <= 64 && f.C % f.G == 0 && f.C <= 4096 && f.ldw % 8 == 0 && f.ldw >= f.C && f.N > 0, "groupnorm fold: bad shape");
+  const float* partial = f.pre;
+  int chunks = f.pre_chunks;
+  if (!partial) {
+    GnArgs a; std::memset(&a, 0, sizeof(a));
+    a.src0 = f.x; a.C0 = a.C = f.C; a.B = f.B; a.HW = f.HW; a.G = f.G; a.partial = f.partial;
+    int block, achunks;
+    gn_geometry(a, &block, &achunks);
+    DFH_REQUIRE(block <= 512, "block too large (more than 4096 channels)");
+    const size_t lds = (size_t)a.PL * a.C * 2 * sizeof(float);
+    DFH_REQUIRE(lds <= 64 * 1024, "GroupNorm LDS reduction too large");
+    ProfScope ps(PC_GNORM, 0.0, 2.0 * a.B * (double)a.HW * a.C, stream);        // one read of the tensor
+    census(CK_GN_STATS);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(a.chunks, a.B), dim3(block), lds, stream, a);
+    if (int rc = check_launch("gn_stats_kernel")) return rc;
+    partial = f.partial; chunks = a.chunks;
+  } else {
+    DFH_REQUIRE(chunks > 0 && chunks <= (int)GN_MAX_CHUNKS, "producer statistics: 1..64 chunks");
+  }
+  ProfScope ps(PC_GNORM, 0.0, (double)f.N * f.C * 2.0 * (1.0 + f.B), stream);
+  census(CK_GN_FOLDED);
+  hipLaunchKernelGGL(gn_fold_kernel, dim3((f.N + 7) / 8, f.B), dim3(256), 0, stream, f, partial, chunks);
+  return check_launch("gn_fold_kernel");
 }
 
 int layernorm_launch(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y, int M, int C, float eps,

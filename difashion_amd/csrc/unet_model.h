@@ -948,10 +948,35 @@ struct dfh_unet {
         g.bias = (const float*)(u->arena8 + a.pin8.boff); g.sa_mul = dfh_unet::GN_Z / 448.0f;
         gemm8(g);
       } else {
-        Tensor gn = talloc(H, W, C);
-        groupnorm(x, nullptr, a.nw, a.nb, 1e-6f, 0, gn);
-        if (tl) token_linear(gn.p, a.tl_pin, v32(a.pinb), nullptr, nullptr, h0.p, true);
-        else linear(gn.p, M, C, a.pin, &a.pinb, ACT_NONE, nullptr, h0.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
+        // GroupNorm FOLDED into proj_in (norm.h GnFoldArgs): per-image weights W . gamma . rstd and a per-image row vector for the mean /
+        // beta terms, so proj_in reads the block input itself and the normalised copy (one read + one write of the tensor) is never made.
+        // Pays while the per-image weights (B x C x C) are small against the tensor: C <= DFH_GN_FOLD (default 320: the five 64x64-level
+        // blocks; 0 = off).  Same box, sampling step: off 15.97 / 15.93, 320: 15.83 / 15.78, 640: 15.86 / 15.90, 1280: 16.01 / 16.00 ms
+        // (profiles/r05/gn_fold_ab.txt).  The images must be whole 128-row tiles.
+        static const int gn_fold_max = [] { const char* e = getenv("DFH_GN_FOLD"); return e ? atoi(e) : 320; }();
+        const bool gfold = !tl && C <= gn_fold_max && N % 128 == 0 && a.pin.K == C && a.pin.N == C;
+        if (gfold) {
+          bf16_t* wimg = (bf16_t*)temp.alloc((size_t)B * C * C * 2);
+          float* rv = (float*)temp.alloc((size_t)B * C * sizeof(float));
+          if (!rc && !dry) {
+            GnFoldArgs f; std::memset(&f, 0, sizeof(f));
+            f.x = x.p; f.B = B; f.HW = N; f.C = C; f.G = u->cfg.norm_num_groups; f.eps = 1e-6f; f.gamma = v32(a.nw); f.beta = v32(a.nb);
+            if (x.gst && x.gst_cpg == C / f.G) { f.pre = x.gst; f.pre_chunks = x.gst_chunks; }
+            f.partial = gn_partial; f.W = w16(a.pin); f.ldw = a.pin.K; f.N = C; f.bias = v32(a.pinb); f.Wimg = wimg; f.rv = rv;
+            rc = dfh::groupnorm_fold_launch(f, s);
+          }
+          GemmArgs g = base(M, C);
+          g.p_src[0] = x.p; g.p_c[0] = C; g.nplain = 1;
+          g.W = wimg; g.ldw = C; g.w_img_bs = (long)C * C;
+          g.rowvec = rv; g.rv_ld = C; g.rv_off = 0; g.rows_per_b = N;
+          g.out = h0.p; g.rowstat = fold ? st : nullptr;
+          gemm(g, nullptr, nullptr, &bn);
+        } else {
+          Tensor gn = talloc(H, W, C);
+          groupnorm(x, nullptr, a.nw, a.nb, 1e-6f, 0, gn);
+          if (tl) token_linear(gn.p, a.tl_pin, v32(a.pinb), nullptr, nullptr, h0.p, true);
+          else linear(gn.p, M, C, a.pin, &a.pinb, ACT_NONE, nullptr, h0.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
+        }
       }
       // --- self attention
       Tensor n1 = talloc(H, W, C);

@@ -235,12 +235,20 @@ typedef struct dfh_gemm_desc {
   float* gstat; int gstat_cpg, gstat_hw;        /* optional: GroupNorm statistics of the output for the consumer (channels per group,
                                                  * pixels per image): [image][group][hw / 256][2] sums / sums of squares; written only
                                                  * by the 256 x 160 tile, and only through dfh_gemm_gstat (dfh_gemm ignores the three fields) */
+  size_t w_img_stride;                          /* 0, or per-IMAGE weights: rows [i * rows_per_b, (i + 1) * rows_per_b) multiply W + i * w_img_stride
+                                                 * (elements) -- dfh_groupnorm_fold; 128-row-tile launches without conv taps / split-K */
 } dfh_gemm_desc;
 size_t dfh_gemm_partial_floats(const dfh_gemm_desc* d);
 int dfh_gemm(const dfh_gemm_desc* d, void* stream);
 /* dfh_gemm + the output statistics for the consuming GroupNorm (d->gstat ...); *written = 1 when they were produced, 0 when the launch
  * ran on a kernel that cannot (the caller then runs plain dfh_groupnorm) */
 int dfh_gemm_gstat(const dfh_gemm_desc* d, void* stream, int* written);
+/* GroupNorm folded into the 1x1 projection that consumes it (transformer entry, difashion.py:249-253): from x [B][HW][C] (statistics: the
+ * producer's partials `pre` [B][G][pre_chunks][2], or NULL -> summed here into `partial`, >= B * 64 * G * 2 floats), gamma / beta and the
+ * projection W [N][ldw] (+ bias) it writes per-image weights Wimg [B][N][C] = bf16(W gamma rstd) and the row vectors rv [B][N] =
+ * bias + W . beta - Wimg . mean; then  proj(GroupNorm(x)) = dfh_gemm(a0 = x, W = Wimg, w_img_stride = N * C, rowvec = rv, rows_per_b = HW). */
+int dfh_groupnorm_fold(const void* x, int B, int HW, int C, int G, const float* gamma, const float* beta, float eps, const float* pre,
+                       int pre_chunks, float* partial, const void* W, int ldw, int N, const float* bias, void* Wimg, float* rv, void* stream);
 /* Weight gradient of the same op (train.py:699 backward): dW[n][k] += sum_m dY[m][n] * A[m][k], where A is the
  * forward operand described by d (conv_src / a0 / a1 segments, M, N, zero_page; W / out / epilogue fields unused).
  * dW: fp32 [N][ldw] in the PACKED weight layout, accumulated (dW += ...; the sum over pixel slices is a fixed-order slab reduce, so

@@ -29,7 +29,7 @@ def stream():
 
 def gemm_desc(*, M, N, W, ldw, a0=None, a0_c=0, a1=None, a1_c=0, conv_src=None, conv_c=0, batch=0, Hin=0, Win=0, stride=1,
               upsample=0, bias=None, rowvec=None, rv_ld=0, rv_off=0, rows_per_b=0, resid=None, act=0, out_mode=0,
-              out=None, ld_out=None, force_tile=0, force_split=0, force_order=-1):
+              out=None, ld_out=None, force_tile=0, force_split=0, force_order=-1, w_img_stride=0):
     """A filled dfh_gemm_desc; the tensors it points at stay alive on the descriptor (``keep_*``), the output is ``d.keep_out``."""
     d = _lib.GemmDesc()
     if conv_src is not None:
@@ -56,6 +56,7 @@ def gemm_desc(*, M, N, W, ldw, a0=None, a0_c=0, a1=None, a1_c=0, conv_src=None, 
     z = zero_page()
     d.zero_page = z.data_ptr()
     d.force_tile, d.force_split, d.force_order = force_tile, force_split, force_order
+    d.w_img_stride = w_img_stride
     need = _lib.raw().dfh_gemm_partial_floats(C.byref(d))
     part = None
     if need:

@@ -1152,3 +1152,36 @@ def test_mlp_fused_matches_torch(M, parts, offset, form):
     two = gu.gemm(M=M, N=C, W=w2p, ldw=5 * C, a0=dd.keep_out, a0_c=4 * C, a1=x, a1_c=C, bias=bias, resid=resid)
     torch.cuda.synchronize()
     assert gu.rel_err(out, two) < 6e-3, gu.rel_err(out, two)
+
+
+@pytest.mark.parametrize("B,HW,C,pre", [(3, 4096, 320, False), (2, 1024, 640, False), (4, 256, 320, True), (2, 128, 64, False)])
+def test_groupnorm_fold_into_projection_matches_torch(B, HW, C, pre):
+    """dfh_groupnorm_fold + dfh_gemm(w_img_stride, rowvec): the transformer entry norm -> proj_in (difashion.py:249-253) without the
+    normalised tensor -- per-image weights W . gamma . rstd, the mean / beta terms as a per-image row vector.  Against fp32 torch
+    (group_norm -> linear on the same bf16 operands) and against the un-folded product path (dfh_groupnorm + dfh_gemm); channel means
+    far from zero (the cancellation the rounded-weight mean term is there for).  pre: statistics handed over as producer partials."""
+    import ctypes
+    G = 32
+    x = bf(rnd(B, HW, C, seed=91) * (1.0 + 2.0 * rnd(1, 1, C, seed=92).abs()) + 3.0 * rnd(1, 1, C, seed=93))
+    gamma, beta = 1.0 + 0.3 * rnd(C, seed=94), 0.5 * rnd(C, seed=95)
+    w, bias = bf(rnd(C, C, seed=96, scale=0.06)), rnd(C, seed=97, scale=0.3)
+    ref = F.linear(F.group_norm(x.float().permute(0, 2, 1), G, gamma, beta, 1e-6).permute(0, 2, 1), w.float(), bias).reshape(B * HW, C)
+    wimg = torch.empty(B, C, C, dtype=torch.bfloat16, device=DEV)
+    rv = torch.empty(B, C, device=DEV)
+    part = torch.zeros(B * 64 * G * 2, device=DEV)
+    pre_t, chunks = None, 0
+    if pre:                                    # [B][G][chunks][2] sums / sums of squares over 2 pixel chunks, as a producer epilogue leaves them
+        chunks = 2
+        xs = x.float().reshape(B, chunks, HW // chunks, G, C // G)
+        pre_t = torch.stack([xs.sum((2, 4)), (xs * xs).sum((2, 4))], -1).permute(0, 2, 1, 3).contiguous()
+    _lib.call("dfh_groupnorm_fold", _lib.ptr(x), B, HW, C, G, _lib.ptr(gamma), _lib.ptr(beta), 1e-6, _lib.ptr(pre_t) if pre else None, chunks,
+              _lib.ptr(part), _lib.ptr(w), C, C, _lib.ptr(bias), _lib.ptr(wimg), _lib.ptr(rv), gu.stream())
+    out = gu.gemm(M=B * HW, N=C, W=wimg, ldw=C, a0=x.reshape(B * HW, C), a0_c=C, rowvec=rv, rv_ld=C, rv_off=0, rows_per_b=HW, w_img_stride=C * C)
+    torch.cuda.synchronize()
+    gu.assert_close_bf16(out, ref, "GroupNorm folded into proj_in")
+    # the un-folded product path on the same operands: the fold must not be the less accurate of the two by more than a rounding
+    gn = torch.empty_like(x)
+    _lib.call("dfh_groupnorm", _lib.ptr(x), C, None, 0, B, HW, G, _lib.ptr(gamma), _lib.ptr(beta), 1e-6, 0, _lib.ptr(gn), _lib.ptr(part), gu.stream())
+    plain = gu.gemm(M=B * HW, N=C, W=w, ldw=C, a0=gn.reshape(B * HW, C), a0_c=C, bias=bias)
+    torch.cuda.synchronize()
+    assert gu.rel_err(out, ref) <= 1.5 * gu.rel_err(plain, ref) + 1e-3, (gu.rel_err(out, ref), gu.rel_err(plain, ref))

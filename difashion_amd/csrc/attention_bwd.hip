@@ -78,6 +78,20 @@ __global__ __launch_bounds__(256, ((D <= 40 && !KV_SIDE) ? 3 : 1)) void attentio
   const float* lse = a.lse + ((long)b * a.H + h) * a.Nq;
   const float* dlt = a.delta + ((long)b * a.H + h) * a.Nq;
 
+  // PADS (head dims whose 32-deep contraction steps leave a free 8-slot chunk: d = 40, 80): the softmax bookkeeping rides in the padding
+  // of the contraction, as in the forward kernel (attention_x32.hip).  The QUERY side carries -lse as a bf16 pair (hi + lo: 16 mantissa
+  // bits) in slots D, D + 1 of Q and -delta in the same slots of dO; the KEY side carries 1.0 there (K and V), and K is pre-scaled by
+  // scale * log2(e).  The two MFMA chains then deliver  s * c - lse  and  dP - delta  directly: per score one v_exp_f32, one multiply and
+  // the packs are left on the VALU (it was fma, exp, subtract, multiply, packs -- and VALU issue, not the matrix pipe, paces d = 40).
+  // Rows beyond the streamed range: slot D + 2 is 1.0 on such a key row and -30000 on every query column (P = exp2(-30000) = 0); a query
+  // row beyond Nq carries -30000 in place of -lse.
+  constexpr bool PADS = KS * 32 - D >= 8 && D % 8 == 0;
+  constexpr float MASKV = -30000.0f;
+  const float c = a.scale * 1.44269504088896340736f;
+  auto split2 = [](float v) {                       // v ~ hi + lo, both bf16
+    const float hi = bf2f((bf16_t)(pack2bf(v, 0.f) & 0xffffu));
+    return pack2bf(hi, v - hi);
+  };
   bf16x8_t y1[NT][KS], y2[NT][KS];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -89,6 +103,16 @@ __global__ __launch_bounds__(256, ((D <= 40 && !KV_SIDE) ? 3 : 1)) void attentio
       if (col < ncols && d0 < D) {
         v1 = *(const uint4*)(Y1 + (long)col * ldy1 + d0);
         v2 = *(const uint4*)(Y2 + (long)col * ldy2 + d0);
+        if (PADS) {                                  // the score scale on the column operand of S (K in the dK / dV pass, Q in the dQ pass)
+          float f[8];
+          unpack8(v1, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] *= c;
+          v1 = pack8(f);
+        }
+      } else if (PADS && col < ncols && d0 == D) {
+        if (KV_SIDE) { v1.x = pack2bf(1.0f, 1.0f); v2.x = v1.x; }
+        else { v1.x = split2(-lse[col]); v1.y = pack2bf(MASKV, 0.f); v2.x = split2(-dlt[col]); }
       }
       y1[nt][ks] = __builtin_bit_cast(bf16x8_t, v1);
       y2[nt][ks] = __builtin_bit_cast(bf16x8_t, v2);
@@ -99,8 +123,8 @@ __global__ __launch_bounds__(256, ((D <= 40 && !KV_SIDE) ? 3 : 1)) void attentio
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int col = c0 + nt * 16 + fr;
-    col_l[nt] = (!KV_SIDE && col < ncols) ? lse[col] : INFINITY;
-    col_d[nt] = (!KV_SIDE && col < ncols) ? dlt[col] : 0.f;
+    col_l[nt] = (!PADS && !KV_SIDE && col < ncols) ? lse[col] : INFINITY;
+    col_d[nt] = (!PADS && !KV_SIDE && col < ncols) ? dlt[col] : 0.f;
   }
 
   // staging bookkeeping: chunk i of a tile -> (row, 16-byte slot)
@@ -114,9 +138,32 @@ __global__ __launch_bounds__(256, ((D <= 40 && !KV_SIDE) ? 3 : 1)) void attentio
   }
   uint4 r1[KS], r2[KS];
   float rl = 0.f, rd = 0.f;
+  float pl[KS], pd[KS]; bool pin[KS];              // PADS: raw lse / delta of the row of chunk i, row inside the streamed range
   // full_c = std::true_type: the tile lies entirely inside nrows (no bounds predicates)
   auto load_tile = [&](int row0, auto full_c) {
     constexpr bool FULL = decltype(full_c)::value;
+    if (PADS) {
+      // Branch-free: every lane loads a chunk (rows beyond the range and the chunks behind the head dim from a clamped address) and
+      // store_tile selects between the data, zeros and the bookkeeping chunk (see PADS above).  With the loads under a lane-varying
+      // branch and the chunk patched in afterwards, the compiler copied the loaded registers INSIDE the branch: an s_waitcnt right behind
+      // the loads, i.e. a synchronous prefetch (1739 -> 2068 us).  The raw statistics are requested by every lane (one address per row)
+      // BEFORE the tile chunks: vector loads return in order, so a wait for these never waits for the tile behind them.
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+        const int r = row0 + s_row[i];
+        const bool in = FULL || r < nrows;
+        pin[i] = in;
+        if (KV_SIDE) { const int rc_ = in ? r : 0; pl[i] = lse[rc_]; pd[i] = dlt[rc_]; }
+      }
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+        const int r = pin[i] ? row0 + s_row[i] : 0;
+        const int sl = min(s_slot[i], D / 8 - 1);
+        r1[i] = *(const uint4*)(X1 + (long)r * ldx1 + sl * 8);
+        r2[i] = *(const uint4*)(X2 + (long)r * ldx2 + sl * 8);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
       r1[i] = uint4{0, 0, 0, 0}; r2[i] = uint4{0, 0, 0, 0};
@@ -135,6 +182,26 @@ __global__ __launch_bounds__(256, ((D <= 40 && !KV_SIDE) ? 3 : 1)) void attentio
   auto store_tile = [&](int buf) {
     unsigned char* T1 = smem + buf * G::BUF;
     unsigned char* T2 = T1 + G::TILE;
+    if (PADS) {
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+        const bool data = pin[i] && s_slot[i] * 8 < D, pad = s_slot[i] * 8 == D;
+        uint4 w1 = r1[i], w2 = r2[i];
+        if (!data) { w1 = uint4{0, 0, 0, 0}; w2 = uint4{0, 0, 0, 0}; }
+        unsigned a1, b1 = 0u, a2;
+        if (KV_SIDE) {                               // query rows: -lse, -delta
+          a1 = pin[i] ? split2(-pl[i]) : pack2bf(MASKV, 0.f);
+          a2 = pin[i] ? split2(-pd[i]) : 0u;
+        } else {                                     // key rows: ones, and the mask slot on rows beyond Nk
+          a1 = pin[i] ? pack2bf(1.0f, 1.0f) : 0u;
+          b1 = pin[i] ? 0u : pack2bf(1.0f, 0.f);
+          a2 = a1;
+        }
+        if (pad) { w1.x = a1; w1.y = b1; w2.x = a2; }
+        *(uint4*)(T1 + s_lds[i]) = w1; *(uint4*)(T2 + s_lds[i]) = w2;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < KS; ++i) { *(uint4*)(T1 + s_lds[i]) = r1[i]; *(uint4*)(T2 + s_lds[i]) = r2[i]; }
     if (KV_SIDE && tid < XT) {
@@ -151,7 +218,6 @@ __global__ __launch_bounds__(256, ((D <= 40 && !KV_SIDE) ? 3 : 1)) void attentio
       acc1[nt][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       if (KV_SIDE) acc2[nt][f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
-  const float c = a.scale * 1.44269504088896340736f;
 
   const int ntiles = (nrows + XT - 1) / XT;
   load_tile(0, std::false_type{});
@@ -165,6 +231,7 @@ __global__ __launch_bounds__(256, ((D <= 40 && !KV_SIDE) ? 3 : 1)) void attentio
     const bool more = FAST || t + 1 < ntiles;
     if (FAST) load_tile(row0 + XT, std::true_type{});
     else if (more) load_tile(row0 + XT, std::false_type{});
+    if (PADS) __builtin_amdgcn_sched_barrier(0);     // straight-line loads: without the fence the scheduler sinks them behind the MFMAs they are meant to hide under
     const unsigned char* T1 = smem + (t & 1) * G::BUF;
     const unsigned char* T2 = T1 + G::TILE;
     const float* st = (const float*)(T2 + G::TILE);
@@ -199,6 +266,12 @@ __global__ __launch_bounds__(256, ((D <= 40 && !KV_SIDE) ? 3 : 1)) void attentio
         for (int u = 0; u < 2; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
+            if (PADS) {                                         // the MFMAs delivered s * c - lse and dP - delta
+              const float pv = __builtin_amdgcn_exp2f(tS[nt][u][r]);
+              p[u * 4 + r] = pv;
+              ds[u * 4 + r] = pv * tU[nt][u][r];
+              continue;
+            }
             const int lr = ch * 32 + fg * 8 + u * 4 + r;      // row inside the tile
             float L, Dl;
             if (KV_SIDE) { L = st[lr]; Dl = st[XT + lr]; }

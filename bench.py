@@ -781,7 +781,10 @@ def main():
                   + ("" if args.fp8_attention else ", attention products") + ", residual stream)"),
         "data": "synthetic",
         "config": {"workload": workload, "unet_batch": 16 * nout, "latent": "64x64x4",
-                   "parallelism": f"outfit-replicas x{world} (no data-path collective)"},
+                   "parallelism": f"outfit-replicas x{world} (no data-path collective)",
+                   # the two guidance branches that differ only in their prompt (difashion.py:388-427) share conv_in, the first resnet and the
+                   # first block up to its self-attention (bf16 walk; DFH_CFG_DEDUP=0 turns it off): images whose prefix is computed once
+                   "cfg_shared_prefix_images": (4 * nout if (args.dtype == "bf16" and os.environ.get("DFH_CFG_DEDUP", "1") != "0") else 0)},
         "roofline": roofline,
         # ranks counted by an all-reduce of ones on the job's process group (RCCL when the backend is "nccl"; null under the gloo test backend)
         "rccl_ranks": args.ranks_seen if args.backend in (None, "nccl") else None, "collective_backend": args.backend,

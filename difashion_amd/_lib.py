@@ -107,6 +107,7 @@ SIGNATURES = {
     "dfh_unet_forward": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "dfh_unet_run_cache_bytes": (_sz, [_vp, _i, _i]),
     "dfh_unet_run_cache": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "dfh_unet_set_dup_tail": (_i, [_vp, _i]),
     "dfh_unet_forward_cached": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "dfh_unet_debug_tap": (_i, [_vp, C.c_char_p, _vp, _sz, _vp]),
     "dfh_vae_create": (_i, [C.POINTER(VAEConfigC), C.POINTER(_vp)]),

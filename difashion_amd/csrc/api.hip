@@ -32,7 +32,7 @@ static long g_census[CK_COUNT] = {0};
 void census(int id) { if (id >= 0 && id < CK_COUNT) ++g_census[id]; }
 static const char* const kCensusNames[CK_COUNT] = {"gemm_wide", "gemm_8wave", "gemm_lean", "gemm_other", "gemm_row", "splitk_reduce",
     "splitk_fused", "gstat_written", "gn_pre", "gn_stats", "gn_small", "gn_mid", "layernorm", "ln_folded", "attention_x32", "attention_16",
-    "gemm_fp8", "text_cached", "conv_phase", "conv_wino", "gemm_rows_geglu", "attention_fp8", "mlp_fused", "gn_folded", "token_linear"};
+    "gemm_fp8", "text_cached", "conv_phase", "conv_wino", "gemm_rows_geglu", "attention_fp8", "mlp_fused", "gn_folded", "token_linear", "dup_prefix"};
 
 struct ProfRec { hipEvent_t e0, e1; int cls; double flops, bytes; };
 static std::vector<ProfRec> g_recs;

@@ -114,6 +114,12 @@ int dfh_unet_run_cache(dfh_unet* u, const void* ehs, int ehs_bf16, int batch, co
   return u->run_cache(ehs, ehs_bf16, batch, timesteps, n_timesteps, cache, (hipStream_t)stream);
 }
 
+int dfh_unet_set_dup_tail(dfh_unet* u, int images) {
+  DFH_REQUIRE(u && images >= 0, "bad argument");
+  u->dup_tail = images;
+  return 0;
+}
+
 int dfh_unet_forward_cached(dfh_unet* u, const void* sample, int sample_bf16, const void* cache, int batch, int n_timesteps, int t_index,
                             float* out, void* stream) {
   DFH_REQUIRE(u && sample && cache && out, "null argument");

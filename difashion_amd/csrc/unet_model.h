@@ -181,6 +181,7 @@ struct dfh_unet {
   bool fp8_attention = false;
   // taps of the last forward
   std::map<std::string, Tensor> taps; int last_batch = 0;
+  int dup_tail = 0;          // one-shot hint for the next forward (dfh_unet_set_dup_tail): trailing images that repeat the inputs of the ones before them
   // ---- training state (unet_train.hip)
   std::vector<TPackOp> tpacks; size_t a16t = 0; bool train_built = false;
   Mat te2t, tprojt;
@@ -620,8 +621,20 @@ struct dfh_unet {
 
     bf16_t* w16(const Mat& m) const { return u->arena16 + m.off; }
     float* v32(const Vec& v) const { return u->arena32 + v.off; }
-    Tensor palloc(int H, int W, int C) { return Tensor{(bf16_t*)persist.alloc((size_t)B * H * W * C * 2), H, W, C}; }
-    Tensor talloc(int H, int W, int C) { return Tensor{(bf16_t*)temp.alloc((size_t)B * H * W * C * 2), H, W, C}; }
+    // Ba: the batch every tensor is ALLOCATED for (the call's batch); B: the batch the launches run on.  They differ only inside the
+    // shared prefix of a guidance batch whose last `dup` images repeat the inputs of the `dup` images before them (dfh_unet::dup_tail):
+    // there B = Ba - dup, and dup_images() then copies the repeated images' rows into place.
+    int Ba = 0;
+    Tensor palloc(int H, int W, int C) { return Tensor{(bf16_t*)persist.alloc((size_t)Ba * H * W * C * 2), H, W, C}; }
+    Tensor talloc(int H, int W, int C) { return Tensor{(bf16_t*)temp.alloc((size_t)Ba * H * W * C * 2), H, W, C}; }
+    void dup_images(Tensor& t, int n) {               // images [Ba - n, Ba) := images [Ba - 2n, Ba - n); producer statistics no longer cover the tensor
+      t.gst = nullptr;
+      if (rc || dry || n <= 0) return;
+      const size_t e = (size_t)t.H * t.W * t.C;
+      if (hipMemcpyAsync(t.p + (size_t)(Ba - n) * e, t.p + (size_t)(Ba - 2 * n) * e, (size_t)n * e * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        dfh::set_error("hipMemcpyAsync failed (dup_images)"); rc = -2;
+      }
+    }
 
     // o / bump: the output tensor and the allocator it came from when the output feeds a GroupNorm -- the epilogue then leaves
     // that GroupNorm's statistics beside it (64x64 level: the launches the 256 x 160 tile takes).  DFH_GN_PRE=0 turns it off (A/B).
@@ -634,7 +647,7 @@ struct dfh_unet {
       float* gst = nullptr;
       const int G = u->cfg.norm_num_groups;
       if (o && bump && !pre_off && (o->H * o->W) % 256 == 0 && o->C % G == 0 && (o->H * o->W) / 256 <= (int)GN_MAX_CHUNKS) {
-        gst = (float*)bump->alloc((size_t)B * G * ((o->H * o->W) / 256) * 2 * sizeof(float));      // same in the dry run
+        gst = (float*)bump->alloc((size_t)Ba * G * ((o->H * o->W) / 256) * 2 * sizeof(float));      // same in the dry run
         g.gstat = gst; g.gstat_cpg = o->C / G; g.gstat_hw = o->H * o->W;
       }
       if (dry) { partial_need = std::max(partial_need, dfh::gemm_partial_floats(g) * sizeof(float)); return; }
@@ -895,8 +908,13 @@ struct dfh_unet {
       return out;
     }
 
-    Tensor transformer(const Tensor& x, const AttL& a, const bf16_t* kx, const bf16_t* vxt, int T) {
-      const int H = x.H, W = x.W, C = a.C, N = H * W, M = B * N;
+    // pre_n > 0 (first transformer block of a guidance batch, dfh_unet::dup_tail): the last pre_n images have the same INPUT as the pre_n
+    // before them and differ only in their text states, so everything up to the self-attention output is computed for B - pre_n images
+    // and the repeated images' rows are copied; from the self-attention output projection on the block runs on the whole batch.
+    Tensor transformer(const Tensor& x, const AttL& a, const bf16_t* kx, const bf16_t* vxt, int T, int pre_n = 0) {
+      const int H = x.H, W = x.W, C = a.C, N = H * W;
+      const int Bfull = B;
+      int M = B * N;
       Tensor out = palloc(H, W, C);
       const size_t mark = temp.off;
       // LayerNorm folding (gemm.h, lnfold.hip): the GEMM that produces a LayerNorm's input leaves per-row statistics of its output, the
@@ -908,7 +926,9 @@ struct dfh_unet {
       // round 4: proj_in, both to_out, ff.net.2 and proj_out in e4m3 as well, every operand quantised by the kernel that produces it
       const bool f8x = f8 && a.pin8.on;
       const bool fold = u->fold_valid && !fold_off && !f8 && !dry;
-      float* st = (float*)temp.alloc((size_t)M * ((C + 63) / 64) * 2 * sizeof(float));       // [C / bn][M][2], bn >= 64
+      const bool pre = pre_n > 0 && !f8 && !dry && 2 * pre_n <= Bfull;
+      if (pre) { B = Bfull - pre_n; M = B * N; }
+      float* st = (float*)temp.alloc((size_t)Ba * N * ((C + 63) / 64) * 2 * sizeof(float));       // [C / bn][M][2], bn >= 64
       int bn = 0;
       auto try_folded = [&](std::initializer_list<GemmArgs> gs) {
         if (!fold || bn <= 0 || C % bn) return false;
@@ -956,8 +976,8 @@ struct dfh_unet {
         static const int gn_fold_max = [] { const char* e = getenv("DFH_GN_FOLD"); return e ? atoi(e) : 320; }();
         const bool gfold = !tl && C <= gn_fold_max && N % 128 == 0 && a.pin.K == C && a.pin.N == C;
         if (gfold) {
-          bf16_t* wimg = (bf16_t*)temp.alloc((size_t)B * C * C * 2);
-          float* rv = (float*)temp.alloc((size_t)B * C * sizeof(float));
+          bf16_t* wimg = (bf16_t*)temp.alloc((size_t)Ba * C * C * 2);
+          float* rv = (float*)temp.alloc((size_t)Ba * C * sizeof(float));
           if (!rc && !dry) {
             GnFoldArgs f; std::memset(&f, 0, sizeof(f));
             f.x = x.p; f.B = B; f.HW = N; f.C = C; f.G = u->cfg.norm_num_groups; f.eps = 1e-6f; f.gamma = v32(a.nw); f.beta = v32(a.nb);
@@ -984,7 +1004,7 @@ struct dfh_unet {
       float* s8 = f8 ? (float*)temp.alloc((size_t)M * sizeof(float)) : nullptr;
       Tensor qk = talloc(H, W, 2 * C);
       const int Np = (N + 7) & ~7;    // V^T rows padded to 8 keys (the 2x2 level of tiny configs has N = 4)
-      bf16_t* vt = (bf16_t*)temp.alloc((size_t)B * C * Np * 2);   // [B][C][Np]
+      bf16_t* vt = (bf16_t*)temp.alloc((size_t)Ba * C * Np * 2);   // [B][C][Np]
       // q | k and V^T from ONE launch (columns 2C .. 3C leave transposed into vt: GemmArgs::out2) wherever the column tile divides 2C;
       // DFH_QKV_MERGE=0 keeps the two launches (A/B)
       static const bool merge_off = [] { const char* e = getenv("DFH_QKV_MERGE"); return e && e[0] == '0'; }();
@@ -1028,6 +1048,11 @@ struct dfh_unet {
         gemm8(g);
       } else {
         attention(qk.p, 2 * C, qk.p + C, 2 * C, vt, Np, at.p, C, a.heads, N, N, 0, f8attn);
+        if (pre) {                                     // end of the shared prefix: the whole batch from here on
+          B = Bfull; M = B * N;
+          dup_images(h0, pre_n); dup_images(at, pre_n);
+          dfh::census(dfh::CK_DUP_PREFIX);
+        }
         if (tl) token_linear(at.p, a.tl_o1, v32(a.o1b), h0.p, nullptr, h1.p, true);
         else linear(at.p, M, C, a.o1, &a.o1b, ACT_NONE, h0.p, h1.p, C, OUT_BF16, -1, 0, nullptr, nullptr, fold ? st : nullptr, &bn);
       }
@@ -1150,8 +1175,11 @@ struct dfh_unet {
 
   int run(const void* sample, int sample_bf16, const float* timestep, const void* ehs, int ehs_bf16, float* out, int B,
           hipStream_t s, bool dry, const RunCache* rcache = nullptr) {
-    Run r; r.u = this; r.B = B; r.s = s; r.dry = dry;
+    Run r; r.u = this; r.B = B; r.Ba = B; r.s = s; r.dry = dry;
     r.temb_ld = (rcache && rcache->temb_row) ? 0 : temb_total;
+    // one-shot hint of the caller (dfh_unet_set_dup_tail): the last `dup` images repeat the sample / timestep of the `dup` before them
+    const int dup = (!dry && !fp8 && dup_tail > 0 && 2 * dup_tail <= B) ? dup_tail : 0;
+    if (!dry) dup_tail = 0;
     const int S = cfg.sample_size, T = cfg.text_len, X = cfg.cross_attention_dim;
     const int* boc = cfg.block_out_channels;
     const int nb = cfg.num_blocks, temb = boc[0] * 4;
@@ -1219,13 +1247,24 @@ struct dfh_unet {
     Tensor x = r.palloc(S, S, conv_in.cin);   // in_channels padded to a multiple of 8
     if (!dry && !r.rc) r.rc = dfh::nchw_to_nhwc_launch(sample, sample_bf16, x.p, B, cfg.in_channels, S * S, s);
 
+    // Shared prefix of a guidance batch (reference difashion.py:388-427, 494-512: the branches of classifier-free guidance that differ only
+    // in their PROMPT get the same latent / mutual / history input): conv_in, the first resnet and the first transformer block up to its
+    // self-attention see no text state, so they run once for the repeated images.
+    if (dup) r.B = B - dup;
     Tensor h = r.conv(x, conv_in, 1, 0, true);
     taps["conv_in"] = h;
     std::vector<Tensor> skips{h};
     for (int i = 0; i < nb; ++i) {
       for (int j = 0; j < cfg.layers_per_block; ++j) {
+        const bool first = dup && i == 0 && j == 0;
         h = r.resnet(h, nullptr, down_res[i][j], temb_all);
-        if (cfg.down_attn[i]) h = r.transformer(h, down_att[i][j], kx, vxt, T);
+        if (first) {
+          r.B = B;
+          r.dup_images(skips[0], dup); taps["conv_in"] = skips[0];
+          if (!cfg.down_attn[i]) r.dup_images(h, dup);
+          else { const float* g = h.gst; r.dup_images(h, dup); h.gst = g; }     // the block's entry GroupNorm still runs on the prefix (transformer(): pre_n), which the producer statistics cover
+        }
+        if (cfg.down_attn[i]) h = r.transformer(h, down_att[i][j], kx, vxt, T, first ? dup : 0);
         skips.push_back(h);
       }
       if (i != nb - 1) { h = r.conv(h, down_samp[i], 2, 0, true); skips.push_back(h); }
@@ -1274,7 +1313,7 @@ struct dfh_unet {
   int run_cache(const void* ehs, int ehs_bf16, int B, const float* timesteps, int n_t, void* cache, hipStream_t s) {
     if (B != plan_batch) run(nullptr, 0, nullptr, nullptr, 0, nullptr, B, nullptr, true);
     DFH_REQUIRE(plan_total <= ws_bytes, "workspace too small for this batch");
-    Run r; r.u = this; r.B = B; r.s = s; r.dry = false;
+    Run r; r.u = this; r.B = B; r.Ba = B; r.s = s; r.dry = false;
     const int T = cfg.text_len, X = cfg.cross_attention_dim, Tp = (T + 7) & ~7;
     const int temb = cfg.block_out_channels[0] * 4, c0 = cfg.block_out_channels[0];
     Bump head; head.base = ws + fold_bytes();

@@ -12,6 +12,7 @@ the U-Net, guidance combine fused with the scheduler update.  Torch only allocat
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Tuple
 
@@ -124,6 +125,11 @@ class OutfitSampler:
         self.ehs = torch.cat([category_prompts.to(dev) if b[2] else null_prompts for b in br], dim=0).contiguous()
         self.hist_real = _u8([b[0] for b in br], dev)
         self.mutual_real = _u8([b[1] if use_mutual_guidance else 0 for b in br], dev)
+        # The last two branches of every category-guidance mode differ only in their PROMPT (difashion.py:388-427: category_prompts vs
+        # null_prompts over the same history / mutual flags), so their U-Net inputs are identical: the U-Net computes the part of the walk
+        # that sees no text state once for the pair (dfh_unet_set_dup_tail).  DFH_CFG_DEDUP=0 turns it off (A/B).
+        flags = [(b[0], b[1] if use_mutual_guidance else 0) for b in br]
+        self.dup_tail = self.F if (len(br) >= 2 and flags[-1] == flags[-2] and os.environ.get("DFH_CFG_DEDUP", "1") != "0") else 0
         tab, wt = sampling_tables(olists)
         self.tab, self.wt, self.olen = tab.to(dev), wt.to(dev), olists.shape[1]
         self.sched.set_timesteps(num_inference_steps, device=dev)
@@ -159,6 +165,8 @@ class OutfitSampler:
         if static is not None:
             self.unet.assume_static_weights = True      # weights cannot change inside the loop: skip the dirty scan
         try:
+            if self.dup_tail and hasattr(self.unet, "_native_forward"):
+                self.unet._dup_tail_once = self.dup_tail
             self.eps_all = self.unet(self.x_in, t, self.ehs, return_dict=False)[0]
         finally:
             if static is not None:

@@ -127,6 +127,12 @@ int dfh_unet_forward(dfh_unet* u, const void* sample, int sample_bf16, const flo
 size_t dfh_unet_run_cache_bytes(const dfh_unet* u, int batch, int n_timesteps);
 int dfh_unet_run_cache(dfh_unet* u, const void* ehs, int ehs_bf16, int batch, const float* timesteps /* device [n] */, int n_timesteps,
                        void* cache, size_t cache_bytes, void* stream);
+/* One-shot hint for the NEXT dfh_unet_forward / dfh_unet_forward_cached call: the last `images` images of its batch have the same
+ * sample and timestep as the `images` before them and differ only in their encoder_hidden_states -- the prompt-only branch of
+ * classifier-free guidance (difashion.py:388-427, 494-512: category_prompts vs null_prompts over the same latent / mutual / history
+ * input).  conv_in, the first resnet and the first transformer block up to its self-attention are then computed once for the pair.
+ * The caller vouches for the equality; the call clears the hint.  bf16 walk only (ignored under dfh_unet_enable_fp8). */
+int dfh_unet_set_dup_tail(dfh_unet* u, int images);
 int dfh_unet_forward_cached(dfh_unet* u, const void* sample, int sample_bf16, const void* cache, int batch, int n_timesteps, int t_index,
                             float* out, void* stream);
 

@@ -544,7 +544,7 @@ def sampling_roofline(_lib, classes, bound, K, dtype):
     saved = float(_lib.raw().dfh_prof_saved_flops())
     executed = (gemm["flops"] - saved) / (gemm["ms"] * 1e-3) / 1e12
     traffic, traffic_src = pmc_traffic(dtype)
-    roofline = dict(bound="mfma", kernel="gemm_bf16_kernel + gemm_wide_kernel + mlp_fused_kernel (conv3x3 + 1x1 + linear: one implicit GEMM, all tile variants; "
+    roofline = dict(bound="mfma", kernel="gemm_bf16_kernel + gemm_wide_kernel + mlp2_fused_kernel (conv3x3 + 1x1 + linear: one implicit GEMM, all tile variants; "
                                          "the Winograd transform launches are timed with the convs they belong to)",
                     achieved=round(achieved, 1), peak=MFMA_BF16_PEAK, unit="TFLOP/s", frac=round(achieved / MFMA_BF16_PEAK, 4),
                     traffic=traffic, traffic_unit="HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE), measured on this walk's own dtype",

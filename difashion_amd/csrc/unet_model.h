@@ -627,13 +627,16 @@ struct dfh_unet {
     int Ba = 0;
     Tensor palloc(int H, int W, int C) { return Tensor{(bf16_t*)persist.alloc((size_t)Ba * H * W * C * 2), H, W, C}; }
     Tensor talloc(int H, int W, int C) { return Tensor{(bf16_t*)temp.alloc((size_t)Ba * H * W * C * 2), H, W, C}; }
-    void dup_images(Tensor& t, int n) {               // images [Ba - n, Ba) := images [Ba - 2n, Ba - n); producer statistics no longer cover the tensor
-      t.gst = nullptr;
+    void dup_bytes(void* p, size_t per_image, int n) {   // images [Ba - n, Ba) := images [Ba - 2n, Ba - n) of a [Ba][per_image bytes] buffer
       if (rc || dry || n <= 0) return;
-      const size_t e = (size_t)t.H * t.W * t.C;
-      if (hipMemcpyAsync(t.p + (size_t)(Ba - n) * e, t.p + (size_t)(Ba - 2 * n) * e, (size_t)n * e * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-        dfh::set_error("hipMemcpyAsync failed (dup_images)"); rc = -2;
+      char* c = (char*)p;
+      if (hipMemcpyAsync(c + (size_t)(Ba - n) * per_image, c + (size_t)(Ba - 2 * n) * per_image, (size_t)n * per_image, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        dfh::set_error("hipMemcpyAsync failed (dup_bytes)"); rc = -2;
       }
+    }
+    void dup_images(Tensor& t, int n) {               // the same for a tensor; its producer statistics no longer cover it
+      t.gst = nullptr;
+      dup_bytes(t.p, (size_t)t.H * t.W * t.C * 2, n);
     }
 
     // o / bump: the output tensor and the allocator it came from when the output feeds a GroupNorm -- the epilogue then leaves
@@ -926,7 +929,7 @@ struct dfh_unet {
       // round 4: proj_in, both to_out, ff.net.2 and proj_out in e4m3 as well, every operand quantised by the kernel that produces it
       const bool f8x = f8 && a.pin8.on;
       const bool fold = u->fold_valid && !fold_off && !f8 && !dry;
-      const bool pre = pre_n > 0 && !f8 && !dry && 2 * pre_n <= Bfull;
+      const bool pre = pre_n > 0 && !dry && 2 * pre_n <= Bfull;
       if (pre) { B = Bfull - pre_n; M = B * N; }
       float* st = (float*)temp.alloc((size_t)Ba * N * ((C + 63) / 64) * 2 * sizeof(float));       // [C / bn][M][2], bn >= 64
       int bn = 0;
@@ -959,9 +962,9 @@ struct dfh_unet {
       auto token_linear = [](const bf16_t*, size_t, const float*, const bf16_t*, const Fold*, bf16_t*, bool) {};
 #endif
       Tensor h0 = talloc(H, W, C);
-      uint8_t* a8 = f8x ? (uint8_t*)temp.alloc((size_t)M * C) : nullptr;          // e4m3 operand of proj_in, then of the two to_out
-      float* am_self = f8x ? amax_self + (size_t)a.idx * B : nullptr;
-      const float* am_cross = f8x ? amax_cross + (size_t)a.idx * B : nullptr;
+      uint8_t* a8 = f8x ? (uint8_t*)temp.alloc((size_t)Ba * N * C) : nullptr;          // e4m3 operand of proj_in, then of the two to_out
+      float* am_self = f8x ? amax_self + (size_t)a.idx * Ba : nullptr;
+      const float* am_cross = f8x ? amax_cross + (size_t)a.idx * Ba : nullptr;
       if (f8x) {
         groupnorm8(x, 1e-6f, a8);
         Fp8GemmArgs g = args8(a8, M, a.pin8, nullptr, h0.p);
@@ -1000,8 +1003,8 @@ struct dfh_unet {
       }
       // --- self attention
       Tensor n1 = talloc(H, W, C);
-      uint8_t* n8 = f8 ? (uint8_t*)temp.alloc((size_t)M * C) : nullptr;
-      float* s8 = f8 ? (float*)temp.alloc((size_t)M * sizeof(float)) : nullptr;
+      uint8_t* n8 = f8 ? (uint8_t*)temp.alloc((size_t)Ba * N * C) : nullptr;
+      float* s8 = f8 ? (float*)temp.alloc((size_t)Ba * N * sizeof(float)) : nullptr;
       Tensor qk = talloc(H, W, 2 * C);
       const int Np = (N + 7) & ~7;    // V^T rows padded to 8 keys (the 2x2 level of tiny configs has N = 4)
       bf16_t* vt = (bf16_t*)temp.alloc((size_t)Ba * C * Np * 2);   // [B][C][Np]
@@ -1043,6 +1046,11 @@ struct dfh_unet {
       const float* f8attn = (f8 && a.f8a && N % 64 == 0) ? (const float*)(u->arena8 + a.f8a_off) : nullptr;
       if (f8x) {
         attention8(qk.p, 2 * C, qk.p + C, 2 * C, vt, Np, a8, am_self, C, a.heads, N, N, 0, f8attn);
+        if (pre) {                                     // end of the shared prefix (e4m3 walk): rows, e4m3 attention output and its per-image max
+          B = Bfull; M = B * N;
+          dup_images(h0, pre_n); dup_bytes(a8, (size_t)N * C, pre_n); dup_bytes(am_self, sizeof(float), pre_n);
+          dfh::census(dfh::CK_DUP_PREFIX);
+        }
         Fp8GemmArgs g = args8(a8, M, a.o18, &a.o1b, h1.p);
         g.sA = am_self; g.sa_div = N; g.sa_mul = 1.0f / 448.0f; g.resid = h0.p; g.ld_res = C;
         gemm8(g);
@@ -1178,7 +1186,7 @@ struct dfh_unet {
     Run r; r.u = this; r.B = B; r.Ba = B; r.s = s; r.dry = dry;
     r.temb_ld = (rcache && rcache->temb_row) ? 0 : temb_total;
     // one-shot hint of the caller (dfh_unet_set_dup_tail): the last `dup` images repeat the sample / timestep of the `dup` before them
-    const int dup = (!dry && !fp8 && dup_tail > 0 && 2 * dup_tail <= B) ? dup_tail : 0;
+    const int dup = (!dry && dup_tail > 0 && 2 * dup_tail <= B) ? dup_tail : 0;
     if (!dry) dup_tail = 0;
     const int S = cfg.sample_size, T = cfg.text_len, X = cfg.cross_attention_dim;
     const int* boc = cfg.block_out_channels;

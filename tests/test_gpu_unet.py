@@ -129,15 +129,17 @@ def test_run_cache_reproduces_the_uncached_forward_bit_for_bit():
 
 
 @pytest.mark.parametrize("name,cfg", [("tiny", unet_ref.TINY), ("glue", GLUE_CFG)])
-@pytest.mark.parametrize("B,n", [(8, 2), (4, 2), (6, 1)])
-def test_dup_tail_prefix_equals_the_full_batch_walk(name, cfg, B, n):
+@pytest.mark.parametrize("B,n,fp8", [(8, 2, False), (4, 2, False), (6, 1, False), (8, 2, True), (4, 2, True)])
+def test_dup_tail_prefix_equals_the_full_batch_walk(name, cfg, B, n, fp8):
     """dfh_unet_set_dup_tail: the prompt-only branch of classifier-free guidance (difashion.py:388-427, 494-512 -- category_prompts vs
     null_prompts over the same latent / mutual / history input).  With the last n images repeating the sample of the n before them and only
     the text states differing, conv_in, the first resnet and the first block up to its self-attention run on B - n images; the result must
     equal the plain walk over all B images (to bf16 tile-choice noise -- the shorter launches may pick other tiles), the hint must be
     consumed by ONE call, and a batch whose repeated images are NOT equal must not be touched by a stale hint."""
     from difashion_amd import _lib
-    m = hip_unet(cfg, unet_ref.init_params(cfg, seed=5), max_batch=8)
+    m = hip_unet(cfg, unet_ref.init_params(cfg, seed=5, w_std=0.05, affine_jitter=0.1) if fp8 else unet_ref.init_params(cfg, seed=5), max_batch=8)
+    if fp8:
+        m.enable_fp8()           # the e4m3 walk: the prefix also carries the e4m3 attention output and its per-image maxima
     x, e = inputs(cfg, B, 23)
     x, e = x.to(DEV), e.to(DEV)
     x[B - n:] = x[B - 2 * n:B - n]
@@ -151,8 +153,8 @@ def test_dup_tail_prefix_equals_the_full_batch_walk(name, cfg, B, n):
     assert used == (1 if cfg.down_attn[0] else 0), used      # the census counts the transformer block that ended the shared prefix
     assert torch.equal(again, ref)
     scale = ref.abs().max().item()
-    assert (got - ref).abs().max().item() <= 2e-2 * scale, ((got - ref).abs().max().item(), scale)
-    assert (got - ref).float().norm().item() <= 4e-3 * ref.float().norm().item()
+    assert (got - ref).abs().max().item() <= (6e-2 if fp8 else 2e-2) * scale, ((got - ref).abs().max().item(), scale)
+    assert (got - ref).float().norm().item() <= (1.5e-2 if fp8 else 4e-3) * ref.float().norm().item()
     # the repeated images went through different text states: their outputs must differ from the images they repeat
     assert not torch.equal(got[B - n:], got[B - 2 * n:B - n])
 

@@ -20,7 +20,7 @@ def gemm_family(stats_csv):
     n, ns = 0, 0.0
     for r in csv.DictReader(open(stats_csv)):
         name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-        if name.startswith(("gemm_bf16_kernel", "gemm_wide_kernel")):
+        if name.startswith(("gemm_bf16_kernel", "gemm_wide_kernel", "mlp2_fused_kernel")):      # the fused feed-forward is part of the family (round 5)
             n += int(r["Calls"]); ns += float(r["TotalDurationNs"])
     return n, ns / 1e6, (ns / n / 1e3 if n else 0.0)
 
@@ -52,6 +52,21 @@ def block(tag):
     tr = last_json(os.path.join(d, "bench_train_n1.json"))
     if tr:
         out.append(f"* training step (`{tag}/bench_train_n1.json`): {tr['value']:.1f} {tr['unit']} ({tr['ms_per_step']:.1f} ms per step).")
+    sc = (b or {}).get("secondary_configs")
+    if sc:
+        parts = []
+        for k, v in sc.items():
+            if not isinstance(v, dict) or "ms_per_step" not in v:
+                continue
+            parts.append(f"{k} {v['ms_per_step']:.2f} ms per step" + (f" ({v['steps_per_s']:.1f} steps/s)" if "steps_per_s" in v else "")
+                         + (f" ({v['items_per_s']:.1f} items/s)" if "items_per_s" in v else ""))
+        if parts:
+            out.append(f"* `secondary_configs` of the same default run (`{tag}/bench_n1.json`): " + "; ".join(parts) + ".")
+    for name, what in (("bench_sd2base_n1.json", "SD-2-base shape, bf16"), ("bench_sd2base_fp8_n1.json", "SD-2-base shape, fp8"),
+                       ("bench_batch64_n1.json", "`--outfits-per-gpu 4` (U-Net batch 64)")):
+        x = last_json(os.path.join(d, name))
+        if x:
+            out.append(f"* {what} (`{tag}/{name}`): {x['value']:.1f} {x['unit']} ({x['ms_per_step']:.2f} ms per step), `roofline.frac` {x['roofline']['frac']:.3f}.")
     va = last_json(os.path.join(d, "bench_vae_n1.json"))
     if va:
         out.append(f"* VAE (`{tag}/bench_vae_n1.json`): {va['value']:.1f} {va['unit']}.")
@@ -62,6 +77,20 @@ def block(tag):
         if b:
             line += f"; `roofline.avg_launch_us` of the committed bench line (another run, HIP events): {b['roofline']['avg_launch_us']:.1f} us"
         out.append(line + ".")
+    st8 = os.path.join(d, "kernel_stats_fp8.csv")
+    if os.path.exists(st8):
+        n8, ns8 = 0, 0.0
+        for r in csv.DictReader(open(st8)):
+            if "gemm_fp8_kernel" in r["Name"]:
+                n8 += int(r["Calls"]); ns8 += float(r["TotalDurationNs"])
+        if n8:
+            out.append(f"* rocprofv3 of the fp8 walk (`{tag}/kernel_stats_fp8.csv`): {n8} launches of `gemm_fp8_kernel` total {ns8 / 1e6:.2f} ms = {ns8 / n8 / 1e3:.1f} us per launch.")
+    p8 = os.path.join(d, "pmc_traffic_fp8.json")
+    if os.path.exists(p8):
+        q = json.load(open(p8))
+        g8 = q.get("gemm_fp8_kernel")
+        out.append(f"* PMC of the fp8 walk (`{tag}/pmc_traffic_fp8.json`): bf16 GEMM family {q['hbm_bytes_per_launch'] / 1e6:.1f} MB per launch over {q['launches']} launches"
+                   + (f"; `gemm_fp8_kernel` {g8['hbm_bytes_per_launch'] / 1e6:.1f} MB per launch over {g8['launches']} launches" if g8 else "") + ".")
     pt = os.path.join(d, "pmc_traffic.json")
     if os.path.exists(pt):
         p = json.load(open(pt))

@@ -1254,6 +1254,24 @@ struct dfh_unet {
     }
     Tensor x = r.palloc(S, S, conv_in.cin);   // in_channels padded to a multiple of 8
     if (!dry && !r.rc) r.rc = dfh::nchw_to_nhwc_launch(sample, sample_bf16, x.p, B, cfg.in_channels, S * S, s);
+    if (dup && !r.rc) {
+      // DFH_CHECK_DUP=1 (debugging a caller): verify what the hint claims -- the repeated images' inputs equal the ones they repeat --
+      // with a synchronous compare of the converted input rows; a wrong hint is an error, not a silently different result
+      static const bool check = [] { const char* e = getenv("DFH_CHECK_DUP"); return e && e[0] == '1'; }();
+      if (check) {
+        const size_t per = (size_t)S * S * conv_in.cin * 2, n = (size_t)dup * per;
+        std::vector<char> a(n), b(n);
+        if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(a.data(), (char*)x.p + (size_t)(B - 2 * dup) * per, n, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(b.data(), (char*)x.p + (size_t)(B - dup) * per, n, hipMemcpyDeviceToHost) != hipSuccess) { dfh::set_error("DFH_CHECK_DUP: copy failed"); return -2; }
+        if (std::memcmp(a.data(), b.data(), n) != 0) { dfh::set_error("dfh_unet_set_dup_tail: the last images do NOT repeat the inputs of the ones before them"); return -1; }
+        if (timestep && !(rcache && rcache->temb_row)) {
+          std::vector<float> t(B);
+          if (hipMemcpy(t.data(), timestep, (size_t)B * 4, hipMemcpyDeviceToHost) != hipSuccess) { dfh::set_error("DFH_CHECK_DUP: copy failed"); return -2; }
+          for (int i = 0; i < dup; ++i)
+            if (t[B - dup + i] != t[B - 2 * dup + i]) { dfh::set_error("dfh_unet_set_dup_tail: the repeated images sit at other timesteps"); return -1; }
+        }
+      }
+    }
 
     // Shared prefix of a guidance batch (reference difashion.py:388-427, 494-512: the branches of classifier-free guidance that differ only
     // in their PROMPT get the same latent / mutual / history input): conv_in, the first resnet and the first transformer block up to its

@@ -131,7 +131,7 @@ int dfh_unet_run_cache(dfh_unet* u, const void* ehs, int ehs_bf16, int batch, co
  * sample and timestep as the `images` before them and differ only in their encoder_hidden_states -- the prompt-only branch of
  * classifier-free guidance (difashion.py:388-427, 494-512: category_prompts vs null_prompts over the same latent / mutual / history
  * input).  conv_in, the first resnet and the first transformer block up to its self-attention are then computed once for the pair.
- * The caller vouches for the equality; the call clears the hint. */
+ * The caller vouches for the equality (DFH_CHECK_DUP=1 verifies it with a synchronous compare: debugging aid); the call clears the hint. */
 int dfh_unet_set_dup_tail(dfh_unet* u, int images);
 int dfh_unet_forward_cached(dfh_unet* u, const void* sample, int sample_bf16, const void* cache, int batch, int n_timesteps, int t_index,
                             float* out, void* stream);

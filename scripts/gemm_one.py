@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One GEMM shape a few times (PMC target): python scripts/gemm_one.py conv320|lin320|conv1280"""
+"""One GEMM shape a few times (PMC target): python scripts/gemm_one.py conv320|lin320|conv1280|lin320k320|lin960k320"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gemm_microbench import run
@@ -8,5 +8,9 @@ if which == "conv320":
     run("conv 320->320 @64", 65536, 320, 0, conv=(16, 64, 320, 1, 0), resid=False)
 elif which == "conv1280":
     run("conv 1280->1280 @16", 4096, 1280, 0, conv=(16, 16, 1280, 1, 0), resid=False)
+elif which == "lin320k320":
+    run("linear 64^2 N=K=320 plain", 65536, 320, 320, resid=False)
+elif which == "lin960k320":
+    run("linear 64^2 N=960 K=320 plain", 65536, 960, 320, resid=False, bias=False)
 else:
     run("linear 64^2 C320 K1280", 65536, 320, 1280)

@@ -4,6 +4,8 @@ Stated tolerance (north star: "within a stated fp32 tolerance"): the HIP path st
 weights in bf16 (fp32 accumulate), the oracle is fp32 end to end.  Bound used here: relative L2 error of
 the noise prediction <= 3e-2 and of every block-level tap <= 3e-2 (observed values are printed).
 """
+import os
+
 import pytest
 import torch
 
@@ -157,6 +159,33 @@ def test_dup_tail_prefix_equals_the_full_batch_walk(name, cfg, B, n, fp8):
     assert (got - ref).float().norm().item() <= (1.5e-2 if fp8 else 4e-3) * ref.float().norm().item()
     # the repeated images went through different text states: their outputs must differ from the images they repeat
     assert not torch.equal(got[B - n:], got[B - 2 * n:B - n])
+
+
+def test_dup_tail_hint_that_does_not_hold_is_caught_under_check_mode():
+    """DFH_CHECK_DUP=1 (a debugging aid for callers of dfh_unet_set_dup_tail): a hint whose repeated images are NOT equal fails loudly
+    instead of producing the repeated images' outputs for the wrong inputs.  Runs in a child process (the switch is read once)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import torch
+        from oracle import unet_ref
+        from tests.test_gpu_unet import hip_unet, inputs, DEV
+        from difashion_amd import _lib
+        cfg = unet_ref.TINY
+        m = hip_unet(cfg, unet_ref.init_params(cfg, seed=5), max_batch=4)
+        x, e = inputs(cfg, 4, 23); x, e = x.to(DEV), e.to(DEV)
+        with torch.no_grad():
+            m._dup_tail_once = 2
+            try:
+                m(x, 501, e); print("NOT CAUGHT")
+            except _lib.DfhError as err:
+                print("CAUGHT", err)
+            x[2:] = x[:2]
+            m._dup_tail_once = 2
+            m(x, 501, e); print("EQUAL INPUTS PASS")
+    """)
+    env = dict(os.environ, DFH_CHECK_DUP="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+    assert "CAUGHT" in r.stdout and "do NOT repeat" in r.stdout and "EQUAL INPUTS PASS" in r.stdout and "NOT CAUGHT" not in r.stdout, r.stdout + r.stderr
 
 
 def test_prepare_run_with_a_batch_above_max_batch_grows_the_context():

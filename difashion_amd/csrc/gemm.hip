@@ -105,7 +105,7 @@ void gemm_bf16_kernel(const GemmArgs a) {
     a_pix[i] = -1; a_y[i] = 0; a_x[i] = 0; a_bbase[i] = 0;
     if (m < a.M && i * NWV + wave < PA) {
       a_pix[i] = m;
-      if (a.ntaps) {
+      if (!LEAN && a.ntaps) {                     // LEAN instantiations only ever see plain segments (lean_plain): no pixel decode
         const int b = m / HWo, rem = m - b * HWo;
         const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
         a_y[i] = oy * a.stride - (a.pad0 ? 0 : 1); a_x[i] = ox * a.stride - (a.pad0 ? 0 : 1);
@@ -128,9 +128,9 @@ void gemm_bf16_kernel(const GemmArgs a) {
   const unsigned cc = (unsigned)a.conv_c;
   // Lean tap staging (stride-1 3x3 convs over whole 64-channel slices), see gemm_wide.hip: centre-pixel offset + 9-bit
   // tap-validity mask per staging piece, fixed for the kernel
-  const bool leanc = (a.ntaps == 9 || a.phase2x) && a.stride == 1 && a.ups == 0 && !a.pad0 && (a.conv_c % BK) == 0;
+  const bool leanc = !LEAN && (a.ntaps == 9 || a.phase2x) && a.stride == 1 && a.ups == 0 && !a.pad0 && (a.conv_c % BK) == 0;
   // phase-decomposed upsample conv (GemmArgs::phase2x): segment s of this plane is 3x3-tap position ((s >> 1) + py, (s & 1) + px)
-  const int ppy = a.phase2x ? (int)(blockIdx.y >> 1) : 0, ppx = a.phase2x ? (int)(blockIdx.y & 1) : 0;
+  const int ppy = (!LEAN && a.phase2x) ? (int)(blockIdx.y >> 1) : 0, ppx = (!LEAN && a.phase2x) ? (int)(blockIdx.y & 1) : 0;
   // phase2x == 2 (the DATA GRADIENT of that conv, training): plane (py, px) convolves ITS image of output-gradient pixels (conv_src + plane *
   // a_bs) with the transposed phase weights, tap s at the mirrored position (2 - py - (s >> 1), 2 - px - (s & 1)); plain output rows per plane
   auto tap_of = [&](int seg) {
@@ -531,7 +531,7 @@ void gemm_bf16_kernel(const GemmArgs a) {
       const int row = c / CPR, cc = c - row * CPR;
       const int m = m0 + row, n = n0 + cc * 8;
       long orow = m;
-      if (a.phase2x == 1) {                          // source pixel (b, y, x) -> pixel (2y + py, 2x + px) of the 2H x 2W output
+      if (!LEAN && a.phase2x == 1) {                 // source pixel (b, y, x) -> pixel (2y + py, 2x + px) of the 2H x 2W output
         const int b = m / HWo, rem = m - b * HWo;
         const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
         orow = (long)b * 4 * HWo + (long)(2 * oy + ppy) * (2 * a.Wout) + 2 * ox + ppx;

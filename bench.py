@@ -534,7 +534,7 @@ def launch_ranks(n, argv):
     return 1
 
 
-def sampling_roofline(_lib, classes, bound, K, dtype):
+def sampling_roofline(_lib, classes, bound, K, dtype, pmc_walk=True):
     """roofline object of a sampling run from the live HIP-event profile (dominant family: every conv3x3 / 1x1 / linear GEMM)."""
     gemm = {k: sum(classes[c][k] for c in ("gemm_conv3x3", "gemm_linear")) for k in ("launches", "ms", "flops", "bytes")}
     achieved = gemm["flops"] / (gemm["ms"] * 1e-3) / 1e12
@@ -543,7 +543,8 @@ def sampling_roofline(_lib, classes, bound, K, dtype):
     # flops = the REFERENCE algorithm's; the upsampler convs (phase planes) and the Winograd convs execute fewer
     saved = float(_lib.raw().dfh_prof_saved_flops())
     executed = (gemm["flops"] - saved) / (gemm["ms"] * 1e-3) / 1e12
-    traffic, traffic_src = pmc_traffic(dtype)
+    # the committed PMC summaries were measured on the configs[1] walk (SD-1.5 shape, one outfit): another shape / batch reports null, never that figure
+    traffic, traffic_src = pmc_traffic(dtype) if pmc_walk else (None, "no PMC summary for this workload (profiles/rNN/pmc_traffic*.json are the SD-1.5, one-outfit walk)")
     roofline = dict(bound="mfma", kernel="gemm_bf16_kernel + gemm_wide_kernel + mlp2_fused_kernel (conv3x3 + 1x1 + linear: one implicit GEMM, all tile variants; "
                                          "the Winograd transform launches are timed with the convs they belong to)",
                     achieved=round(achieved, 1), peak=MFMA_BF16_PEAK, unit="TFLOP/s", frac=round(achieved / MFMA_BF16_PEAK, 4),
@@ -632,7 +633,8 @@ def measure_sampling(da, _lib, ddist, unet, enc, dev, rank, K, W, outfits=1, dty
         res["prof_ms"] = (time.perf_counter() - t1) * 1e3 / K
         res["bound"] = per_launch_bound(dump, K)
         res["classes"] = classes
-        res["roofline"] = sampling_roofline(_lib, classes, res["bound"], K, dtype)
+        res["roofline"] = sampling_roofline(_lib, classes, res["bound"], K, dtype,
+                                            pmc_walk=(outfits == 1 and cross == 768))      # the PMC summaries are the SD-1.5, one-outfit walk
     unet.end_run()
     return res
 

@@ -1,4 +1,4 @@
-// Fused GEGLU feed-forward + proj_out of a transformer block at C = 320 (mlp_fused.hip).
+// Fused GEGLU feed-forward + proj_out of a transformer block at C = 320 (mlp_fused2.hip; form 1, a probe kernel: scripts/probes/kernels/mlp_fused_v1.hip).
 #pragma once
 #include "gemm.h"
 

@@ -1,16 +1,32 @@
-// The GEGLU feed-forward + proj_out of a C = 320 transformer block as one kernel, SECOND form: eight waves of 16 tokens (two per SIMD).
+// The GEGLU feed-forward of a transformer block as ONE kernel (C = 320: the 64x64 level of the SD U-Nets):
 //
-// Same algorithm and the same memory traffic as mlp_fused.hip (read that header first): X in registers as the MFMA B operand, the hidden
-// units never leave the wave, [pout . ff2 | pout] as the second GEMM with the raw rows as its last K segment, the weights as a
-// fragment-major image staged through registers into a double-buffered LDS ring.  What changes is the shape of a wave.  The first form
-// gave a wave 32 tokens on v_mfma_f32_32x32x16_bf16: 80 + 160 accumulator / operand registers, one wave per SIMD -- and measured
-// (profiles/r05/mlp_fused_v1_microbench.txt) that ONE wave does not overlap its own MFMAs with its own VALU / LDS / VMEM issue: an
-// iteration took the SUM of its 1920 matrix-pipe cycles and its ~3000 cycles of other instructions (257 us per launch, 39 % matrix-pipe
-// occupancy).  Here a wave owns 16 tokens on v_mfma_f32_16x16x32_bf16 -- X 40 + D2 80 + D1 2 x 16 registers of ~250, ALL of them VGPRs:
-// a function that touches AGPRs gets its 256-register budget split 128 / 128 by the compiler, and 128 VGPRs do not hold the rest -- so
-// a 512-thread workgroup puts TWO waves on every SIMD and one's MFMAs run under the other's GEGLU slices, fragment reads and staging.
-// The price: a 16-row weight fragment (1 KB from LDS) feeds one 16-cycle MFMA, so at full matrix-pipe rate the four SIMDs would ask
-// the LDS for its whole 256 B/clk -- the kernel is LDS-read bound at ~480 KB per iteration, not MFMA bound.
+//     out = proj_out( ff.net.2( GEGLU( ff.net.0( LayerNorm3(x) ) ) ) + x ) + resid
+//
+// Reference call site: DiFashion/models/difashion.py:518-523 -> diffusers BasicTransformerBlock.ff (GEGLU FeedForward) + Transformer2DModel.proj_out.
+// As two launches (the folded-LayerNorm GEGLU projection, then [proj_out . ff2 | proj_out] over [hidden | h2]) the hidden tensor
+// ([tokens][4 C] bf16: 168 MB at batch 16) makes a round trip through HBM and the short-K GEMMs around it run behind their epilogues
+// (250-262 us per block).  Here a wave owns 16 tokens for the whole chain and the hidden units never leave its registers:
+//
+//   * X (raw rows; LayerNorm folded into the weights: lnfold.hip) sits in 40 VGPRs as the B operand of v_mfma_f32_16x16x32_bf16 for all ten
+//     k-steps, read once from HBM;
+//   * per chunk of 32 hidden units: D1[64 packed rows][16 tokens] = W1'[chunk] . X^T (40 MFMAs), the LayerNorm fix-up and the GEGLU gate on the
+//     accumulators (the packed rows put value and gate of a hidden unit into the same lane), and the rounded product IS the B operand of the
+//     second GEMM -- the C layout of two 16-row tiles is the B layout of a 32-deep k-step once the weight columns are permuted to match
+//     (mlp2_pack_kernel) -- D2[320][16 tokens] += W2[:, chunk] . H (20 MFMAs);
+//   * the [hidden | h2] K-segment trick of the unfused walk (AttL::fffp: ff.net.2 and proj_out as one matrix) carries over: after the last
+//     chunk D2 += Wp . X^T (100 MFMAs on the same X registers), then bias + residual + store through the dead weight ring, and the
+//     GroupNorm statistics of the output for the next resnet.
+//
+// Eight waves of one workgroup (two per SIMD) share the weight stream: every chunk's W1' / W2 slices are stored in HBM as the LDS image the
+// fragment reads want (1-KB blocks, lane-linear), staged through registers one chunk ahead into a double-buffered ring, one barrier per
+// chunk.  The shape of a wave is the result of a measurement: the first form of this kernel (scripts/probes/kernels/mlp_fused_v1.hip) gave a
+// wave 32 tokens on v_mfma_f32_32x32x16_bf16, one wave per SIMD, and showed that ONE wave does not overlap its own MFMAs with its own
+// VALU / LDS / VMEM issue: an iteration took the SUM of its 1920 matrix-pipe cycles and its ~3000 cycles of other instructions (257-265 us
+// per launch, profiles/r05/mlp_fused_v1_microbench.txt).  With 16 tokens per wave -- X 40 + D2 80 + D1 2 x 16 registers of ~250, ALL of
+// them VGPRs (a function that touches AGPRs gets its 256-register budget split 128 / 128) -- a 512-thread workgroup puts TWO waves on
+// every SIMD and one's MFMAs run under the other's GEGLU slices, fragment reads and staging: 239-250 us.  The price: a 16-row weight
+// fragment (1 KB from LDS) feeds one 16-cycle MFMA, so at full matrix-pipe rate the four SIMDs would ask the LDS for its whole 256 B/clk
+// -- the kernel is LDS-read bound at ~480 KB per iteration, not MFMA bound.
 //
 // Layouts (v_mfma_f32_16x16x32_bf16; lane = (c = lane & 15, g = lane >> 4)): A row c, k = 8 g .. 8 g + 7 of the 32-deep step; B column c,
 // same k; D column c, rows 4 g + r.  Packed W1' rows come as [16 values | 16 gates] per 16 hidden units, so a (value tile, gate tile)

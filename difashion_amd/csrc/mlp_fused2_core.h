@@ -80,7 +80,7 @@ DFH_DEVICE void geglu_slice2(Mlp2State& st, unsigned vb, int pr, int k) {
   }
 }
 
-// One pipeline iteration (see mlp_fused.hip mlp_iter): KIND 0 = first GEMM of a chunk (parity PAR) into st.d1[PAR], KIND 1 = h2 slice Q;
+// One pipeline iteration: KIND 0 = first GEMM of a chunk (parity PAR) into st.d1[PAR], KIND 1 = h2 slice Q;
 // PREV: GEGLU + second GEMM of the previous chunk; off_w1 / off_w2: image offsets of the 40-piece W1-ring set (-> slot 1 - PAR) and of
 // the 21-piece W2 + vector set of the current chunk (-> slot PAR) staged by this iteration, negative = none.
 template <int KIND, int PAR, bool PREV, int Q>

@@ -62,7 +62,7 @@ struct AttL {
   // pout . ff2b + poutb -- proj_out(ff2(f) + ff2b + h2) + poutb as written, minus one launch, one bf16 rounding and one round trip
   // of a [tokens][C] tensor per transformer block
   Fold fffp;
-  // C = 320 (the 64x64 level): the whole feed-forward + proj_out as ONE kernel (mlp_fused.hip); its weight image (fragment-major LDS
+  // C = 320 (the 64x64 level): the whole feed-forward + proj_out as ONE kernel (mlp_fused2.hip); its weight image (fragment-major LDS
   // image of fff1 and fffp, 2.7 MB) in the fold region
   size_t mlp_img = 0; bool has_mlp = false;
   // ... and its four K = N = C projections (proj_in, attn1.to_out, attn2.to_q folded, attn2.to_out) as register-resident token linears

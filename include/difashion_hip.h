@@ -361,7 +361,7 @@ typedef struct dfh_gemm_fp8_desc {
 int dfh_quantize_rows_fp8(const void* x, int ldx, void* q, float* scale, int R, int K, void* stream);
 int dfh_layernorm_fp8(const void* x, const float* gamma, const float* beta, void* q, float* scale, int M, int C, float eps, void* stream);
 int dfh_gemm_fp8(const dfh_gemm_fp8_desc* d, void* stream);
-/* Fused GEGLU feed-forward + proj_out of a transformer block at C = 320 (csrc/mlp_fused.hip; replaces the ff.net.0 / ff.net.2 / proj_out
+/* Fused GEGLU feed-forward + proj_out of a transformer block at C = 320 (csrc/mlp_fused2.hip; replaces the ff.net.0 / ff.net.2 / proj_out
  * launches of diffusers BasicTransformerBlock.ff + Transformer2DModel.proj_out at the 64x64 level, reference call site
  * DiFashion/models/difashion.py:518-523):  out = [pout . ff2 | pout] . [GEGLU(LN3(x) . W1^T + b1) | x] + bias + resid.
  *   dfh_mlp_fused_pack : builds the layer's weight image (dfh_mlp_fused_image_bytes() bytes) from the LayerNorm-folded GEGLU projection

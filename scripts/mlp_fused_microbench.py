@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The fused GEGLU feed-forward + proj_out kernel (csrc/mlp_fused.hip) against the two launches it replaces, at the 64x64-level shape of a
+"""The fused GEGLU feed-forward + proj_out kernel (csrc/mlp_fused2.hip; FORM=1: the probe kernel, with the probe library) against the two launches it replaces, at the 64x64-level shape of a
 sampling step (M = 16 x 4096 tokens, C = 320), through the C ABI.  GPU only.
     python scripts/mlp_fused_microbench.py [M]"""
 import ctypes, os, sys

@@ -55,7 +55,7 @@ def per_kernel(sub):
 ft, fn = per_kernel("pmc_fetch")
 wt, wn = per_kernel("pmc_write")
 # the dominant family as bench.py defines it: every conv3x3 / 1x1 / linear launch of the bf16 classes (the fused feed-forward kernel included)
-gem = [k for k in ft if k.startswith(("gemm_bf16_kernel", "gemm_wide_kernel", "mlp2_fused_kernel", "mlp_fused_kernel"))]
+gem = [k for k in ft if k.startswith(("gemm_bf16_kernel", "gemm_wide_kernel", "mlp2_fused_kernel"))]
 if gem:
     launches = sum(fn[k] for k in gem)
     fetch_kb = sum(ft[k] for k in gem); write_kb = sum(wt.get(k, 0) for k in gem)

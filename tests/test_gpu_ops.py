@@ -1092,7 +1092,7 @@ def test_gemm_fp8_transposed_output():
 @pytest.mark.parametrize("form", [1, 2])
 @pytest.mark.parametrize("M,parts,offset", [(128, 2, 0.0), (512, 2, 3.0), (1024, 5, 0.0), (384, 1, 0.0)])
 def test_mlp_fused_matches_torch(M, parts, offset, form):
-    """dfh_mlp_fused (csrc/mlp_fused.hip): the GEGLU feed-forward + proj_out of a C = 320 transformer block in one kernel,
+    """dfh_mlp_fused (csrc/mlp_fused2.hip; form 1 = the probe kernel scripts/probes/kernels/mlp_fused_v1.hip): the GEGLU feed-forward + proj_out of a C = 320 transformer block in one kernel,
     out = proj_out(ff.net.2(GEGLU(ff.net.0(LN3(x)))) + x) + resid, against fp32 torch on the same bf16 operands -- and against the
     two-launch walk it replaces (folded-LayerNorm GEGLU projection, then the [hidden | x] linear), in both forms of the kernel (32-token
     waves on the 32x32x16 MFMA, one per SIMD; 16-token waves on the 16x16x32 MFMA, two per SIMD: the walk's default).  Row statistics come in the producer's

@@ -335,7 +335,7 @@ def test_unet_sd15_full_size_batch16_matches_oracle():
     assert cen["gemm_lean"] + cen["gemm_row"] > 0, cen                 # the short-K token linears
     assert cen["ln_folded"] >= 45 and cen["layernorm"] <= 3, cen       # LayerNorm folded into its consumers (all but the 8x8 block)
     assert cen["conv_wino"] == 24 and cen["conv_phase"] == 3, cen      # Winograd at the 16x16 / 8x8 levels, phase-plane upsamplers
-    assert cen["mlp_fused"] == 5, cen                                  # the five 64x64-level feed-forwards as one kernel each (mlp_fused.hip)
+    assert cen["mlp_fused"] == 5, cen                                  # the five 64x64-level feed-forwards as one kernel each (mlp_fused2.hip)
     assert cen["gn_folded"] == 5, cen                                  # ... and their entry GroupNorms folded into proj_in (norm.h GnFoldArgs)
     m.enable_fp8()
     with torch.no_grad():

@@ -15,6 +15,7 @@
 // (X^T fragments: head-dim rows, tile rows as contraction) are read transposed from the same row-major
 // LDS tiles with ds_read_b64_tr_b16.  Accumulators are transposed (out^T[d][col]) so a lane finishes with
 // 4 consecutive head-dim values of its own query / key: 8-byte stores, no cross-lane traffic.
+#include <cstdlib>
 #include <type_traits>
 #include "dfh_common.h"
 #include "attention.h"
@@ -54,8 +55,22 @@ DFH_DEVICE bf16x8_t tr_frag(const unsigned char* tile, int m0, int d0, int L) {
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// X32 variant: rows m0 + {0..3} and m0 + 8 + {0..3} of head-dim column d0 + L (the k-slot order the swapped 32x32 C layout leaves in a lane
+// group), tile swizzled by (row >> 1) & 7
+template <int STR>
+DFH_DEVICE bf16x8_t tr_frag_x32(const unsigned char* tile, int m0, int d0, int L) {
+  const int col = d0 + (L & 3) * 4;
+  const int r0 = m0 + (L >> 2), r1 = r0 + 8;
+  const unsigned char* p0 = tile + r0 * STR + ((((col >> 3)) ^ ((r0 >> 1) & 7)) << 4) + (col & 7) * 2;
+  const unsigned char* p1 = tile + r1 * STR + ((((col >> 3)) ^ ((r1 >> 1) & 7)) << 4) + (col & 7) * 2;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
 // KV_SIDE = false: columns are queries (dQ pass); true: columns are keys (dK / dV pass)
-template <int D, bool KV_SIDE, int NT>
+template <int D, bool KV_SIDE, int NT, bool X32W = false>
 __global__ __launch_bounds__(256, ((D <= 40 && !KV_SIDE) ? 3 : 1)) void attention_bwd_kernel(const AttnBwdArgs a) {
   using G = BwdGeom<D>;
   constexpr int KS = G::KS, DF = G::DF, STR = G::STR;
@@ -86,15 +101,48 @@ __global__ __launch_bounds__(256, ((D <= 40 && !KV_SIDE) ? 3 : 1)) void attentio
   // Rows beyond the streamed range: slot D + 2 is 1.0 on such a key row and -30000 on every query column (P = exp2(-30000) = 0); a query
   // row beyond Nq carries -30000 in place of -lse.
   constexpr bool PADS = KS * 32 - D >= 8 && D % 8 == 0;
+  // X32 (d = 40): S and dP on v_mfma_f32_32x32x16_bf16 -- the contraction padded to 48 instead of 64 (three 16-deep steps: a quarter of
+  // the S / dP matrix-pipe cycles), a lane owns ONE column (lane & 31) and 16 of the 32 rows of a chunk.  P and dS then leave the C
+  // layout of the 32x32 tile for the B layout of the 16x16x32 accumulation MFMAs through four v_permlane16_swap per matrix: the pairs
+  // of rows (8 i + 4 hi + j, i = 0..1) and (i = 2..3) of the two column halves trade 16-lane rows, after which lane group g holds
+  // rows {0-3, 8-11} + {0, 16, 4, 20}[g] of its column -- the order the transposed fragment reads of X^T follow.
+  constexpr bool X32 = X32W && PADS && D == 40 && NT == 2;
+  constexpr int KS32 = (D + 8 + 15) / 16;
   constexpr float MASKV = -30000.0f;
   const float c = a.scale * 1.44269504088896340736f;
   auto split2 = [](float v) {                       // v ~ hi + lo, both bf16
     const float hi = bf2f((bf16_t)(pack2bf(v, 0.f) & 0xffffu));
     return pack2bf(hi, v - hi);
   };
+  auto sw_of = [](int row) { return X32 ? ((row >> 1) & 7) : swz<STR>(row); };      // X32: 32 consecutive rows per fragment read
+  // X32: column operands of the 32x32x16 MFMAs -- lane (column lane & 31, half hi = lane >> 5) holds d = 16 ks + 8 hi .. + 7
+  bf16x8_t yx1[X32 ? KS32 : 1], yx2[X32 ? KS32 : 1];
+  if (X32) {
+    const int col = c0 + (lane & 31), hi = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < KS32; ++ks) {
+      const int d0 = ks * 16 + hi * 8;
+      uint4 v1 = uint4{0, 0, 0, 0}, v2 = uint4{0, 0, 0, 0};
+      if (col < ncols && d0 < D) {
+        v1 = *(const uint4*)(Y1 + (long)col * ldy1 + d0);
+        v2 = *(const uint4*)(Y2 + (long)col * ldy2 + d0);
+        float f[8];
+        unpack8(v1, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= c;
+        v1 = pack8(f);
+      } else if (col < ncols && d0 == D) {
+        if (KV_SIDE) { v1.x = pack2bf(1.0f, 1.0f); v2.x = v1.x; }
+        else { v1.x = split2(-lse[col]); v1.y = pack2bf(MASKV, 0.f); v2.x = split2(-dlt[col]); }
+      }
+      yx1[ks] = __builtin_bit_cast(bf16x8_t, v1);
+      yx2[ks] = __builtin_bit_cast(bf16x8_t, v2);
+    }
+  }
   bf16x8_t y1[NT][KS], y2[NT][KS];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
+    if (X32) break;
     const int col = c0 + nt * 16 + fr;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -134,7 +182,7 @@ __global__ __launch_bounds__(256, ((D <= 40 && !KV_SIDE) ? 3 : 1)) void attentio
     const int idx = tid + i * 256;
     s_row[i] = idx / (KS * 4);
     s_slot[i] = idx - s_row[i] * (KS * 4);
-    s_lds[i] = s_row[i] * STR + ((s_slot[i] ^ swz<STR>(s_row[i])) << 4);
+    s_lds[i] = s_row[i] * STR + ((s_slot[i] ^ sw_of(s_row[i])) << 4);
   }
   uint4 r1[KS], r2[KS];
   float rl = 0.f, rd = 0.f;
@@ -237,8 +285,47 @@ __global__ __launch_bounds__(256, ((D <= 40 && !KV_SIDE) ? 3 : 1)) void attentio
     const float* st = (const float*)(T2 + G::TILE);
 
     bf16x8_t pf[NT][2], dsf[NT][2];
+    if (X32) {
+      typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+      const int hi = lane >> 5;
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        const int row = ch * 32 + (lane & 31);
+        const int sw = (row >> 1) & 7;
+        f32x16_t tS, tU;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { tS[e] = 0.f; tU[e] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS32; ++ks) {
+          const bf16x8_t x1 = *(const bf16x8_t*)(T1 + row * STR + (((ks * 2 + hi) ^ sw) << 4));
+          const bf16x8_t x2 = *(const bf16x8_t*)(T2 + row * STR + (((ks * 2 + hi) ^ sw) << 4));
+          tS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, yx1[ks], tS, 0, 0, 0);
+          tU = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, yx2[ks], tU, 0, 0, 0);
+        }
+        // lane (column lane & 31, half hi) holds rows 8 i + 4 hi + j of the chunk in register 4 i + j
+        unsigned pp[8], dd[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float p0 = __builtin_amdgcn_exp2f(tS[2 * e]), p1 = __builtin_amdgcn_exp2f(tS[2 * e + 1]);
+          pp[e] = pack2bf(p0, p1);
+          dd[e] = pack2bf(p0 * tU[2 * e], p1 * tU[2 * e + 1]);
+        }
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+        u32x4_t p0v, p1v, d0v, d1v;                      // column half 0 / 1 after the swaps
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const u32x2_t sp = __builtin_amdgcn_permlane16_swap(pp[e], pp[4 + e], false, false);
+          const u32x2_t sd = __builtin_amdgcn_permlane16_swap(dd[e], dd[4 + e], false, false);
+          p0v[e] = sp[0]; p1v[e] = sp[1]; d0v[e] = sd[0]; d1v[e] = sd[1];
+        }
+        pf[0][ch] = __builtin_bit_cast(bf16x8_t, p0v); pf[1][ch] = __builtin_bit_cast(bf16x8_t, p1v);
+        dsf[0][ch] = __builtin_bit_cast(bf16x8_t, d0v); dsf[1][ch] = __builtin_bit_cast(bf16x8_t, d1v);
+      }
+    }
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
+      if (X32) break;
       // two 16-row MFMA tiles cover rows ch*32 + fg*8 + {0..3} and {4..7} for this lane
       f32x4_t tS[NT][2], tU[NT][2];
 #pragma unroll
@@ -292,11 +379,11 @@ __global__ __launch_bounds__(256, ((D <= 40 && !KV_SIDE) ? 3 : 1)) void attentio
     for (int f = 0; f < DF; ++f)
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch) {
-        const bf16x8_t a1 = tr_frag<STR>(T1, ch * 32 + fg * 8, f * 16, fr);
+        const bf16x8_t a1 = X32 ? tr_frag_x32<STR>(T1, ch * 32 + (((fg & 1) << 4) | ((fg >> 1) << 2)), f * 16, fr) : tr_frag<STR>(T1, ch * 32 + fg * 8, f * 16, fr);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc1[nt][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, dsf[nt][ch], acc1[nt][f], 0, 0, 0);
         if (KV_SIDE) {
-          const bf16x8_t a2 = tr_frag<STR>(T2, ch * 32 + fg * 8, f * 16, fr);
+          const bf16x8_t a2 = X32 ? tr_frag_x32<STR>(T2, ch * 32 + (((fg & 1) << 4) | ((fg >> 1) << 2)), f * 16, fr) : tr_frag<STR>(T2, ch * 32 + fg * 8, f * 16, fr);
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc2[nt][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, pf[nt][ch], acc2[nt][f], 0, 0, 0);
         }
@@ -366,23 +453,33 @@ __global__ __launch_bounds__(256) void attention_delta_kernel(const bf16_t* __re
   }
 }
 
-template <int D, bool KV, int NT>
+template <int D, bool KV, int NT, bool X32W = false>
 int launch_pass(const AttnBwdArgs& a, hipStream_t stream) {
   constexpr int lds = 2 * BwdGeom<D>::BUF;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attention_bwd_kernel<D, KV, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)attention_bwd_kernel<D, KV, NT, X32W>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
   const int ncols = KV ? a.Nk : a.Nq;
   dim3 grid((ncols + 4 * NT * 16 - 1) / (4 * NT * 16), a.H, a.B);
-  hipLaunchKernelGGL((attention_bwd_kernel<D, KV, NT>), grid, dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((attention_bwd_kernel<D, KV, NT, X32W>), grid, dim3(256), lds, stream, a);
   return dfh::check_launch("attention_bwd_kernel");
 }
 
 template <int D>
 int launch_bwd(const AttnBwdArgs& a, hipStream_t stream) {
   dfh::ProfScope ps(dfh::PC_ATTN_BWD, 14.0 * a.B * a.H * (double)a.Nq * a.Nk * D, 2.0 * a.B * a.H * D * (4.0 * a.Nq + 4.0 * a.Nk), stream);
+#ifdef DFH_PROBES
+  if constexpr (D == 40) {
+    // PROBE builds only -- DFH_ATTN_BWD_X32: 1 = both passes with S / dP on 32x32x16 (48-deep instead of 64-deep: a quarter of their
+    // matrix-pipe cycles, P / dS re-laid-out with v_permlane16_swap), 2 / 3 = only the dQ / the dK-dV pass.  Parity-green and SLOWER:
+    // 1616 against 1575 us on the 64x64-level launch pair (profiles/r05/attn_bwd_x32_ab.txt) -- the passes are not matrix-pipe bound.
+    static const int x32 = [] { const char* e = getenv("DFH_ATTN_BWD_X32"); return e ? atoi(e) : 0; }();
+    if (int rc = (x32 == 1 || x32 == 2) ? launch_pass<D, false, 2, true>(a, stream) : launch_pass<D, false, 2>(a, stream)) return rc;
+    return (x32 == 1 || x32 == 3) ? launch_pass<D, true, 2, true>(a, stream) : launch_pass<D, true, 2>(a, stream);
+  }
+#endif
   if (int rc = launch_pass<D, false, 2>(a, stream)) return rc;
   return launch_pass<D, true, (D > 80 ? 1 : 2)>(a, stream);
 }

@@ -135,3 +135,16 @@ def test_token_linear_matches_torch(M, resid, folded):
     if not folded:
         plain = gu.gemm(M=M, N=C, W=w, ldw=C, a0=x, a0_c=C, bias=bias, resid=res)
         assert gu.rel_err(out, plain) < 4e-3
+
+
+def test_attention_backward_x32_variant_is_parity_green():
+    """attention_bwd.hip X32 (probe builds, DFH_ATTN_BWD_X32=1): S / dP of the d = 40 backward on 32x32x16 with the P / dS re-layout through
+    v_permlane16_swap.  Slower than the product path (profiles/r05/attn_bwd_x32_ab.txt) but it must stay correct: the product's own
+    attention-backward test, run in a child process with the variant switched on (the switch is read once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    env = dict(os.environ, DFH_ATTN_BWD_X32="1")
+    assert "probes" in env.get("DFH_LIB", ""), "run with DFH_LIB=<probe library>"
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_backward.py", "-x", "-q", "-k", "attention_backward and 40-8"],
+                       capture_output=True, text=True, env=env, cwd=root, timeout=900)
+    assert r.returncode == 0 and "5 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

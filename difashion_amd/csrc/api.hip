@@ -144,9 +144,9 @@ int dfh_gemm_gstat(const dfh_gemm_desc* d, void* stream, int* written) {
   const size_t need = d->force_split > 1 ? (size_t)d->force_split * g.M * g.N : dfh::gemm_partial_floats(g);
   DFH_REQUIRE(need == 0 || (d->partial && d->partial_floats >= need), "partial buffer too small for split-K");
   g.gstat = d->gstat; g.gstat_cpg = d->gstat_cpg; g.gstat_hw = d->gstat_hw;
-  bool w = false;
-  const int rc = dfh::gemm_launch(g, (hipStream_t)stream, d->force_tile, d->force_split, d->force_order, &w);
-  *written = w ? 1 : 0;
+  int rows = 0;
+  const int rc = dfh::gemm_launch(g, (hipStream_t)stream, d->force_tile, d->force_split, d->force_order, &rows);
+  *written = rows;            // pixel rows per statistics chunk (256 or 128): d->gstat is [image][group][gstat_hw / rows][2]; 0 = not written
   return rc;
 }
 

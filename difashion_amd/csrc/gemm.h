@@ -142,7 +142,7 @@ int layernorm_fp8_launch(const bf16_t* x, const float* gamma, const float* beta,
 // Picks a tile shape + split-K factor, launches, and (if split) launches the reduce.  ``partial``
 // must hold gemm_partial_floats(...) floats when the heuristic splits.
 int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile = 0, int force_split = 0, int force_order = -1,
-                bool* gstat_written = nullptr,    // *gstat_written: whether a.gstat was filled (only the 256 x 160 epilogue can)
+                int* gstat_rows = nullptr,        // *gstat_rows: pixel rows per statistics chunk a.gstat was filled with (256 / 128), 0 = not filled
                 int* rowstat_bn = nullptr);       // *rowstat_bn: column tile of the a.rowstat records written (0 = none: kernel / shape cannot)
 // lnfold.hip: W' = bf16(W * gamma) [N][K], s[n] = sum_k W'[n][k], b[n] = bias[n] (or 0) + sum_k W[n][k] * beta[k]
 int ln_fold_launch(const bf16_t* W, int ldw, const float* gamma, const float* beta, const float* bias, bf16_t* WF, float* s, float* b,

@@ -567,6 +567,43 @@ void gemm_bf16_kernel(const GemmArgs a) {
       const int m = m0 + row;
       if (part == 0 && m < a.M) *(float2*)(a.rowstat + ((long)nt_ * a.M + m) * 2) = float2{mean, m2};
     }
+    if constexpr (BM == 128 && BN == 160 && !WEPI) {
+      if (a.gstat) {
+        // GroupNorm statistics of this tile's bf16-rounded outputs for the consumer (gemm.h GemmArgs::gstat; round 5: the 128-row tile too,
+        // so that the 32x32-level producers leave them and gn_stats_kernel disappears there).  As in the 256-row epilogue: per column the
+        // sum / sum of squares of two row halves, the halves in order, then the columns of a group in order -- fixed orders, reruns are
+        // bit-identical.  The launcher guarantees whole tiles inside one image and BN % cpg == 0.
+        constexpr int GST_OFF = LNROW + BM * 8;
+        static_assert(GST_OFF + 3 * BN * 8 <= NSTAGE * STAGE, "statistics scratch must fit behind the staged output tile");
+        float* qrt = (float*)(smem + GST_OFF);         // [2 row halves][BN][2]
+        float* cst = qrt + 2 * BN * 2;                 // [BN][2]
+        if (tid < 2 * BN) {
+          const int rq = tid / BN, col = tid - rq * BN;
+          const unsigned char* src = smem + (rq * (BM / 2)) * RS + col * 2;
+          float ss = 0.f, qq = 0.f;
+          for (int r = 0; r < BM / 2; ++r) {
+            const float v = bf2f(*(const bf16_t*)(src + r * RS));
+            ss += v; qq = fmaf(v, v, qq);
+          }
+          qrt[(rq * BN + col) * 2] = ss; qrt[(rq * BN + col) * 2 + 1] = qq;
+        }
+        __syncthreads();
+        if (tid < BN) {
+          cst[tid * 2] = qrt[tid * 2] + qrt[(BN + tid) * 2];
+          cst[tid * 2 + 1] = qrt[tid * 2 + 1] + qrt[(BN + tid) * 2 + 1];
+        }
+        __syncthreads();
+        const int cpg = a.gstat_cpg;
+        if (tid < BN / cpg) {
+          float ss = 0.f, qq = 0.f;
+          for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { ss += cst[c * 2]; qq += cst[c * 2 + 1]; }
+          const int b = m0 / a.gstat_hw, chunk = (m0 - b * a.gstat_hw) / BM, chunks = a.gstat_hw / BM;
+          const int g = (n0 + tid * cpg) / cpg, G = a.N / cpg;
+          float* dst = a.gstat + (((long)b * G + g) * chunks + chunk) * 2;
+          dst[0] = ss; dst[1] = qq;
+        }
+      }
+    }
     return;
   }
   if (staged_geglu) {
@@ -963,8 +1000,8 @@ bool gemm_ln_consumer_ok(GemmArgs a) {
   return a.ntaps == 0 && a.resid == nullptr && a.rowvec == nullptr;
 }
 
-int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split, int force_order, bool* gstat_written, int* rowstat_bn) {
-  if (gstat_written) *gstat_written = false;
+int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split, int force_order, int* gstat_rows, int* rowstat_bn) {
+  if (gstat_rows) *gstat_rows = 0;
   if (rowstat_bn) *rowstat_bn = 0;
   DFH_REQUIRE(a.M > 0 && a.N > 0, "empty GEMM");
   DFH_REQUIRE(a.N % 4 == 0, "N must be a multiple of 4");
@@ -1094,12 +1131,17 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     else gemm_pick_tile_order(a, split, kTiles[tile].bm, kTiles[tile].bn);
     if (force_wide == 6 || force_wide == 7) wide = 0;                      // not eligible (odd N, transposed / fp32 output): the default tile runs
     if (force_wide == 15) wide = halo ? 1 : 0;
-    // output statistics for the consuming GroupNorm: only the 256 x 160 epilogue writes them, on full tiles inside one image
+    // output statistics for the consuming GroupNorm: the 256-row epilogues (256 x 160 wide, 256 x 320) and, since round 5, the staged
+    // epilogue of the eight-wave 128 x 160 tile write them, on full tiles inside one image; *gstat_rows = pixel rows per statistics chunk
     const int gbn = big ? 320 : 160;
-    const bool gst_ok = a.gstat && (halo || big || (wide == 1 && !ws)) && a.gstat_cpg > 0 && gbn % a.gstat_cpg == 0 && a.N % gbn == 0 &&
-                        a.N % a.gstat_cpg == 0 && a.M % 256 == 0 && a.gstat_hw % 256 == 0 && a.act != ACT_GEGLU;
+    const bool gst256 = (halo || big || (wide == 1 && !ws)) && a.M % 256 == 0 && a.gstat_hw % 256 == 0;
+    static const bool gst128_off = [] { const char* e = getenv("DFH_GSTAT128"); return e && e[0] == '0'; }();      // A/B
+    const bool gst128 = !gst128_off && !halo && !big && !bigg && !wide && !ws && tile == kEightWave && split == 1 && a.out_mode == OUT_BF16 && (a.N & 7) == 0 &&
+                        (a.ld_out & 7) == 0 && a.M % 128 == 0 && a.gstat_hw % 128 == 0 && a.nbatch <= 1 && !a.phase2x;
+    const bool gst_ok = a.gstat && (gst256 || gst128) && a.gstat_cpg > 0 && gbn % a.gstat_cpg == 0 && a.N % gbn == 0 &&
+                        a.N % a.gstat_cpg == 0 && a.act != ACT_GEGLU;
     if (!gst_ok) a.gstat = nullptr;
-    else if (gstat_written) *gstat_written = true;
+    else if (gstat_rows) *gstat_rows = gst256 ? 256 : 128;
     // per-row output statistics for a LayerNorm folded into the consumer: the staged bf16 epilogue of gemm_bf16_kernel and the 256-row
     // epilogue write them, on whole column tiles
     {

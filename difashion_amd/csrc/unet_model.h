@@ -649,15 +649,15 @@ struct dfh_unet {
       static const bool pre_off = [] { const char* e = getenv("DFH_GN_PRE"); return e && e[0] == '0'; }();
       float* gst = nullptr;
       const int G = u->cfg.norm_num_groups;
-      if (o && bump && !pre_off && (o->H * o->W) % 256 == 0 && o->C % G == 0 && (o->H * o->W) / 256 <= (int)GN_MAX_CHUNKS) {
-        gst = (float*)bump->alloc((size_t)Ba * G * ((o->H * o->W) / 256) * 2 * sizeof(float));      // same in the dry run
+      if (o && bump && !pre_off && (o->H * o->W) % 128 == 0 && o->C % G == 0 && (o->H * o->W) / 128 <= (int)GN_MAX_CHUNKS) {
+        gst = (float*)bump->alloc((size_t)Ba * G * ((o->H * o->W) / 128) * 2 * sizeof(float));      // same in the dry run; chunks of 256 or 128 pixel rows
         g.gstat = gst; g.gstat_cpg = o->C / G; g.gstat_hw = o->H * o->W;
       }
       if (dry) { partial_need = std::max(partial_need, dfh::gemm_partial_floats(g) * sizeof(float)); return; }
       if (dfh::gemm_partial_floats(g) * sizeof(float) > partial_cap) { dfh::set_error("split-K partial buffer too small"); rc = -1; return; }
-      bool written = false;
-      rc = dfh::gemm_launch(g, s, 0, 0, -1, &written, rs_bn);
-      if (o && written) { o->gst = gst; o->gst_cpg = g.gstat_cpg; o->gst_chunks = g.gstat_hw / 256; }
+      int gst_rows = 0;
+      rc = dfh::gemm_launch(g, s, 0, 0, -1, &gst_rows, rs_bn);
+      if (o && gst_rows) { o->gst = gst; o->gst_cpg = g.gstat_cpg; o->gst_chunks = g.gstat_hw / gst_rows; }
     }
     static GemmArgs base(int M, int N) {
       GemmArgs g; std::memset(&g, 0, sizeof(g));

@@ -239,15 +239,16 @@ typedef struct dfh_gemm_desc {
   const void* zero_page;                        /* >= 256 zero bytes */
   int force_tile, force_split, force_order;     /* 0,0,-1 = heuristics; force_order 2 / 3 = tile ids n-major / m-major */
   float* gstat; int gstat_cpg, gstat_hw;        /* optional: GroupNorm statistics of the output for the consumer (channels per group,
-                                                 * pixels per image): [image][group][hw / 256][2] sums / sums of squares; written only
-                                                 * by the 256 x 160 tile, and only through dfh_gemm_gstat (dfh_gemm ignores the three fields) */
+                                                 * pixels per image): [image][group][hw / rows][2] sums / sums of squares, rows = 256
+                                                 * or 128 (dfh_gemm_gstat reports which); only through dfh_gemm_gstat (dfh_gemm ignores the three fields) */
   size_t w_img_stride;                          /* 0, or per-IMAGE weights: rows [i * rows_per_b, (i + 1) * rows_per_b) multiply W + i * w_img_stride
                                                  * (elements) -- dfh_groupnorm_fold; 128-row-tile launches without conv taps / split-K */
 } dfh_gemm_desc;
 size_t dfh_gemm_partial_floats(const dfh_gemm_desc* d);
 int dfh_gemm(const dfh_gemm_desc* d, void* stream);
-/* dfh_gemm + the output statistics for the consuming GroupNorm (d->gstat ...); *written = 1 when they were produced, 0 when the launch
- * ran on a kernel that cannot (the caller then runs plain dfh_groupnorm) */
+/* dfh_gemm + the output statistics for the consuming GroupNorm (d->gstat ..., sized for gstat_hw / 128 chunks); *written = the pixel rows
+ * per statistics chunk they were produced with (256 or 128: pass gstat_hw / *written as the chunk count to dfh_groupnorm_pre), 0 when the
+ * launch ran on a kernel that cannot (the caller then runs plain dfh_groupnorm) */
 int dfh_gemm_gstat(const dfh_gemm_desc* d, void* stream, int* written);
 /* GroupNorm folded into the 1x1 projection that consumes it (transformer entry, difashion.py:249-253): from x [B][HW][C] (statistics: the
  * producer's partials `pre` [B][G][pre_chunks][2], or NULL -> summed here into `partial`, >= B * 64 * G * 2 floats), gamma / beta and the

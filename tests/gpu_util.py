@@ -67,7 +67,8 @@ def gemm_desc(*, M, N, W, ldw, a0=None, a0_c=0, a1=None, a1_c=0, conv_src=None, 
 
 
 def gemm(*, gstat=None, gstat_cpg=0, gstat_hw=0, **kw):
-    """gstat: a float32 device tensor for the output's GroupNorm statistics (dfh_gemm_gstat); the call then returns (out, written)."""
+    """gstat: a float32 device tensor for the output's GroupNorm statistics (dfh_gemm_gstat); the call then returns (out, rows) with rows = the
+    pixel rows per statistics chunk (256 / 128) or 0 when the launch could not write them."""
     d = gemm_desc(**kw)
     out = d.keep_out
     if gstat is not None:
@@ -75,7 +76,7 @@ def gemm(*, gstat=None, gstat_cpg=0, gstat_hw=0, **kw):
         written = C.c_int(0)
         _lib.call("dfh_gemm_gstat", C.byref(d), stream(), C.byref(written))
         torch.cuda.synchronize()
-        return out, bool(written.value)
+        return out, int(written.value)
     _lib.call("dfh_gemm", C.byref(d), stream())
     torch.cuda.synchronize()
     return out

@@ -412,17 +412,20 @@ def test_conv3x3_lean_tap_staging_on_non_square_inputs(cin, H, W, tile):
     ("conv", 64, 320, 32, 2, 21),     # the 256 x 320 tile: all 32 groups of a row tile in one workgroup
     ("conv", 32, 640, 16, 3, 21),
     ("linear", 320, 320, 32, 2, 6),   # proj_out shape class: linear + residual
+    ("conv", 64, 640, 32, 2, 10),     # round 5: the eight-wave 128 x 160 tile (the 32x32-level producers): 128-row chunks, cpg 20
+    ("conv", 32, 320, 16, 3, 10),     # ... two chunks per image, cpg 10
+    ("linear", 640, 640, 32, 2, 10),  # ... the LEAN instantiation (plain segment) + residual
 ])
 def test_gemm_writes_groupnorm_statistics_for_its_consumer(kind, cin, cout, H, B, tile):
-    """The 256-row epilogue writes, per (image, group, row tile), the sum and the sum of squares of the bf16 outputs (dfh_gemm_gstat);
+    """The 256-row epilogues and (round 5) the staged epilogue of the eight-wave 128 x 160 tile write, per (image, group, row tile), the sum and the sum of squares of the bf16 outputs (dfh_gemm_gstat);
     dfh_groupnorm_pre normalises from them in ONE launch.  Checked: the partials against torch sums of the GEMM's own output, and
     the normalised tensor against plain dfh_groupnorm of that output (same statistics up to summation order) and against
     F.group_norm; a launch on a kernel that cannot produce them reports written = 0."""
     G, HW = 32, H * H
-    M, cpg, chunks = B * HW, cout // 32, HW // 256
+    M, cpg = B * HW, cout // 32
     bias = rnd(cout, seed=41)
     res = bf(rnd(M, cout, seed=42))
-    gst = torch.full((B * G * chunks * 2,), float("nan"), dtype=torch.float32, device=DEV)
+    gst = torch.full((B * G * (HW // 128) * 2,), float("nan"), dtype=torch.float32, device=DEV)      # room for 128-row chunks
     if kind == "conv":
         x = bf(rnd(B, cin, H, H, seed=43))
         w = rnd(cout, cin, 3, 3, seed=44, scale=0.05)
@@ -433,11 +436,12 @@ def test_gemm_writes_groupnorm_statistics_for_its_consumer(kind, cin, cout, H, B
         a = bf(rnd(M, cin, seed=43))
         w = bf(rnd(cout, cin, seed=44, scale=0.05))
         kw = dict(M=M, N=cout, W=w, ldw=cin, a0=a, a0_c=cin, bias=bias, resid=res)
-    out, written = gu.gemm(force_tile=tile, gstat=gst, gstat_cpg=cpg, gstat_hw=HW, **kw)
-    assert written
-    y = out.float().view(B, chunks, 256, G, cpg)
+    out, rows = gu.gemm(force_tile=tile, gstat=gst, gstat_cpg=cpg, gstat_hw=HW, **kw)
+    assert rows == (128 if tile == 10 else 256), rows
+    chunks = HW // rows
+    y = out.float().view(B, chunks, rows, G, cpg)
     ref = torch.stack([y.sum(dim=(2, 4)), (y * y).sum(dim=(2, 4))], dim=-1).permute(0, 2, 1, 3)     # [B][G][chunks][2]
-    got = gst.view(B, G, chunks, 2)
+    got = gst[:B * G * chunks * 2].view(B, G, chunks, 2)
     assert torch.allclose(got, ref, rtol=2e-5, atol=1e-2), float((got - ref).abs().max())
     gamma, beta = rnd(cout, seed=46) + 1.0, rnd(cout, seed=47)
     o_pre = torch.empty(M, cout, dtype=torch.bfloat16, device=DEV)
@@ -455,8 +459,11 @@ def test_gemm_writes_groupnorm_statistics_for_its_consumer(kind, cin, cout, H, B
     gu.assert_close_bf16(gu.nchw(o_pre.view(B, H, H, cout)), gref, "groupnorm from producer statistics")
     mean = xr.view(B, G, -1).mean(-1)
     assert torch.allclose(stats.view(B, G, 2)[..., 0], mean, atol=1e-3)
-    # a launch that runs on another kernel (eight-wave 128 x 160) must say so
-    _, w2 = gu.gemm(force_tile=10, gstat=gst, gstat_cpg=cpg, gstat_hw=HW, **kw)
+    # bit-identical reruns (fixed summation orders), and a launch that runs on a kernel without the statistics epilogue must say so
+    g1 = gst.clone()
+    gu.gemm(force_tile=tile, gstat=gst, gstat_cpg=cpg, gstat_hw=HW, **kw)
+    assert torch.equal(gst[:B * G * chunks * 2], g1[:B * G * chunks * 2])
+    _, w2 = gu.gemm(force_tile=5, gstat=gst, gstat_cpg=cpg, gstat_hw=HW, **kw)      # the four-wave 128 x 128 tile
     assert not w2
 
 

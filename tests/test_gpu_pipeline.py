@@ -99,7 +99,8 @@ def test_sampler_vs_reference_golden(case, unet):
 def test_fp8_sampler_vs_reference_golden(case):
     """BASELINE configs[4] end to end ("fp8 ... path, CFG batch, 4-item GOR sampling"): the product sampler with the U-Net in fp8 mode (every
     transformer linear in e4m3) against the golden run of the REAL reference glue.  Stated tolerances of the fp8 walk: raw U-Net output
-    of the first step <= 6e-2, final latents after the 10 guided steps <= 0.15 (bf16 walk: 3e-2 / 8e-2)."""
+    of the first step <= 6e-2, final latents after the 10 guided steps <= 0.12 (measured, round 5: 2.9e-2 / 8.9e-2 GOR, 3.1e-2 / 8.1e-2 FITB;
+    the bound was 0.15; bf16 walk: 3e-2 / 8e-2)."""
     from difashion_amd import _lib
     rec = load(f"sample_{case}.npz")
     m = hip_unet(GLUE_CFG, glue_unet_params(), max_batch=32)
@@ -117,7 +118,7 @@ def test_fp8_sampler_vs_reference_golden(case):
     assert _lib.census()["gemm_fp8"] > 0
     e0, ef = rel_err(taps["unet_out_0"].cpu(), rec["unet_out_0"]), rel_err(final.cpu(), rec["final"])
     print(case, f"fp8: unet_out_0 {e0:.2e} final {ef:.2e}")
-    assert e0 <= 6e-2 and ef <= 0.15
+    assert e0 <= 6e-2 and ef <= 0.12
 
 
 @pytest.mark.parametrize("case", ["gor_full_ddim10", "mix_full_pndm10", "gor_full_ddim50"])

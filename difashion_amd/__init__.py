@@ -13,10 +13,11 @@ from .schedulers import DDIMScheduler, PNDMScheduler
 from .training import EMAModel, FusedAdamW, clip_grad_norm_, train_step
 from .unet import UNet2DConditionModel, UNet2DConditionOutput
 from .vae import AutoencoderKL
+from .clip import CLIPTextModel
 from .difashion import DiFashion
 
 __all__ = [
     "DfhError", "UNet2DConditionModel", "UNet2DConditionOutput", "DDIMScheduler", "PNDMScheduler",
     "MutualEncoder", "OutfitSampler", "sample_outfits", "train_forward", "guidance_plan", "sampling_tables", "training_tables",
-    "FusedAdamW", "EMAModel", "clip_grad_norm_", "train_step", "AutoencoderKL", "DiFashion",
+    "FusedAdamW", "EMAModel", "clip_grad_norm_", "train_step", "AutoencoderKL", "CLIPTextModel", "DiFashion",
 ]

@@ -17,14 +17,18 @@ import torch
 WEIGHTS_STEM = "diffusion_pytorch_model"
 
 
-def weight_candidates(variant: Optional[str] = None):
-    stem = f"{WEIGHTS_STEM}.{variant}" if variant else WEIGHTS_STEM
-    return [stem + ext for ext in (".safetensors", ".bin")]
+def weight_candidates(variant: Optional[str] = None, stems=(WEIGHTS_STEM,)):
+    return [(f"{stem}.{variant}" if variant else stem) + ext for stem in stems for ext in (".safetensors", ".bin")]
 
 
-def load_weights(directory: str, variant: Optional[str] = None) -> Dict[str, torch.Tensor]:
+# transformers writes ``model.safetensors`` (>= 4.3x with safe serialization) or ``pytorch_model.bin`` (4.32.1 default; what the
+# text_encoder/ directory of the published SD-1.5 / SD-2 snapshots holds next to it)
+TRANSFORMERS_STEMS = ("model", "pytorch_model")
+
+
+def load_weights(directory: str, variant: Optional[str] = None, stems=(WEIGHTS_STEM,)) -> Dict[str, torch.Tensor]:
     tried = []
-    for name in weight_candidates(variant):
+    for name in weight_candidates(variant, stems):
         f = os.path.join(directory, name)
         tried.append(name)
         if not os.path.isfile(f):

@@ -37,6 +37,12 @@ class VAEConfigC(C.Structure):
                 ("block_out_channels", C.c_int * DFH_MAX_BLOCKS), ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int)]
 
 
+class CLIPConfigC(C.Structure):
+    _fields_ = [("vocab_size", C.c_int), ("hidden_size", C.c_int), ("intermediate_size", C.c_int), ("num_hidden_layers", C.c_int),
+                ("num_attention_heads", C.c_int), ("max_position_embeddings", C.c_int), ("hidden_act", C.c_int),
+                ("layer_norm_eps", C.c_float)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("conv_src", C.c_void_p), ("conv_c", C.c_int), ("conv", C.c_int),
@@ -110,6 +116,14 @@ SIGNATURES = {
     "dfh_unet_set_dup_tail": (_i, [_vp, _i]),
     "dfh_unet_forward_cached": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "dfh_unet_debug_tap": (_i, [_vp, C.c_char_p, _vp, _sz, _vp]),
+    "dfh_clip_create": (_i, [C.POINTER(CLIPConfigC), C.POINTER(_vp)]),
+    "dfh_clip_destroy": (None, [_vp]),
+    "dfh_clip_num_params": (_i, [_vp]),
+    "dfh_clip_param_name": (C.c_char_p, [_vp, _i]),
+    "dfh_clip_param_ndim": (_i, [_vp, _i]),
+    "dfh_clip_param_dim": (_i, [_vp, _i, _i]),
+    "dfh_clip_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "dfh_clip_encode": (_i, [_vp, C.POINTER(_vp), _i, _vp, _vp, _vp, _i, _vp, _vp, _sz, _i, _i, _vp]),
     "dfh_vae_create": (_i, [C.POINTER(VAEConfigC), C.POINTER(_vp)]),
     "dfh_vae_destroy": (None, [_vp]),
     "dfh_vae_num_params": (_i, [_vp]),
@@ -219,10 +233,10 @@ SIGNATURES = {
     "dfh_mse_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
 }
 _NO_STATUS = {"dfh_abi_version", "dfh_census_count", "dfh_unet_num_params", "dfh_unet_param_ndim", "dfh_unet_param_dim", "dfh_vae_num_params",
-              "dfh_vae_param_ndim", "dfh_vae_param_dim"}
+              "dfh_vae_param_ndim", "dfh_vae_param_dim", "dfh_clip_num_params", "dfh_clip_param_ndim", "dfh_clip_param_dim"}
 
 _lib = None
-ABI_VERSION = 6          # == DFH_ABI_VERSION of include/difashion_hip.h (checked when the library is loaded)
+ABI_VERSION = 7          # == DFH_ABI_VERSION of include/difashion_hip.h (checked when the library is loaded)
 
 
 def build(force: bool = False) -> str:

@@ -29,7 +29,7 @@ extern "C" {
 /* Bumped whenever an entry point, a struct layout or the meaning of an argument changes (round 4: 4).  The Python host side
  * (difashion_amd/_lib.py ABI_VERSION) refuses a library that reports another number: a stale .so next to new Python, or the reverse,
  * fails at load time instead of at a symbol lookup or silently. */
-#define DFH_ABI_VERSION 6
+#define DFH_ABI_VERSION 7
 #define DFH_MAX_BLOCKS 4
 
 /* ------------------------------------------------------------------ library */
@@ -220,6 +220,44 @@ int dfh_vae_pack(dfh_vae* u, const float* const* master_params, int count, void*
 int dfh_vae_encode(dfh_vae* u, const float* images, float* moments, int batch, int image_size, void* stream);
 /* latents [B][latent_channels][s][s] fp32 -> images [B][4][8s][8s] fp32 (out_channels = 3 used, the 4th plane is padding) */
 int dfh_vae_decode(dfh_vae* u, const float* latents, float* images, int batch, int latent_size, void* stream);
+
+/* ------------------------------------------------------------------ CLIP text encoder
+ * Replaces transformers' CLIPTextModel as the reference builds and calls it: CLIPTextModel.from_pretrained(..., subfolder="text_encoder")
+ * at df.py:70-72, text_encoder(input_ids)[0] at df.py:224,234 (every training batch) and df.py:340-342,352 (every sampling call).
+ * fp32 end to end (csrc/clip.hip: linears on v_mfma_f32_16x16x4_f32): the prompts are a closed set encoded once per run, so the
+ * encoder is built for agreement with the fp32 class (1e-6), not for speed.  The fp32 master parameters are read in place
+ * (nn.Linear layout): no arenas, no pack step; parameter table in transformers 4.32.1 state-dict order / names ("text_model.*"). */
+typedef struct dfh_clip_config {
+  int vocab_size;                  /* 49408 */
+  int hidden_size;                 /* 768 (SD-1.5, CLIP ViT-L/14) / 1024 (SD-2, OpenCLIP ViT-H/14) */
+  int intermediate_size;           /* 3072 / 4096 */
+  int num_hidden_layers;           /* 12 / 23 */
+  int num_attention_heads;         /* 12 / 16 */
+  int max_position_embeddings;     /* 77 (<= 128) */
+  int hidden_act;                  /* 1 quick_gelu (SD-1.5) / 2 gelu, erf form (SD-2) */
+  float layer_norm_eps;            /* 1e-5 */
+} dfh_clip_config;
+typedef struct dfh_clip dfh_clip;
+int dfh_clip_create(const dfh_clip_config* cfg, dfh_clip** out);   /* host-only work */
+void dfh_clip_destroy(dfh_clip* c);
+int dfh_clip_num_params(const dfh_clip* c);
+const char* dfh_clip_param_name(const dfh_clip* c, int i);
+int dfh_clip_param_ndim(const dfh_clip* c, int i);
+int dfh_clip_param_dim(const dfh_clip* c, int i, int d);
+size_t dfh_clip_workspace_bytes(const dfh_clip* c, int batch, int seq_len);
+/* outputs = text_encoder(input_ids):
+ *   master_params     : HOST array of `count` device pointers to the fp32 parameters, table order
+ *   input_ids         : [batch][seq_len] int64 (tokenizer output, data_utils.py:107-110); causal mask only, no padding mask (the
+ *                       reference passes input_ids alone)
+ *   last_hidden_state : [batch][seq_len][hidden_size] fp32 = outputs[0], after final_layer_norm
+ *   pooler_output     : [batch][hidden_size] fp32 or NULL; the row at argmax(input_ids) when eos_token_id == 2 (transformers 4.32.1),
+ *                       else at the first eos_token_id
+ *   hidden_states     : NULL, or [num_hidden_layers + 1][batch][seq_len][hidden_size] fp32 = output_hidden_states=True (embeddings
+ *                       output, then every layer's output; layer-level parity tests)
+ *   workspace         : >= dfh_clip_workspace_bytes(batch, seq_len), 256-byte aligned */
+int dfh_clip_encode(dfh_clip* c, const float* const* master_params, int count, const int64_t* input_ids, float* last_hidden_state,
+                    float* pooler_output, int eos_token_id, float* hidden_states, void* workspace, size_t workspace_bytes, int batch,
+                    int seq_len, void* stream);
 
 /* ------------------------------------------------------------------ op-level entry points (tests, profiling)
  * ResnetBlock2D conv3x3 / Downsample2D / Upsample2D / 1x1 conv / Linear, as one implicit GEMM:

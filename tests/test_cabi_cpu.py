@@ -30,7 +30,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/difashion_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype in difashion_amd/_lib.py"
     assert set(_lib.SIGNATURES) <= set(names)
-    assert lib.dfh_abi_version() == _lib.ABI_VERSION == 6 and b"abi=6" in lib.dfh_build_info() and b"gfx950" in lib.dfh_build_info()
+    assert lib.dfh_abi_version() == _lib.ABI_VERSION == 7 and b"abi=7" in lib.dfh_build_info() and b"gfx950" in lib.dfh_build_info()
 
 
 def test_struct_layouts_match_header_field_order():

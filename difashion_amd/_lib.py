@@ -236,6 +236,7 @@ _NO_STATUS = {"dfh_abi_version", "dfh_census_count", "dfh_unet_num_params", "dfh
               "dfh_vae_param_ndim", "dfh_vae_param_dim", "dfh_clip_num_params", "dfh_clip_param_ndim", "dfh_clip_param_dim"}
 
 _lib = None
+_UNBOUND = set()
 ABI_VERSION = 7          # == DFH_ABI_VERSION of include/difashion_hip.h (checked when the library is loaded)
 
 
@@ -258,11 +259,15 @@ def raw():
             raise DfhError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU / PyTorch fallback for the compute path)")
         lib = C.CDLL(LIB_PATH)
-        # DFH_LIB (a same-box A/B probe against ANOTHER build, e.g. last round's): entry points that build does not have are left
-        # unbound and its ABI number is not checked -- the probe only drives calls both builds share.  Never on the product path.
-        probe = bool(os.environ.get("DFH_LIB"))
+        # DFH_LIB=<path> loads another build; it is held to the same ABI check as the default path.  Only with the explicit
+        # DFH_LIB_ALLOW_ABI_MISMATCH=1 (same-box A/B probes against LAST ROUND's library) are missing entry points left unbound and
+        # the ABI number ignored -- and then call() refuses an unbound entry point instead of calling it through ctypes' default
+        # int prototype (which truncates pointers and size_t).  Never on the product path.
+        probe = bool(os.environ.get("DFH_LIB")) and os.environ.get("DFH_LIB_ALLOW_ABI_MISMATCH") == "1"
+        unbound = set()
         for name, (res, args) in SIGNATURES.items():
             if probe and not hasattr(lib, name):
+                unbound.add(name)
                 continue
             fn = getattr(lib, name)       # AttributeError here = header/library drift
             fn.restype = res
@@ -270,7 +275,10 @@ def raw():
         got = lib.dfh_abi_version()
         if got != ABI_VERSION and not probe:
             raise DfhError(f"{LIB_PATH} reports ABI {got}, this Python side binds ABI {ABI_VERSION} (include/difashion_hip.h "
-                           "DFH_ABI_VERSION): rebuild the library (`python -c 'import __graft_entry__ as g; g.build()'`)")
+                           "DFH_ABI_VERSION): rebuild the library (`python -c 'import __graft_entry__ as g; g.build()'`)"
+                           + ("; DFH_LIB_ALLOW_ABI_MISMATCH=1 loads it anyway for an A/B probe" if os.environ.get("DFH_LIB") else ""))
+        global _UNBOUND
+        _UNBOUND = unbound
         _lib = lib
     return _lib
 
@@ -281,7 +289,10 @@ def last_error() -> str:
 
 def call(name: str, *args):
     """Call a status-returning entry point; raise DfhError with the library's message on failure."""
-    rc = getattr(raw(), name)(*args)
+    lib = raw()
+    if name in _UNBOUND:
+        raise DfhError(f"{name} is not exported by {LIB_PATH} (an older build loaded under DFH_LIB_ALLOW_ABI_MISMATCH=1)")
+    rc = getattr(lib, name)(*args)
     if name not in _NO_STATUS and SIGNATURES[name][0] is _i and rc != 0:
         raise DfhError(f"{name} failed ({rc}): {last_error()}")
     return rc
@@ -289,7 +300,10 @@ def call(name: str, *args):
 
 def call_count(name: str, *args):
     """Call an entry point that returns a count (>= 0) or a negative status."""
-    rc = getattr(raw(), name)(*args)
+    lib = raw()
+    if name in _UNBOUND:
+        raise DfhError(f"{name} is not exported by {LIB_PATH} (an older build loaded under DFH_LIB_ALLOW_ABI_MISMATCH=1)")
+    rc = getattr(lib, name)(*args)
     if rc < 0:
         raise DfhError(f"{name} failed ({rc}): {last_error()}")
     return rc

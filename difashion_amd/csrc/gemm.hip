@@ -23,6 +23,7 @@
 #include "gemm.h"
 #include "gemm_kiter.h"
 #include "gemm_wide_epilogue.h"
+#include "norm.h"   // GN_MAX_CHUNKS: what the consuming GroupNorm kernels accept per (image, group)
 #ifdef DFH_PROBES
 #include "token_linear.h"
 #endif
@@ -567,7 +568,8 @@ void gemm_bf16_kernel(const GemmArgs a) {
       const int m = m0 + row;
       if (part == 0 && m < a.M) *(float2*)(a.rowstat + ((long)nt_ * a.M + m) * 2) = float2{mean, m2};
     }
-    if constexpr (BM == 128 && BN == 160 && !WEPI) {
+    if constexpr (BM == 128 && BN == 160 && !WEPI && WM * WN == 8) {      // tid < 2 * BN needs the eight-wave block (320 <= 512 threads)
+      static_assert(WM * WN * 64 >= 2 * BN, "the statistics epilogue indexes 2 * BN threads");
       if (a.gstat) {
         // GroupNorm statistics of this tile's bf16-rounded outputs for the consumer (gemm.h GemmArgs::gstat; round 5: the 128-row tile too,
         // so that the 32x32-level producers leave them and gn_stats_kernel disappears there).  As in the 256-row epilogue: per column the
@@ -1134,10 +1136,12 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     // output statistics for the consuming GroupNorm: the 256-row epilogues (256 x 160 wide, 256 x 320) and, since round 5, the staged
     // epilogue of the eight-wave 128 x 160 tile write them, on full tiles inside one image; *gstat_rows = pixel rows per statistics chunk
     const int gbn = big ? 320 : 160;
-    const bool gst256 = (halo || big || (wide == 1 && !ws)) && a.M % 256 == 0 && a.gstat_hw % 256 == 0;
+    const bool gst256 = (halo || big || (wide == 1 && !ws)) && a.M % 256 == 0 && a.gstat_hw % 256 == 0 && a.gstat_hw / 256 <= (int)GN_MAX_CHUNKS;
     static const bool gst128_off = [] { const char* e = getenv("DFH_GSTAT128"); return e && e[0] == '0'; }();      // A/B
     const bool gst128 = !gst128_off && !halo && !big && !bigg && !wide && !ws && tile == kEightWave && split == 1 && a.out_mode == OUT_BF16 && (a.N & 7) == 0 &&
-                        (a.ld_out & 7) == 0 && a.M % 128 == 0 && a.gstat_hw % 128 == 0 && a.nbatch <= 1 && !a.phase2x;
+                        (a.ld_out & 7) == 0 && a.M % 128 == 0 && a.gstat_hw % 128 == 0 && a.nbatch <= 1 && !a.phase2x &&
+                        a.gstat_hw / 128 <= (int)GN_MAX_CHUNKS &&
+                        a.out2 == nullptr;           // the transposed / out2 column tiles return before the statistics block
     const bool gst_ok = a.gstat && (gst256 || gst128) && a.gstat_cpg > 0 && gbn % a.gstat_cpg == 0 && a.N % gbn == 0 &&
                         a.N % a.gstat_cpg == 0 && a.act != ACT_GEGLU;
     if (!gst_ok) a.gstat = nullptr;

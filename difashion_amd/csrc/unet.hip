@@ -90,8 +90,16 @@ int dfh_unet_pack(dfh_unet* u, const float* const* master_params, int count, voi
   return u->pack(master_params, count, (hipStream_t)stream);
 }
 
+// The dup-tail hint is ONE-SHOT: whatever happens inside the forward entry points -- including every early DFH_REQUIRE return -- the hint is
+// gone when they return, so a refused call can never leak it into a later forward on other inputs (round-5 advisor).
+struct DupTailGuard {
+  dfh_unet* u;
+  ~DupTailGuard() { if (u) u->dup_tail = 0; }
+};
+
 int dfh_unet_forward(dfh_unet* u, const void* sample, int sample_bf16, const float* timestep, const void* ehs, int ehs_bf16,
                      float* out, int batch, void* stream) {
+  DupTailGuard guard{u};
   DFH_REQUIRE(u && sample && timestep && ehs && out, "null argument");
   DFH_REQUIRE(u->ws != nullptr, "dfh_unet_bind not called");
   DFH_REQUIRE(batch > 0 && batch <= u->max_batch, "batch exceeds the bound max_batch");
@@ -122,6 +130,7 @@ int dfh_unet_set_dup_tail(dfh_unet* u, int images) {
 
 int dfh_unet_forward_cached(dfh_unet* u, const void* sample, int sample_bf16, const void* cache, int batch, int n_timesteps, int t_index,
                             float* out, void* stream) {
+  DupTailGuard guard{u};
   DFH_REQUIRE(u && sample && cache && out, "null argument");
   DFH_REQUIRE(u->ws != nullptr, "dfh_unet_bind not called");
   DFH_REQUIRE(batch > 0 && batch <= u->max_batch, "batch exceeds the bound max_batch");

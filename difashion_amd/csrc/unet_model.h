@@ -649,7 +649,10 @@ struct dfh_unet {
       static const bool pre_off = [] { const char* e = getenv("DFH_GN_PRE"); return e && e[0] == '0'; }();
       float* gst = nullptr;
       const int G = u->cfg.norm_num_groups;
-      if (o && bump && !pre_off && (o->H * o->W) % 128 == 0 && o->C % G == 0 && (o->H * o->W) / 128 <= (int)GN_MAX_CHUNKS) {
+      // the consumers take at most GN_MAX_CHUNKS chunks per (image, group): a level fits when its 256-row chunk count does; gemm_launch
+      // refuses the 128-row writer by itself when HW / 128 would exceed it (96x96 latents: 36 chunks of 256 rows, 72 of 128)
+      if (o && bump && !pre_off && (o->H * o->W) % 128 == 0 && o->C % G == 0 &&
+          (o->H * o->W) / ((o->H * o->W) % 256 == 0 ? 256 : 128) <= (int)GN_MAX_CHUNKS) {
         gst = (float*)bump->alloc((size_t)Ba * G * ((o->H * o->W) / 128) * 2 * sizeof(float));      // same in the dry run; chunks of 256 or 128 pixel rows
         g.gstat = gst; g.gstat_cpg = o->C / G; g.gstat_hw = o->H * o->W;
       }

@@ -895,6 +895,7 @@ int dfh_unet_pack_all(dfh_unet* u, const float* const* master_params, int count,
 
 int dfh_unet_forward_train(dfh_unet* u, const void* sample, int sample_bf16, const float* timestep, const void* ehs, int ehs_bf16,
                            float* out, int batch, void* stream) {
+  if (u) u->dup_tail = 0;          // the guidance-batch hint is an inference-walk hint: a training forward never consumes it and never leaves it behind
   DFH_REQUIRE(u && sample && timestep && ehs && out, "null argument");
   DFH_REQUIRE(u->tws != nullptr, "dfh_unet_bind_train not called");
   DFH_REQUIRE(batch > 0 && batch <= u->train_max_batch, "batch exceeds the bound max_batch");

@@ -169,6 +169,8 @@ class OutfitSampler:
                 self.unet._dup_tail_once = self.dup_tail
             self.eps_all = self.unet(self.x_in, t, self.ehs, return_dict=False)[0]
         finally:
+            if hasattr(self.unet, "_dup_tail_once"):
+                self.unet._dup_tail_once = 0            # one-shot: a forward that raised before consuming the hint must not leave it behind
             if static is not None:
                 self.unet.assume_static_weights = static
         sc, sh, sm = self.scales

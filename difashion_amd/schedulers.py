@@ -232,14 +232,21 @@ class PNDMScheduler(_SchedulerBase):
         a_t = self.alphas_cumprod[t]
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         b_t, b_prev = 1 - a_t, 1 - a_prev
-        if self.config.prediction_type == "v_prediction":
-            raise NotImplementedError("v_prediction with PNDM is not on the DiFashion path")
-        coeff = (a_prev / a_t) ** 0.5
+        coeff = float((a_prev / a_t) ** 0.5)
         denom = a_t * b_prev ** 0.5 + (a_t * b_t * a_prev) ** 0.5
+        c_e = float((a_prev - a_t) / denom)
         k = _lib.StepCoef()
         k.kind = STEP_LINEAR
-        k.sqrt_a_t = float(coeff)
-        k.sqrt_b_t = float((a_prev - a_t) / denom)
+        if self.config.prediction_type == "v_prediction":
+            # diffusers _get_prev_sample: eps = sqrt(a_t) v + sqrt(b_t) x first, then the same transfer -- still linear in (x, v):
+            # x' = (coeff - c_e sqrt(b_t)) x - c_e sqrt(a_t) v   (difashion.py:241-247 trains the v target under this setting)
+            k.sqrt_a_t = coeff - c_e * float(b_t ** 0.5)
+            k.sqrt_b_t = c_e * float(a_t ** 0.5)
+        elif self.config.prediction_type == "epsilon":
+            k.sqrt_a_t = coeff
+            k.sqrt_b_t = c_e
+        else:
+            raise ValueError(f"prediction_type given as {self.config.prediction_type} must be one of `epsilon` or `v_prediction`")
         prev = self._apply(k, model_output, sample)
         self.counter += 1
         return SchedulerOutput(prev_sample=prev) if return_dict else (prev,)

@@ -59,14 +59,15 @@ def object_kernels(obj):
 
 
 def kernel_table(csrc=None):
-    """{demangled kernel name: fields} over every object of the product library."""
+    """{demangled kernel name: fields} over every object of the product library; ``fields["mangled"]`` is the Itanium symbol (what the
+    tests match on: it does not depend on llvm-cxxfilt being installed)."""
     csrc = csrc or os.path.join(ROOT, "difashion_amd", "csrc")
     rows = []
     for f in sorted(os.listdir(csrc)):
         if f.endswith(".o"):
             rows += [(f, n, c) for n, c in object_kernels(os.path.join(csrc, f))]
     names = demangle([n for _, n, _ in rows])
-    return {names[n]: dict(c, object=f) for f, n, c in rows}
+    return {names[n]: dict(c, object=f, mangled=n) for f, n, c in rows}
 
 
 if __name__ == "__main__":

@@ -744,14 +744,17 @@ def test_ddim_eta_noise_and_scheduler_api():
     torch.testing.assert_close(got.cpu(), ref, rtol=3e-6, atol=3e-6)
 
 
-def test_add_noise_velocity_and_pndm_match_oracle():
+@pytest.mark.parametrize("pred", ["epsilon", "v_prediction"])
+def test_add_noise_velocity_and_pndm_match_oracle(pred):
+    """PNDM / PLMS is the scheduler the reference instantiates (difashion.py:64) and ``prediction_type`` the switch it branches on
+    (:241-247): both settings through the whole 11-entry PLMS list (warm-up step, 2-, 3- and 4-term blends)."""
     from difashion_amd.schedulers import DDIMScheduler, PNDMScheduler
     s, r = DDIMScheduler(), sched_ref.DDIMRef()
     x0, n = rnd(6, 4, 8, 8, seed=64), rnd(6, 4, 8, 8, seed=65)
     t = torch.tensor([0, 1, 500, 999, 37, 640], device=DEV)
     assert torch.equal(s.add_noise(x0, n, t).cpu(), r.add_noise(x0.cpu(), n.cpu(), t.cpu()))
     assert torch.equal(s.get_velocity(x0, n, t).cpu(), r.get_velocity(x0.cpu(), n.cpu(), t.cpu()))
-    p, pr = PNDMScheduler(), sched_ref.PNDMRef()
+    p, pr = PNDMScheduler(prediction_type=pred), sched_ref.PNDMRef(prediction_type=pred)
     p.set_timesteps(10, device=DEV)
     pr.set_timesteps(10)
     assert p.timesteps.tolist() == pr.timesteps.tolist()

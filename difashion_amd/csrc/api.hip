@@ -32,7 +32,7 @@ static long g_census[CK_COUNT] = {0};
 void census(int id) { if (id >= 0 && id < CK_COUNT) ++g_census[id]; }
 static const char* const kCensusNames[CK_COUNT] = {"gemm_wide", "gemm_8wave", "gemm_lean", "gemm_other", "gemm_row", "splitk_reduce",
     "splitk_fused", "gstat_written", "gn_pre", "gn_stats", "gn_small", "gn_mid", "layernorm", "ln_folded", "attention_x32", "attention_16",
-    "gemm_fp8", "text_cached", "conv_phase", "conv_wino", "gemm_rows_geglu", "attention_fp8", "mlp_fused", "gn_folded", "token_linear", "dup_prefix"};
+    "gemm_fp8", "text_cached", "conv_phase", "conv_wino", "gemm_rows_geglu", "attention_fp8", "mlp_fused", "gn_folded", "token_linear", "dup_prefix", "gemm_persist"};
 
 struct ProfRec { hipEvent_t e0, e1; int cls; double flops, bytes; };
 static std::vector<ProfRec> g_recs;
@@ -368,7 +368,9 @@ int dfh_gemm_out2(const dfh_gemm_desc* d, void* out2, int ld_out2, int n_split, 
   DFH_REQUIRE(out2 != nullptr, "null argument");
   g.out2 = out2; g.ld_out2 = ld_out2; g.n_split = n_split;
   DFH_REQUIRE(dfh::gemm_out2_ok(g), "this launch cannot carry a second destination (split-K, or n_split is no multiple of its column tile)");
-  return dfh::gemm_launch(g, (hipStream_t)stream, 0, 0, d->force_order);
+  // tile ids 10 / 24 pin the one-tile-per-workgroup / the persistent 128 x 160 kernel (tests, same-box A/B); anything else = heuristics
+  const int ft = (d->force_tile == 10 || d->force_tile == 24) ? d->force_tile : 0;
+  return dfh::gemm_launch(g, (hipStream_t)stream, ft, 0, d->force_order);
 }
 
 // nearest-2x upsample + 3x3 conv as four phase planes over the source image (gemm.h GemmArgs::phase2x)

@@ -199,7 +199,7 @@ enum ProfClass { PC_CONV3 = 0, PC_LINEAR = 1, PC_ATTN = 2, PC_GNORM = 3, PC_LNOR
 // the batch-16 forward really took the wide tile, the producer-statistics GroupNorm and the split-K path; dfh_census_* in the C ABI)
 enum CensusId { CK_GEMM_WIDE = 0, CK_GEMM_8WAVE, CK_GEMM_LEAN, CK_GEMM_OTHER, CK_GEMM_ROW, CK_SPLITK, CK_SPLITK_FUSED, CK_GSTAT_WRITTEN,
                 CK_GN_PRE, CK_GN_STATS, CK_GN_SMALL, CK_GN_MID, CK_LAYERNORM, CK_LN_FOLDED, CK_ATTN_X32, CK_ATTN_16, CK_GEMM_FP8,
-                CK_TEXT_CACHED, CK_CONV_PHASE, CK_CONV_WINO, CK_GEMM_ROWS_GEGLU, CK_ATTN_FP8, CK_MLP_FUSED, CK_GN_FOLDED, CK_TOKEN_LINEAR, CK_DUP_PREFIX, CK_COUNT };
+                CK_TEXT_CACHED, CK_CONV_PHASE, CK_CONV_WINO, CK_GEMM_ROWS_GEGLU, CK_ATTN_FP8, CK_MLP_FUSED, CK_GN_FOLDED, CK_TOKEN_LINEAR, CK_DUP_PREFIX, CK_GEMM_PERSIST, CK_COUNT };
 void census(int id);
 bool prof_enabled();
 void prof_open(int cls, double flops, double bytes, hipStream_t s);   // no-ops unless enabled

@@ -189,5 +189,9 @@ int gemm_ws_launch(GemmArgs a, hipStream_t stream, int bn);
 // inside the step (profiles/r03/geglu_phases.txt)
 bool gemm_geglu_rows_ok(const GemmArgs& a);
 int gemm_geglu_rows_launch(const GemmArgs& a, hipStream_t stream);
+// persistent short-K token linear (scripts/probes/kernels/gemm_persist.hip, round 6): one workgroup per CU walks its 128 x 160 tiles, the LDS ring
+// runs across tiles; bit-identical to gemm_bf16_kernel<128,160,4,2,*,LEAN>, measured 1.2-1.5 x SLOWER (profiles/r06/persistent_lean_gemm.md)
+bool gemm_persist_ok(const GemmArgs& a);
+int gemm_persist_launch(const GemmArgs& a, hipStream_t stream, int max_wgs = 0);
 #endif
 }  // namespace dfh

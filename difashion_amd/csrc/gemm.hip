@@ -1102,14 +1102,17 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     // tile id 23: the 256 x 256 GEGLU tile
     const bool force_bigg = force_wide == 18;
     if (force_bigg) force_wide = 0;
+    // tile id 24: the persistent 128 x 160 kernel (gemm_persist.hip) for every launch it can take; otherwise persist_pick decides
+    const bool force_persist = force_wide == 19;
+    if (force_persist) { force_wide = 0; tile = kEightWave; }
     const bool pre = a.pre_out != nullptr;      // training GEGLU with its pre-activations as a second output: the 256 x 128 wide tile only
     if (pre) DFH_REQUIRE(wide_ok && a.act == ACT_GEGLU && a.N % 128 == 0 && !a.ln_stat && !a.resid && !a.rowvec && (a.ld_pre & 7) == 0 && a.ld_pre >= a.N,
                          "pre_out: GEGLU launches with N % 128 == 0, no split-K, no folded LayerNorm");
-    const bool bigg = !pre && wide_ok && !force_deep && a.act == ACT_GEGLU && a.N % 32 == 0 && !a.resid && !a.rowvec &&
+    const bool bigg = !pre && wide_ok && !force_deep && !force_persist && a.act == ACT_GEGLU && a.N % 32 == 0 && !a.resid && !a.rowvec &&
                       (force_bigg || (!force_wide && force_tile == 0 && force_split == 0 && gemm_big_geglu_pick(a)));
     const bool big_ok = wide_ok0 && !force_deep && a.act != ACT_GEGLU && !a.ln_stat && (a.nbatch <= 1 || force_big) && !a.w_img_bs;
-    const bool big = big_ok && (force_big || (!force_wide && force_tile == 0 && force_split == 0 && gemm_big_pick(a)));
-    int wide = pre ? 5 : (!wide_ok || force_deep || big || force_big || bigg || force_bigg) ? 0 : (force_wide ? force_wide : ((force_tile == 0 && force_split == 0) ? gemm_wide_pick(a) : 0));
+    const bool big = big_ok && !force_persist && (force_big || (!force_wide && force_tile == 0 && force_split == 0 && gemm_big_pick(a)));
+    int wide = pre ? 5 : (!wide_ok || force_deep || big || force_big || bigg || force_bigg || force_persist) ? 0 : (force_wide ? force_wide : ((force_tile == 0 && force_split == 0) ? gemm_wide_pick(a) : 0));
     int ws = 0; bool halo = false;
 #ifdef DFH_PROBES
     // Probe builds only (scripts/probes/Makefile): tile ids 11 / 12 = the wave-specialised kernel (scripts/probes/kernels/gemm_ws.hip, opt-in
@@ -1154,6 +1157,17 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
       if (!(a.rowstat && bn > 0 && staged_ok && a.N % bn == 0 && !halo)) a.rowstat = nullptr;
       else if (rowstat_bn) *rowstat_bn = bn;
     }
+    bool persist = false;
+#ifdef DFH_PROBES
+    // Probe builds only: the persistent 128 x 160 kernel (scripts/probes/kernels/gemm_persist.hip; tile id 24, or DFH_PERSIST=1 / 2 for every
+    // eligible launch with >= 512 / >= 1 tiles).  Bit-identical to the tile kernel and 1.2-1.5 x slower: profiles/r06/persistent_lean_gemm.md.
+    static const int persist_mode = [] { const char* e = getenv("DFH_PERSIST"); return e ? atoi(e) : 0; }();
+    persist = !bigg && !big && !wide && !halo && !ws && tile == kEightWave && !force_deep && (force_tile == 0 || force_persist) &&
+              gemm_persist_ok(a) && (force_persist || (persist_mode != 0 && (long)(a.M / 128) * (a.N / 160) >= (persist_mode >= 2 ? 1 : 512)));
+    if (force_persist) DFH_REQUIRE(persist, "tile id 24: this launch cannot run on the persistent kernel (gemm_persist_ok)");
+#else
+    DFH_REQUIRE(!force_persist, "tile id 24 is a probe kernel: build scripts/probes (make -C scripts/probes) and load it with DFH_LIB");
+#endif
 #ifdef DFH_PROBES
     if (halo) rc = gemm_halo_launch(a, stream);
     else if (ws) rc = gemm_ws_launch(a, stream, ws);
@@ -1164,7 +1178,11 @@ int gemm_launch(GemmArgs a, hipStream_t stream, int force_tile, int force_split,
     if (bigg) rc = launch_big_geglu(a, stream);
     else if (big) rc = launch_big(a, stream);
     else if (wide) rc = gemm_wide_launch(a, stream, wide);
+#ifdef DFH_PROBES
+    else if (persist) rc = gemm_persist_launch(a, stream);
+#endif
     else rc = launch_variant(tile, a, stream);
+    if (persist) census(CK_GEMM_PERSIST);
     census((big || bigg) ? CK_GEMM_ROW : wide ? CK_GEMM_WIDE : ((halo || ws) ? CK_GEMM_OTHER : (tile == kEightWave ? (lean_plain(a) ? CK_GEMM_LEAN : CK_GEMM_8WAVE) : CK_GEMM_OTHER)));
     if (a.gstat) census(CK_GSTAT_WRITTEN);
     if (a.phase2x) census(CK_CONV_PHASE);

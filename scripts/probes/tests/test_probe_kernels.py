@@ -148,3 +148,102 @@ def test_attention_backward_x32_variant_is_parity_green():
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_backward.py", "-x", "-q", "-k", "attention_backward and 40-8"],
                        capture_output=True, text=True, env=env, cwd=root, timeout=900)
     assert r.returncode == 0 and "5 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+PERSIST_CASES = {
+    # name: (M, N, K segments, options)   -- whole 128 x 160 tiles, K >= 256 in 64-deep steps (gemm_persist_ok)
+    "resid_two_tiles_per_cu": (128 * 600, 320, (320,), dict(bias=True, resid=True)),               # 1200 tiles: every workgroup walks 4-5 tiles
+    "plain_ragged_rounds": (128 * 301, 320, (320,), dict(bias=False, resid=False)),                # 602 tiles over 256 workgroups: 2 or 3 each
+    "single_round": (128 * 9, 160, (256,), dict(bias=True, resid=True)),                           # 9 tiles: one per workgroup, no ring reuse
+    "silu_k640": (128 * 160, 640, (640,), dict(bias=True, resid=True, act=1)),
+    "two_segments": (128 * 130, 320, (1280, 320), dict(bias=True, resid=True)),                    # ff.net.2 . proj_out: [hidden | x] operands
+    "transposed": (6 * 1024, 320, (320,), dict(bias=True, out_t=True, rows_per_b=1024)),           # V^T
+    "qk_and_vt": (6 * 4096, 960, (320,), dict(out2=True, rows_per_b=4096)),                        # q | k | V^T from one launch
+    "rowstat_producer": (128 * 300, 640, (320,), dict(bias=True, resid=True, rowstat=True)),
+    "ln_consumer": (128 * 300, 640, (320,), dict(bias=True, ln_parts=2)),
+    "ln_consumer_4_parts": (128 * 150, 960, (640,), dict(bias=False, ln_parts=4)),
+    "gstat_32x32": (24 * 1024, 640, (640,), dict(bias=True, resid=True, gstat=(20, 1024))),
+    "per_image_weights": (6 * 4096, 320, (320,), dict(rowvec_img=True, w_img=True, rows_per_b=4096)),   # GroupNorm folded into proj_in
+}
+
+
+@pytest.mark.parametrize("name", list(PERSIST_CASES))
+def test_gemm_persistent_matches_the_tile_kernel_bit_for_bit(name):
+    """gemm_persist.hip (tile id 24: one workgroup per CU walks its 128 x 160 tiles, the LDS ring runs across tiles, every epilogue operand
+    arrives by LDS-DMA, counted waits only) against gemm_bf16_kernel<128,160,4,2,*,LEAN> (tile id 10) on the same operands: the same
+    MFMA sequence per tile and the same epilogue arithmetic -> every output, row-statistics record and GroupNorm partial BIT for bit, and
+    the fp32 reference within the bf16 tolerance.  Runs each launch twice (a race on the ring or the staging region would differ)."""
+    import ctypes
+    M, N, segs, o = PERSIST_CASES[name]
+    K = sum(segs)
+    a0 = bf(rnd(M, segs[0], seed=201))
+    a1 = bf(rnd(M, segs[1], seed=202)) if len(segs) > 1 else None
+    rows_per_b = o.get("rows_per_b", 0)
+    B = M // rows_per_b if rows_per_b else 1
+    w = bf(rnd((B if o.get("w_img") else 1) * N, K, seed=203, scale=0.05))
+    bias = rnd(N, seed=204) if o.get("bias") else None
+    resid = bf(rnd(M, N, seed=205)) if o.get("resid") else None
+    rowvec = rnd(B, N, seed=206) if o.get("rowvec_img") else None
+    parts = o.get("ln_parts", 0)
+    ln_stat = ln_s = None
+    if parts:
+        cnt = segs[0] // parts
+        xp = a0.float().view(M, parts, cnt).transpose(0, 1)
+        mean_t = xp.mean(-1)
+        ln_stat = torch.stack([mean_t, ((xp - mean_t[..., None]) ** 2).sum(-1)], dim=-1).contiguous()      # [parts][M][2]
+        ln_s = w.float().sum(1).contiguous()
+
+    def run(tile):
+        kw = dict(M=M, N=N, W=w, ldw=K, a0=a0, a0_c=segs[0], bias=bias, resid=resid, act=o.get("act", 0), force_tile=tile,
+                  rows_per_b=rows_per_b)
+        if a1 is not None:
+            kw.update(a1=a1, a1_c=segs[1])
+        if rowvec is not None:
+            kw.update(rowvec=rowvec, rv_ld=N, rv_off=0)
+        if o.get("w_img"):
+            kw.update(w_img_stride=N * K)
+        res = {}
+        if o.get("out_t"):
+            out = torch.zeros((B, N, rows_per_b + 8), dtype=torch.bfloat16, device=DEV)
+            kw.update(out=out, ld_out=rows_per_b + 8, out_mode=1)
+        if o.get("out2"):
+            qk = torch.zeros((M, 640), dtype=torch.bfloat16, device=DEV)
+            vt = torch.zeros((B, N - 640, rows_per_b + 8), dtype=torch.bfloat16, device=DEV)
+            d = gu.gemm_desc(**dict(kw, out=qk, ld_out=640))
+            _lib.call("dfh_gemm_out2", ctypes.byref(d), _lib.ptr(vt), rows_per_b + 8, 640, gu.stream())
+            torch.cuda.synchronize()
+            return dict(out=qk, vt=vt)
+        if o.get("rowstat") or parts:
+            d = gu.gemm_desc(**kw)
+            st = torch.full((8 * M * 2,), float("nan"), dtype=torch.float32, device=DEV) if o.get("rowstat") else None
+            bn = ctypes.c_int(0)
+            _lib.call("dfh_gemm_ln", ctypes.byref(d), _lib.ptr(st), ctypes.byref(bn) if st is not None else None,
+                      _lib.ptr(ln_stat), parts, (segs[0] // parts) if parts else 0, 1e-5, _lib.ptr(ln_s), gu.stream())
+            torch.cuda.synchronize()
+            res["out"] = d.keep_out
+            if st is not None:
+                assert bn.value == 160
+                res["rowstat"] = st[:(N // 160) * M * 2].clone()
+            return res
+        if o.get("gstat"):
+            cpg, hw = o["gstat"]
+            gst = torch.full(((M // hw) * (N // cpg) * (hw // 128) * 2,), float("nan"), dtype=torch.float32, device=DEV)
+            out, rows = gu.gemm(gstat=gst, gstat_cpg=cpg, gstat_hw=hw, **kw)
+            assert rows == 128
+            return dict(out=out, gstat=gst)
+        return dict(out=gu.gemm(**kw))
+
+    _lib.census_reset()
+    got = run(24)
+    assert _lib.census()["gemm_persist"] == 1
+    again = run(24)
+    ref = run(10)
+    assert _lib.census()["gemm_persist"] == 2
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), (name, k, float((got[k].float() - ref[k].float()).abs().max()))
+        assert torch.equal(again[k], got[k]), (name, k, "rerun differs")
+    # ... and the tile kernel itself is held to fp32 by the tests above; one direct check here for the plain shapes
+    if not parts and not o.get("out_t") and not o.get("out2") and not o.get("w_img") and o.get("act", 0) == 0:
+        A = a0.float() if a1 is None else torch.cat([a0.float(), a1.float()], 1)
+        want = A @ w.float().T + (bias if bias is not None else 0) + (resid.float() if resid is not None else 0)
+        gu.assert_close_bf16(got["out"], want, name)

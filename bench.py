@@ -282,7 +282,8 @@ def measure_train(args, da, _lib, ddist, rank, world, dev, K, W, profile=True):
            # time per step the compute stream waited for the side-stream gradient exchange = the part of the exchange the backward
            # walk did not hide (max over ranks; null on one GPU: no exchange)
            "comm_exposed_ms": None if comm_exposed_ms is None else round(comm_exposed_ms, 3), "grad_wire": wire,
-           "rccl_ranks": args.ranks_seen if args.backend in (None, "nccl") else None, "collective_backend": args.backend}
+           "rccl_ranks": args.ranks_seen if args.backend in (None, "nccl") else None, "collective_backend": args.backend,
+           "rccl_ranks_match_n_gpus": (args.ranks_seen == world) if args.backend in (None, "nccl") else None}
     if world > 1:       # a slow rank or an exposed exchange must be visible from this one record
         out["rank_ms_per_step"] = dict(min=round(own_min * 1e3 / K, 2), max=round(own_max * 1e3 / K, 2),
                                        note="each rank's own K steps up to its device sync, before the closing barrier")
@@ -714,12 +715,27 @@ def main():
                          "cross q, cross to_out, the GEGLU pair, proj_out) in e4m3 on the block-scaled MFMA; 3x3 convs stay bf16")
     ap.add_argument("--fp8-attention", action="store_true",
                     help="with --dtype fp8: also the self-attention products QK^T / PV on the e4m3 MFMA (opt-in: measured slower, profiles/r04)")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU-only check of the --gpus N launcher flow (tests/test_host_logic_cpu.py, world 8): every rank joins a gloo group "
+                         "from the RANK / WORLD_SIZE / MASTER_* environment launch_ranks gives it, one all-reduce counts the ranks, rank 0 prints "
+                         "one JSON line.  Touches no GPU and measures nothing")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process becomes the launcher.  Nothing here has touched the GPU yet (no HIP call, no
         # torch.cuda.is_available()), and it never will: it starts N fresh ranks and relays rank 0's line.
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    if args.selftest_launcher:
+        from difashion_amd import dist as ddist
+        rank, world, local = ddist.init("gloo")
+        seen = int(round(ddist.sum_over_ranks(1.0)))
+        slowest = ddist.max_over_ranks(float(rank))               # the max-over-ranks reduction the timed region closes with
+        ddist.barrier()
+        if rank == 0:
+            print(json.dumps({"selftest": "launcher", "n_gpus": args.gpus, "world_size": world, "ranks_seen": seen, "max_rank": int(slowest),
+                              "local_rank": local, "collective_backend": "gloo", "rccl_ranks": None}), flush=True)
+        return
 
     import difashion_amd as da
     from difashion_amd import _lib, dist as ddist
@@ -790,6 +806,7 @@ def main():
         "roofline": roofline,
         # ranks counted by an all-reduce of ones on the job's process group (RCCL when the backend is "nccl"; null under the gloo test backend)
         "rccl_ranks": args.ranks_seen if args.backend in (None, "nccl") else None, "collective_backend": args.backend,
+        "rccl_ranks_match_n_gpus": (args.ranks_seen == world) if args.backend in (None, "nccl") else None,
     }
     if nout > 1:
         out["ms_per_step_per_outfit"] = round(elapsed * 1e3 / K / nout, 3)
@@ -821,6 +838,18 @@ def main():
                                      mfma_frac_whole_step=tr.get("mfma_frac_whole_step"), roofline=tr["roofline"])
         except Exception as e:
             sec["configs[2]"] = {"error": repr(e)}
+        # ---- SD-2-base, the reference's OWN default model (train.py:44, inf4eval.py:65: linear projections, 1024-wide text states, head dim 64
+        #      at every level): the configs[1] sampler on that shape, bf16, so that the default model is driver-witnessed too
+        try:
+            gc.collect(); torch.cuda.empty_cache()
+            u2, e2 = build_models(dev, "sd2base")
+            r2 = measure_sampling(da, _lib, ddist, u2, e2, dev, 0, 10, 3, outfits=1, dtype="bf16", profile=False)
+            sec["sd2base_bf16"] = dict(workload="the configs[1] sampler on the SD-2-base shape (the reference's default pretrained_model_name_or_path, "
+                                                "train.py:44): one 4-item outfit, CFG on -> U-Net batch 16, DDIM-50 schedule, bf16",
+                                       steps=10, warmup=3, ms_per_step=round(r2["elapsed"] * 1e3 / 10, 3), steps_per_s=round(10 / r2["elapsed"], 3))
+            del u2, e2
+        except Exception as e:
+            sec["sd2base_bf16"] = {"error": repr(e)}
         sec["seconds_spent"] = round(took + time.time() - t1, 1)
         out["secondary_configs"] = sec
     if not args.no_cpu_baseline and world == 1:

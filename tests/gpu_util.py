@@ -10,6 +10,17 @@ from difashion_amd import _lib
 DEV = "cuda"
 
 
+def release_cached_gpu_memory():
+    """Before a test starts CHILD processes that use the GPU: hand the caching allocator's free blocks back to the driver.  After the
+    full-size training tests the pytest process sits on > 100 GB of cached HBM; a child that then allocates makes the kernel driver
+    evict / migrate that memory (one test took 243 s of which the two children ran 6 s each: gpurun_out/r06_run2, round 6)."""
+    import gc
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+
 def bf(x):
     return x.to(torch.bfloat16)
 

@@ -12,6 +12,15 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _free_parent_cache():
+    """every test of this module starts GPU child processes (tests/gpu_util.py release_cached_gpu_memory)"""
+    from tests.gpu_util import release_cached_gpu_memory
+    release_cached_gpu_memory()
+    yield
+
 TWO_GPUS = torch.cuda.device_count() >= 2          # does not initialise the GPU
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -446,6 +446,8 @@ def test_side_stream_weight_gradients_are_bit_identical_to_the_one_stream_walk(t
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from tests.gpu_util import release_cached_gpu_memory
+    release_cached_gpu_memory()
     got = {}
     for name, env in (("one", {"DFH_TRAIN_SIDE": "0"}), ("side", {"DFH_TRAIN_SIDE_MIN_FLOP": "0"})):
         out = tmp_path / f"{name}.pt"

@@ -205,6 +205,8 @@ def test_dup_tail_hint_that_does_not_hold_is_caught_under_check_mode():
             m(x, 501, e); print("EQUAL INPUTS PASS")
     """)
     env = dict(os.environ, DFH_CHECK_DUP="1")
+    from tests.gpu_util import release_cached_gpu_memory
+    release_cached_gpu_memory()
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
     assert "CAUGHT" in r.stdout and "do NOT repeat" in r.stdout and "EQUAL INPUTS PASS" in r.stdout and "NOT CAUGHT" not in r.stdout, r.stdout + r.stderr
 

@@ -393,6 +393,78 @@ def test_world_size_2_gloo_bf16_wire_gradient_exchange():
     assert bool(((want - (g0 + g1) / 2).abs() <= 2.0 ** -7 * (g0.abs() + g1.abs()) / 2 + 1e-30).all())   # bf16-close to the fp32 average
 
 
+def _world8_worker(rank, world, port, q):
+    """One rank of an 8-rank data-parallel job on CPU (gloo): outfit sharding + the in-backward range exchange of the flat gradient arena
+    (unet.py _backward_overlapped hands out final ranges back to front, the last one ragged), fp32 all-reduce per range and the bf16 wire."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    ddist.init("gloo")
+    mine = ddist.shard_range(37, rank, world)                      # 37 outfits over 8 ranks: ragged (5 x 5 + 3 x 4)
+    n, bucket = 10007, 4096                                        # arena length not a multiple of the bucket nor of 8 ranks
+    g = torch.Generator().manual_seed(500 + rank)
+    arena = torch.randn(n, generator=g) * (10.0 ** torch.randint(-2, 3, (n,), generator=g).float())
+    own = arena.clone()
+    fp32, bf16 = arena.clone(), arena.clone()
+    ranges = []
+    hi = n
+    while hi > 0:                                                  # back to front, like dfh_unet_backward_next
+        lo = max(0, ((hi - 1) // bucket) * bucket)
+        ranges.append((lo, hi))
+        hi = lo
+    for lo, hi in ranges:
+        ddist.all_reduce_gradients(fp32[lo:hi])                    # the default wire: one fp32 all-reduce per range (reference DDP semantics)
+        ddist.all_reduce_gradients(bf16[lo:hi], wire="bf16")       # opt-in wire: rank-order fp32 accumulation of bf16 contributions
+    logged = float(ddist.gather_mean(torch.tensor(float(len(mine)))))
+    q.put((rank, (mine.start, mine.stop), own.tolist(), fp32.tolist(), bf16.tolist(), ranges, logged))
+    dist.destroy_process_group()
+
+
+def test_world_size_8_gloo_sharding_and_in_backward_range_exchange():
+    """the 8-rank shape of BASELINE configs[3] on CPU -- `shard_range` over a ragged outfit count and the range-by-range
+    gradient exchange (ragged last range; fp32 wire and rank-order bf16 wire), every rank ending with identical values."""
+    world = 8
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    spans = [r[1] for r in res]
+    assert spans[0][0] == 0 and spans[-1][1] == 37 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))       # exact partition, rank order
+    assert sorted(b - a for a, b in spans) == [4, 4, 4, 5, 5, 5, 5, 5]
+    assert res[0][5] == [(8192, 10007), (4096, 8192), (0, 4096)]                                                 # ragged range first
+    own = torch.tensor([r[2] for r in res])
+    want32 = own.double().sum(0) / world
+    for r in res:
+        assert r[3] == res[0][3] and r[4] == res[0][4]                                                           # replicas bit-identical
+        assert abs(r[6] - 37 / 8) < 1e-6
+    torch.testing.assert_close(torch.tensor(res[0][3]).double(), want32, rtol=1e-5, atol=1e-6)
+    acc = own[0].bfloat16().float()
+    for k in range(1, world):
+        acc = acc + own[k].bfloat16().float()                                                                    # rank order, fp32
+    assert torch.equal(torch.tensor(res[0][4]), (acc / world).bfloat16().float())
+
+
+def test_bench_gpus_8_launcher_flow_without_gpus():
+    """`python bench.py --gpus 8 --selftest-launcher`: the launcher path of the driver's N = 8 run with the GPU taken out -- launch_ranks
+    starts 8 fresh ranks with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT, they rendezvous (gloo), one all-reduce
+    counts them, rank 0's single JSON line is relayed and the launcher exits 0."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--selftest-launcher"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["world_size"] == 8 and rec["ranks_seen"] == 8 and rec["max_rank"] == 7 and rec["local_rank"] == 0
+
+
 def test_profiles_readme_numbers_are_generated_from_the_artefacts():
     """profiles/README.md quotes each round's numbers between generated markers; the block must equal what scripts/profiles_readme.py
     derives from the committed artefacts of that round (bench JSON lines, rocprofv3 kernel_stats.csv, pmc_traffic.json), so prose and

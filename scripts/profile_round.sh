@@ -16,6 +16,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o $TAG -- $B
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o $TAG -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o $TAG -- $BENCH > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o $TAG -- $BENCH > $OUT/pmc_mfma.log 2>&1
+# round 6: L2 (TCC) hit rate and fabric-side read requests per kernel -- backs "the re-reads beyond the algorithmic bytes are L2 / MALL hits"
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d $OUT/pmc_tcc -o $TAG -- $BENCH > $OUT/pmc_tcc.log 2>&1
 cd $GRAFT_REPO_ROOT
 find $OUT -name "*.csv" | head -30
 python3 scripts/summarize_profile.py $OUT $DT > $OUT/summary.md 2>&1

@@ -86,18 +86,41 @@ if st:
         dur[short(r["Name"])] = (float(r["TotalDurationNs"]), int(r["Calls"]))
 if mf:
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    fnm = collections.Counter()
     for r in csv.DictReader(open(mf)):
         agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            fnm[short(r["Kernel_Name"])] += 1
     print("\n## derived per kernel\n")
     print("MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES): SQ_BUSY_CYCLES is summed over the 32 shader engines, each with")
     print("32 SIMDs (8 CUs x 4), so the denominator is the SIMD-cycles of the launch; HBM GB/s = (FETCH_SIZE x 2 + WRITE_SIZE) KiB per")
     print("dispatch over the traced average duration (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md HBM section).\n")
-    print("| kernel | MFMA busy % | HBM GB/s | avg us |\n|---|---|---|---|")
-    for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0))[:14]:
+    tc = find("pmc_tcc", "*counter_collection.csv")
+    tcc = collections.defaultdict(lambda: collections.defaultdict(float))
+    tcn = collections.Counter()
+    if tc:
+        for r in csv.DictReader(open(tc)):
+            tcc[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "TCC_HIT_sum":
+                tcn[short(r["Kernel_Name"])] += 1
+    print("clock MHz = GRBM_GUI_ACTIVE per dispatch / 8 XCDs / the traced average duration (two different passes: +-10 %); L2 hit % =")
+    print("TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum); fabric reads MB = TCC_EA0_RDREQ_sum x 128 B per dispatch (wide reads: the request the")
+    print("counter tallies at 64 B is a 128-B one, MI355X_MICROARCH.md HBM section) -- reads that left the XCD's L2 for MALL / HBM.\n")
+    print("| kernel | MFMA busy % | HBM GB/s | avg us | clock MHz | L2 hit % | fabric reads MB / launch |\n|---|---|---|---|---|---|---|")
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0))[:16]:
         sqb = v.get("SQ_BUSY_CYCLES", 0)
         busy = 100.0 * v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (sqb * 32) if sqb else 0.0
         gbs = ""
         if k in dur and dur[k][0] > 0 and k in ft:
             byts = (2 * ft[k] / max(1, fn[k]) + wt.get(k, 0) / max(1, wn.get(k, 1))) * 1024 * dur[k][1]
             gbs = f"{byts / dur[k][0]:.0f}"
-        print(f"| {k} | {busy:.1f} | {gbs} | {dur[k][0] / dur[k][1] / 1e3 if k in dur else 0:.1f} |")
+        avg_us = dur[k][0] / dur[k][1] / 1e3 if k in dur else 0.0
+        mhz = ""
+        if avg_us > 0 and fnm.get(k):
+            mhz = f"{v.get('GRBM_GUI_ACTIVE', 0) / fnm[k] / 8.0 / avg_us:.0f}"
+        hit, fab = "", ""
+        if k in tcc and tcn[k]:
+            h, m = tcc[k].get("TCC_HIT_sum", 0.0), tcc[k].get("TCC_MISS_sum", 0.0)
+            hit = f"{100.0 * h / (h + m):.1f}" if h + m > 0 else ""
+            fab = f"{tcc[k].get('TCC_EA0_RDREQ_sum', 0.0) * 128.0 / tcn[k] / 1e6:.1f}"
+        print(f"| {k} | {busy:.1f} | {gbs} | {avg_us:.1f} | {mhz} | {hit} | {fab} |")

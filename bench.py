@@ -406,6 +406,68 @@ def run_vae(args, da, _lib, ddist, rank, world, dev):
     print(json.dumps(out), flush=True)
 
 
+def run_clip(args, da, _lib, ddist, rank, world, dev):
+    """the frozen CLIP text encoder in front of the denoising path.  One step = what a run pays ONCE: the closed prompt set of
+    the dataset -- 50 category prompts + the empty prompt (data_utils.py:96-111, difashion.py:226-234) = 51 sequences of 77 tokens -- through
+    the HIP encoder (csrc/clip.hip, fp32 on v_mfma_f32_16x16x4_f32), i.e. PromptTable.build.  Random CLIP ViT-L/14 (SD-1.5) or OpenCLIP ViT-H/14
+    (--config sd2base) shape weights, prompt-like token ids.  Roofline: the fp32 matrix instruction, 256 FLOP / clk / CU = 157.3 TFLOP/s."""
+    from oracle import clip_ref          # shapes + synthetic ids only (test infrastructure); timed further down as the cpu_baseline
+    cfg = clip_ref.SD2_CLIP if args.config == "sd2base" else clip_ref.SD15_CLIP
+    m = da.CLIPTextModel(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                         num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads, hidden_act=cfg.hidden_act,
+                         eos_token_id=cfg.eos_token_id, init_seed=0).to(dev).eval().requires_grad_(False)
+    B, T = 51, 77
+    ids = clip_ref.prompt_like_ids(cfg, B, T, seed=rank).to(dev)
+    K, W = args.steps, args.warmup
+    for _ in range(W):
+        m(ids)
+    torch.cuda.synchronize(); ddist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        out = m(ids)[0]
+    torch.cuda.synchronize(); ddist.barrier(); torch.cuda.synchronize()
+    el = ddist.max_over_ranks(time.perf_counter() - t0)
+    assert torch.isfinite(out).all()
+    D, I, L, H = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.num_attention_heads
+    M = B * T
+    gemm_flops = 2.0 * M * L * (4 * D * D + 2 * D * I)                       # q / k / v / out projections + the two MLP linears
+    attn_flops = 2.0 * B * H * L * 2 * (T * (T + 1) / 2) * (D // H)          # causal scores + PV (VALU fp32)
+    # HIP events on the launch stream around the K timed encodes of a second pass (the whole encoder is one stream of launches)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(K):
+        m(ids)
+    e1.record()
+    torch.cuda.synchronize()
+    ev_ms = e0.elapsed_time(e1) / K
+    if rank != 0:
+        return
+    FP32_MFMA_PEAK = 157.3
+    ach = (gemm_flops + attn_flops) / (ev_ms * 1e-3) / 1e12
+    rec = {"metric": "CLIP text encoder, prompt tables/sec (51 prompts x 77 tokens)", "value": round(world * K / el, 3), "unit": "tables/s",
+           "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(el * 1e3 / K, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"SURVEY 8f-2: {('OpenCLIP ViT-H/14, 23 layers x 1024' if args.config == 'sd2base' else 'CLIP ViT-L/14, 12 layers x 768')} text tower, "
+                                  "the dataset's closed prompt set (50 category prompts + the empty prompt) = 51 x 77 tokens per step: what a run pays once "
+                                  "(PromptTable.build)", "prompts": B, "tokens": T, "prompts_per_s": round(world * K * B / el, 1)},
+           "roofline": {"bound": "mfma", "kernel": "clip_gemm_f32_kernel (v_mfma_f32_16x16x4_f32) + clip_attention_kernel", "achieved": round(ach, 2),
+                        "peak": FP32_MFMA_PEAK, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK, 4), "traffic": None,
+                        "algorithmic_tflop_per_step": round((gemm_flops + attn_flops) / 1e12, 4), "event_ms_per_step": round(ev_ms, 3),
+                        "note": "HIP events on the launch stream around the K encodes; fp32 matrix peak 256 FLOP/clk/CU x 256 CUs x 2.4 GHz"}}
+    if not args.no_cpu_baseline and world == 1:
+        torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+        p = clip_ref.init_params(cfg, 0)
+        ids_c = ids.cpu()
+        with torch.no_grad():
+            clip_ref.clip_text_forward(p, cfg, ids_c[:4])
+            t0 = time.perf_counter()
+            clip_ref.clip_text_forward(p, cfg, ids_c)
+            t = time.perf_counter() - t0
+        rec["cpu_baseline"] = dict(value=round(1.0 / t, 3), unit="tables/s", cores=torch.get_num_threads(), kind="port",
+                                   sample=f"oracle/clip_ref.py fp32 (pinned to transformers.CLIPTextModel) on the same 51 x 77 ids = {t:.2f}s")
+    print(json.dumps(rec), flush=True)
+
+
 def pmc_traffic(dtype="bf16"):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/rNN/pmc_traffic.json for the bf16
     walk, profiles/rNN/pmc_traffic_fp8.json for --dtype fp8: each measured ON ITS OWN walk by scripts/profile_round.sh with separate
@@ -701,8 +763,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short configs[4] / inference-batch-64 / configs[2] legs the default one-GPU invocation runs after the headline")
-    ap.add_argument("--mode", default="sample", choices=["sample", "train", "vae"],
-                    help="sample: the headline metric (default); train: BASELINE configs[2]/[3] training step; vae: SURVEY 8f-1")
+    ap.add_argument("--mode", default="sample", choices=["sample", "train", "vae", "clip"],
+                    help="sample: the headline metric (default); train: BASELINE configs[2]/[3] training step; vae: SURVEY 8f-1; clip: SURVEY 8f-2 "
+                         "(the prompt table through the HIP CLIP text encoder)")
     ap.add_argument("--outfits", type=int, default=8, help="--mode train: outfits per GPU per step")
     ap.add_argument("--outfits-per-gpu", type=int, default=1,
                     help="--mode sample: outfits denoised together on each GPU (1 = BASELINE configs[1], U-Net batch 16; 4 = the reference's own "
@@ -767,6 +830,8 @@ def main():
         return run_train(args, da, _lib, ddist, rank, world, dev)
     if args.mode == "vae":
         return run_vae(args, da, _lib, ddist, rank, world, dev)
+    if args.mode == "clip":
+        return run_clip(args, da, _lib, ddist, rank, world, dev)
     unet, enc = build_models(dev, args.config)
     if args.dtype == "fp8":
         unet.enable_fp8(True, attention=args.fp8_attention)

@@ -97,3 +97,57 @@ def test_clip_checkpoint_directory_round_trip(tmp_path):
     m2 = da.CLIPTextModel.from_pretrained(str(tmp_path), subfolder="text_encoder").to(DEV)
     assert m2.config.hidden_act == "gelu" and m2.config.eos_token_id == cfg.eos_token_id
     assert torch.equal(m2(ids.to(DEV))[0], want)
+
+
+def test_difashion_runs_end_to_end_on_the_hip_text_encoder():
+    """The reference's own wiring (difashion.py:70-72, :340-353): ``DiFashion`` holding the HIP ``CLIPTextModel`` as ``text_encoder`` and
+    calling ``text_encoder(input_ids)[0]`` per sampling call -- against the same run fed from a ``PromptTable`` built ONCE with that encoder
+    (prompts.py): the encoder is deterministic and its rows independent, so the two runs must agree bit for bit; and against the fp32
+    oracle text states within the sampler's tolerance."""
+    import types
+    from difashion_amd.difashion import DiFashion
+    from oracle import clip_ref as cr
+    from tests.helpers import GLUE_CFG, glue_unet_params, load
+    from tests.test_gpu_difashion import CATE_NUM, H, IdentityVAE, TensorKeyDict, sample_inputs
+    from tests.test_gpu_pipeline import encoder
+    from tests.test_gpu_unet import hip_unet
+    cfg = dataclasses.replace(cr.TINY_CLIP, hidden_size=GLUE_CFG.cross_attention_dim, vocab_size=64)
+    params = cr.init_params(cfg, 9)
+    text = hip_clip(cfg, params)
+    unet = hip_unet(GLUE_CFG, glue_unet_params(), max_batch=32)
+    rec = load("sample_fitb_full_ddim10.npz")
+    olists = torch.tensor([[3, 0, 5, 6], [7, 8, 9, 0]])
+    images, null_img, cats, ids, uids, oids, init, hist = sample_inputs(2, olists, seed=31)
+
+    class Tok:                       # the category id is the prompt (one token + eos), "" is the bare eos row
+        model_max_length = 77
+
+        def __call__(self, texts, padding=None, max_length=77, truncation=True, return_tensors="pt"):
+            out = torch.zeros(len(texts), max_length, dtype=torch.long)
+            out[:, 0] = 1
+            return types.SimpleNamespace(input_ids=out)
+
+    ids = ids.clone()
+    ids[:, :, 1] = 1
+    args = types.SimpleNamespace(use_history=True, use_mutual_guidance=True, eta=0.1)
+    d = lambda t: t.to(DEV)
+    hist_dev = {u: TensorKeyDict({c: d(v) for c, v in h.items()}) for u, h in hist.items()}
+    kw = dict(uids=uids, oids=oids, input_ids=ids, olists=olists, outfit_images=d(images.reshape(8, 4, H, H)), category=cats, history=hist_dev,
+              num_inference_steps=4, category_guidance_scale=7.5, hist_guidance_scale=3.0, mutual_guidance_scale=2.0, null_img=d(null_img), eta=0.0,
+              init_latents=d(init), output_type="latent", return_dict=True)
+    live = DiFashion(args, vae=IdentityVAE(), unet=unet, fashion_encoder=encoder(rec), noise_scheduler=da.DDIMScheduler(), text_encoder=text,
+                     tokenizer=Tok())
+    got = live.fashion_generation(**kw)[0].images
+    # the same prompts through a table built once: row c = text_encoder(ids of category c)[0], last row the empty prompt
+    cat_ids = sorted(set(cats.reshape(-1).tolist()))
+    rows = torch.zeros(len(cat_ids) + 1, 77, dtype=torch.long)
+    rows[:-1, 0] = torch.tensor(cat_ids) + 5
+    rows[:, 1] = 1
+    rows[-1, 0], rows[-1, 1] = 1, 0
+    table = PromptTable(text(rows.to(DEV))[0], cat_ids)
+    cached = DiFashion(args, vae=IdentityVAE(), unet=unet, fashion_encoder=encoder(rec), noise_scheduler=da.DDIMScheduler(), prompt_table=table)
+    assert torch.equal(cached.fashion_generation(**kw)[0].images, got)
+    assert torch.isfinite(got).all() and got.shape == init.shape
+    # fp32 oracle text states for the same ids: the HIP encoder's are 1e-6 away, far inside what the U-Net's bf16 path resolves
+    want = cr.clip_text_forward(params, cfg, ids[0])[0]
+    assert rel(text(ids[0].to(DEV))[0].cpu(), want) < TOL

@@ -9,6 +9,10 @@
 // ring: two stages (72 KB) are in flight at every moment, including under every epilogue; the next tile's first two k-steps land while the
 // current tile is staged and stored.
 //
+// The k-loop is software-pipelined (second form, see profiles/r06/persistent_lean_gemm.md): fragment reads of the next 32-deep half in front of the
+// MFMAs of the current one, the workgroup's barrier in the middle of a k-step, stage g + 3 refilled behind it; the tile order advances without
+// divisions.  MEASURED 1.1-1.5 x SLOWER than the tile kernel at two workgroups per CU: this file lives in the probe library only.
+//
 // What makes the ring survive the epilogue:
 //   * the staged output tile has its own LDS region (43.5 KB behind the ring); the ring is never the epilogue's scratch;
 //   * EVERYTHING the epilogue needs from global memory arrives by LDS-DMA issued at the tile's first k-step: the residual tile (42 pieces,
@@ -60,7 +64,8 @@ DFH_DEVICE void wait_vmcnt_dyn(int n) {
 // workgroup barrier that orders LDS traffic ONLY: __syncthreads() carries a workgroup-scope fence, i.e. s_waitcnt vmcnt(0) -- it would drain
 // the two ring stages in flight under every epilogue.  LDS writes are complete when lgkmcnt reaches zero.
 DFH_DEVICE void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);                    // vmcnt(63) expcnt(7) lgkmcnt(0)
+  asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
@@ -103,13 +108,38 @@ __global__ __launch_bounds__(PNWV * 64, 2) void gemm_persist_kernel(const GemmAr
   int issued = 0;                      // counted vector-memory operations this wave has issued
   int mark0 = 0, mark1 = 0, mark2 = 0; // `issued` right after the pieces of the stage in ring slot 0 / 1 / 2 (scalars, not an indexed array: no scratch)
 
-  // ---- producer side: the stream of (tile, k-step) pairs, two k-steps ahead of the consumer
-  int is_j = 0, is_t = 0, is_slot = 0;                  // next stage to issue: tile ordinal, k-step inside the tile, ring slot
+  // ---- tile order without divisions in the loop.  Workgroup b owns the tile ids v = b + j P (P a multiple of 8: every one of them on XCD b & 7,
+  //      dfh_common.h xcd_remap); in the legacy order (tm_gm == 0, required by gemm_persist_ok) the logical tile of id v is base(xcd) + (v >> 3), so
+  //      consecutive tiles of a workgroup are P / 8 apart: (hi, lo) = divmod(tile, D) advances by divmod(P / 8, D) with one carry.  The divisions the
+  //      compiler would run on the VALU (~40 instructions each, 8 waves) cost more than a k-step when done per tile.
+  const int Dv = a.n_major ? ntm : ntn;                 // m-major: tile = mt * ntn + nt;  n-major: tile = nt * ntm + mt
+  int q_hi, q_lo;                                       // divmod(logical tile, Dv) of the NEXT tile the producer will start
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+    const int tile0 = (P & 7) ? (int)blockIdx.x : ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    q_hi = tile0 / Dv; q_lo = tile0 - q_hi * Dv;
+  }
+  const int st = (P & 7) ? P : (P >> 3);                // logical-tile distance between a workgroup's consecutive tiles
+  const int st_hi = st / Dv, st_lo = st - st_hi * Dv;
+  int q_m0 = 0, q_n0 = 0;                               // coordinates of the tile the producer started last: read by the consumer two k-steps later
+  // residual pieces: staged-layout chunk c = p * 64 + lane -> (row, 16-byte chunk) once per kernel
+  unsigned r_row[(P_RES_PIECES + PNWV - 1) / PNWV], r_q8[(P_RES_PIECES + PNWV - 1) / PNWV];
+#pragma unroll
+  for (int i = 0; i < (P_RES_PIECES + PNWV - 1) / PNWV; ++i) {
+    const int c = (i * PNWV + wave) * 64 + lane, row = c / 21, qq = c - row * 21;
+    r_row[i] = (unsigned)row; r_q8[i] = (unsigned)((qq < 20 ? qq : 0) * 8);
+  }
+  const bool need_tb = a.w_img_bs != 0 || a.rowvec != nullptr || a.out2 != nullptr || a.out_mode == OUT_BF16_T;
+
+  // ---- producer side: the stream of (tile, k-step) pairs, up to three k-steps ahead of the consumer
+  int is_t = 0, is_slot = 0;                            // next stage to issue: k-step inside its tile, ring slot
+  int n_issued = 0;                                     // stages issued so far (all tiles)
   unsigned lo_a[P_IA], lo_w[P_IB];
   const char* is_abase = (const char*)a.p_src[0];
   const char* is_wb = (const char*)a.W;
   int is_left = 0x7fffffff, is_m0 = 0;
   const int steps0 = a.p_c[0] / BK;
+  const unsigned pc0 = (unsigned)a.p_c[0], pc1 = (unsigned)a.p_c[1], ldw_u = (unsigned)a.ldw;
 
   f32x4_t acc[PFM][PFN];
 #pragma unroll
@@ -122,65 +152,102 @@ __global__ __launch_bounds__(PNWV * 64, 2) void gemm_persist_kernel(const GemmAr
   unsigned char* const epi = smem + P_EPI;
   unsigned char* const aux = smem + P_AUX;
 
-  // ---- consumer side: tile ordinal j, k-step t of it, ring slot buf; its tile coordinates
-  int j = 0, t = 0, buf = 0;
+  // One stage = this wave's pieces of the A and W tiles of the next (tile, k-step) of the stream
+#define DFH_ISSUE_STAGE()                                                                                                                    \
+  do {                                                                                                                                        \
+    if (is_t == 0) {                                                                                                                          \
+      const int mt = a.n_major ? q_lo : q_hi, nt = a.n_major ? q_hi : q_lo;                                                                   \
+      q_lo += st_lo; q_hi += st_hi;                                                                                                           \
+      if (q_lo >= Dv) { q_lo -= Dv; ++q_hi; }                                                                                                 \
+      is_m0 = mt * PBM; q_m0 = is_m0; q_n0 = nt * PBN;                                                                                        \
+      is_abase = (const char*)a.p_src[0];                                                                                                     \
+      is_left = a.nplain == 2 ? steps0 : 0x7fffffff;                                                                                          \
+      is_wb = (const char*)(a.W + (a.w_img_bs ? (long)(is_m0 / a.rows_per_b) * a.w_img_bs : 0L));                                              \
+      _Pragma("unroll") for (int i = 0; i < P_IA; ++i) lo_a[i] = ((unsigned)(is_m0 + (i * PNWV + wave) * 8 + srow) * pc0 + (unsigned)sslot * 8) * 2u; \
+      _Pragma("unroll") for (int i = 0; i < P_IB; ++i)                                                                                        \
+        lo_w[i] = ((unsigned)min(q_n0 + (i * PNWV + wave) * 8 + srow, a.N - 1) * ldw_u + (unsigned)sslot * 8) * 2u;                            \
+    }                                                                                                                                         \
+    if (is_left == 0) {                                                                                                                       \
+      is_abase = (const char*)a.p_src[1];                                                                                                     \
+      _Pragma("unroll") for (int i = 0; i < P_IA; ++i) lo_a[i] = ((unsigned)(is_m0 + (i * PNWV + wave) * 8 + srow) * pc1 + (unsigned)sslot * 8) * 2u; \
+      is_left = 0x7fffffff;                                                                                                                   \
+    }                                                                                                                                         \
+    --is_left;                                                                                                                                \
+    const unsigned As_ = lds0 + is_slot * P_STAGE + wave * 1024, Bs_ = As_ + P_A_BYTES;                                                       \
+    const char* ab = uni_ptr(is_abase);                                                                                                       \
+    const char* wb = uni_ptr(is_wb);                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < P_IA; ++i) { glds(ab, lo_a[i], As_ + i * PNWV * 1024); lo_a[i] += BK * 2; }                          \
+    _Pragma("unroll") for (int i = 0; i < P_IB; ++i) {                                                                                        \
+      if (i * PNWV + wave >= P_PB) continue;                                                                                                  \
+      glds(wb, lo_w[i], Bs_ + i * PNWV * 1024); lo_w[i] += BK * 2;                                                                            \
+    }                                                                                                                                         \
+    issued += n_stage;                                                                                                                        \
+    if (is_slot == 0) mark0 = issued; else if (is_slot == 1) mark1 = issued; else mark2 = issued;                                             \
+    if (++is_slot == PNST) is_slot = 0;                                                                                                       \
+    if (++is_t == nk) is_t = 0;                                                                                                               \
+    ++n_issued;                                                                                                                               \
+  } while (0)
+
+  // fragments of one 32-deep half of a k-step: ds_read_b128 with the swizzle of gemm.hip
+#define DFH_LOAD_FRAGS(AF, BF, SLOT, KS)                                                                                                      \
+  do {                                                                                                                                        \
+    const unsigned char* As_ = smem + (SLOT) * P_STAGE;                                                                                       \
+    const unsigned char* Bs_ = As_ + P_A_BYTES;                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < PFM; ++i) {                                                                                         \
+      const int row = wm * PTM + i * 16 + fr;                                                                                                 \
+      AF[i] = *(const bf16x8_t*)(As_ + row * 128 + ((((KS) * 4 + fg) ^ ((row >> 1) & 7)) << 4));                                               \
+    }                                                                                                                                         \
+    _Pragma("unroll") for (int jj = 0; jj < PFN; ++jj) {                                                                                      \
+      const int row = wn * PTN + jj * 16 + fr;                                                                                                \
+      BF[jj] = *(const bf16x8_t*)(Bs_ + row * 128 + ((((KS) * 4 + fg) ^ ((row >> 1) & 7)) << 4));                                              \
+    }                                                                                                                                         \
+  } while (0)
+#define DFH_MFMAS(AF, BF)                                                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < PFM; ++i)                                                                                             \
+    _Pragma("unroll") for (int jj = 0; jj < PFN; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[jj], AF[i], acc[i][jj], 0, 0, 0)
+
+  // ---- consumer side: k-step t of the current tile, ring slot buf; its tile coordinates
+  int t = 0, buf = 0;
   int m0 = 0, n0 = 0, nt_ = 0, tb_ = 0;
   bool part2 = false, tr = false;
+  bf16x8_t afA[PFM], bfA[PFN], afB[PFM], bfB[PFN];      // fragment sets of the two halves of a k-step: one is read while the other feeds the MFMAs
 
-  // ONE flat loop over this workgroup's k-steps; the two iterations before the first k-step only issue (pipeline fill, once per launch)
-  for (int g = -2; g < G; ++g) {
-    if (g >= 0) {
-      if (!(a.pad0 & 2)) wait_vmcnt_dyn(issued - (buf == 0 ? mark0 : (buf == 1 ? mark1 : mark2)));      // stage g landed: only what was issued after its pieces may still be in flight
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();                      // ... for every wave; every wave is done with k-step g - 1 (and with the last epilogue's LDS reads)
-      asm volatile("" ::: "memory");
-    }
-    if (g + 2 < G && !((a.pad0 & 4) && g >= 0)) {                                     // issue stage g + 2 into the slot k-step g - 1 released
-      if (is_t == 0) {                                   // first k-step of tile ordinal is_j: per-piece byte offsets of its operands
-        int mt, nt;
-        tile_coords((int)blockIdx.x + is_j * P, ntm, ntn, a.n_major, a.tm_xm, a.tm_gm, mt, nt);
-        is_m0 = mt * PBM;
-        const int in0 = nt * PBN;
-        is_abase = (const char*)a.p_src[0];
-        is_left = a.nplain == 2 ? steps0 : 0x7fffffff;
-        is_wb = (const char*)(a.W + (a.w_img_bs ? (long)(is_m0 / a.rows_per_b) * a.w_img_bs : 0L));
-#pragma unroll
-        for (int i = 0; i < P_IA; ++i) lo_a[i] = ((unsigned)(is_m0 + (i * PNWV + wave) * 8 + srow) * (unsigned)a.p_c[0] + (unsigned)sslot * 8) * 2u;
-#pragma unroll
-        for (int i = 0; i < P_IB; ++i) {
-          const int n = min(in0 + (i * PNWV + wave) * 8 + srow, a.N - 1);
-          lo_w[i] = ((unsigned)n * (unsigned)a.ldw + (unsigned)sslot * 8) * 2u;
-        }
-      }
-      if (is_left == 0) {                                // block-uniform: the second plain segment starts at this k-step
-        is_abase = (const char*)a.p_src[1];
-#pragma unroll
-        for (int i = 0; i < P_IA; ++i) lo_a[i] = ((unsigned)(is_m0 + (i * PNWV + wave) * 8 + srow) * (unsigned)a.p_c[1] + (unsigned)sslot * 8) * 2u;
-        is_left = 0x7fffffff;
-      }
-      --is_left;
-      const unsigned As = lds0 + is_slot * P_STAGE + wave * 1024;
-      const unsigned Bs = As + P_A_BYTES;
-      const char* ab = uni_ptr(is_abase);
-      const char* wb = uni_ptr(is_wb);
-#pragma unroll
-      for (int i = 0; i < P_IA; ++i) { glds(ab, lo_a[i], As + i * PNWV * 1024); lo_a[i] += BK * 2; }
-#pragma unroll
-      for (int i = 0; i < P_IB; ++i) {
-        if (i * PNWV + wave >= P_PB) continue;           // wave-uniform
-        glds(wb, lo_w[i], Bs + i * PNWV * 1024); lo_w[i] += BK * 2;
-      }
-      issued += n_stage;
-      if (is_slot == 0) mark0 = issued; else if (is_slot == 1) mark1 = issued; else mark2 = issued;
-      if (++is_slot == PNST) is_slot = 0;
-      if (++is_t == nk) { is_t = 0; ++is_j; }
-    }
-    if (g < 0) continue;
+  // pipeline fill, once per launch: all three ring slots, then the first half-step's fragments
+  if (G > 0) DFH_ISSUE_STAGE();
+  if (G > 1) DFH_ISSUE_STAGE();
+  if (G > 2) DFH_ISSUE_STAGE();
+  if (G > 0) {
+    wait_vmcnt_dyn(issued - mark0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    DFH_LOAD_FRAGS(afA, bfA, 0, 0);
+  }
+  // SOFTWARE-PIPELINED k-loop: the fragment reads of the NEXT 32-deep half are issued in front of the MFMAs of the current one, and the
+  // workgroup meets in the MIDDLE of a k-step (when its second half sits in registers, i.e. when nobody reads the stage any more).  One
+  // workgroup per CU moves through its phases in lock step -- without this, "all waves read LDS" (875 cycles per k-step of this tile) and "all
+  // waves issue MFMAs" (640) add up instead of overlapping (profiles/r06/persistent_lean_gemm.md).
+  for (int g = 0; g < G; ++g) {
+    const int nbuf = buf == PNST - 1 ? 0 : buf + 1;
+    DFH_LOAD_FRAGS(afB, bfB, buf, 1);                    // second half of stage g -> registers ...
+    __builtin_amdgcn_sched_barrier(0);
+    DFH_MFMAS(afA, bfA);                                 // ... under the MFMAs of its first half
+    __builtin_amdgcn_sched_barrier(0);
+    // lgkmcnt(0) through the BUILTIN: the compiler's own wait insertion sees it and knows the second-half fragments are in registers; behind an
+    // asm wait it re-waits in front of their MFMAs -- by then the next half's reads are in flight, and it waits for THOSE (in-order counter)
+    __builtin_amdgcn_s_waitcnt(0xC07F);                  // vmcnt(63) expcnt(7) lgkmcnt(0): this wave no longer reads stage g
+    asm volatile("" ::: "memory");
+    if (g + 1 < G) wait_vmcnt_dyn(issued - (nbuf == 0 ? mark0 : (nbuf == 1 ? mark1 : mark2)));      // stage g + 1 landed (this wave's pieces)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // stage g + 1 visible to every wave; every wave is done with stage g (and with the last epilogue's LDS reads)
+    asm volatile("" ::: "memory");
+    if (n_issued < G) DFH_ISSUE_STAGE();                 // refill the slot of stage g with stage g + 3
     if (t == 0) {
-      int mt_;
-      tile_coords((int)blockIdx.x + j * P, ntm, ntn, a.n_major, a.tm_xm, a.tm_gm, mt_, nt_);
-      m0 = mt_ * PBM; n0 = nt_ * PBN;
-      tb_ = m0 / a.rows_per_b;
+      // tile start.  The producer started this tile's first stage three k-steps ago and will not start the next tile before k-step nk - 3 of
+      // this one (nk >= 4): q_m0 / q_n0 still hold what it saved then.
+      m0 = q_m0; n0 = q_n0;
+      nt_ = n0 / PBN;
+      tb_ = need_tb ? m0 / a.rows_per_b : 0;
       part2 = a.out2 != nullptr && n0 >= a.n_split;      // block-uniform: a transposed tile of the second destination
       tr = part2 || a.out_mode == OUT_BF16_T;
       // the epilogue's operands, by LDS-DMA: residual tile -> staging region (staged layout, in place), column slices and LayerNorm records
@@ -190,8 +257,7 @@ __global__ __launch_bounds__(PNWV * 64, 2) void gemm_persist_kernel(const GemmAr
         for (int i = 0; i < (P_RES_PIECES + PNWV - 1) / PNWV; ++i) {
           const int p = i * PNWV + wave;
           if (p >= P_RES_PIECES) continue;               // wave-uniform
-          const int c = p * 64 + lane, row = c / 21, q = c - row * 21;
-          const unsigned off = ((unsigned)(m0 + row) * (unsigned)a.ld_res + (unsigned)(n0 + (q < 20 ? q : 0) * 8)) * 2u;
+          const unsigned off = (((unsigned)m0 + r_row[i]) * (unsigned)a.ld_res + (unsigned)n0 + r_q8[i]) * 2u;
           glds(rb, off, lds0 + P_EPI + p * 1024);
         }
         issued += (P_RES_PIECES / PNWV) + (wave < P_RES_PIECES % PNWV ? 1 : 0);
@@ -207,32 +273,13 @@ __global__ __launch_bounds__(PNWV * 64, 2) void gemm_persist_kernel(const GemmAr
         glds(uni_ptr(a.ln_stat + ((long)(wave - 2) * a.M + m0) * 2), lane * 16, lds0 + P_AUX + wave * 1024); issued += 1;
       }
     }
-    {
-      const unsigned char* As = smem + buf * P_STAGE;
-      const unsigned char* Bs = As + P_A_BYTES;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8_t af[PFM], bfr[PFN];
-#pragma unroll
-        for (int i = 0; i < PFM; ++i) {
-          const int row = wm * PTM + i * 16 + fr;
-          af[i] = *(const bf16x8_t*)(As + row * 128 + (((ks * 4 + fg) ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int jj = 0; jj < PFN; ++jj) {
-          const int row = wn * PTN + jj * 16 + fr;
-          bfr[jj] = *(const bf16x8_t*)(Bs + row * 128 + (((ks * 4 + fg) ^ ((row >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < PFM; ++i)
-#pragma unroll
-          for (int jj = 0; jj < PFN; ++jj)
-            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[jj], af[i], acc[i][jj], 0, 0, 0);
-      }
-      if (++buf == PNST) buf = 0;
-    }
+    if (g + 1 < G) DFH_LOAD_FRAGS(afA, bfA, nbuf, 0);    // first half of stage g + 1 -> registers ...
+    __builtin_amdgcn_sched_barrier(0);
+    DFH_MFMAS(afB, bfB);                                 // ... under the MFMAs of the second half of stage g
+    __builtin_amdgcn_sched_barrier(0);
+    buf = nbuf;
     if (++t < nk) continue;
-    t = 0; ++j;
+    t = 0;
 
     // ---------------------------------------------------------------- epilogue of tile j (gemm.hip's staged branch on its own LDS)
     // Its DMA operands were issued at this tile's first k-step, BEFORE the stage of k-step 2: the counted waits of k-steps >= 3 retired
@@ -420,7 +467,7 @@ int gemm_persist_launch(const GemmArgs& a, hipStream_t stream, int max_wgs) {
   int wgs = std::min(tiles, max_wgs > 0 ? max_wgs : 256);
   if (wgs >= 8) wgs &= ~7;                               // a multiple of the 8 XCDs: tile v and v + grid then run on the same XCD, as in the tile launch
   GemmArgs b = a;
-  static const int dbg = [] { const char* e = getenv("DFH_PERSIST_DBG"); return e ? atoi(e) : 0; }();      // timing probes only (results are wrong): 1 no stores, 2 no waits, 4 no ring refills
+  static const int dbg = [] { const char* e = getenv("DFH_PERSIST_DBG"); return e ? atoi(e) : 0; }();      // timing probe only (results are wrong): 1 = no output stores (the first form also had 2 = no waits, 4 = no refills: profiles/r06/persist_timing_probes.txt)
   b.pad0 = dbg;
   hipLaunchKernelGGL(gemm_persist_kernel, dim3(wgs), dim3(PNWV * 64), P_LDS, stream, b);
   return check_launch("gemm_persist_kernel");

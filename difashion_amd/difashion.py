@@ -8,9 +8,10 @@
     prompts, then the fused ``pipeline.sample_outfits`` loop and the VAE decode.
 
 The outer bookkeeping (dict lookups, index lists, RNG draws in the reference's order) is plain Python / torch -- plumbing; every
-tensor op of the path runs in libdifashion_hip.so.  Components are injected (the reference builds them from a checkpoint
-directory inside ``__init__``; ``from_components`` keeps that out of this class): any ``vae`` / ``text_encoder`` with the
-diffusers call signatures works, e.g. this package's ``AutoencoderKL`` and a ``prompts.PromptTable`` in place of CLIP.
+tensor op of the path runs in libdifashion_hip.so.  ``__init__`` takes the components (any ``vae`` / ``text_encoder`` with the
+diffusers / transformers call signatures works, e.g. a ``prompts.PromptTable`` in place of the text encoder);
+``DiFashion.from_pretrained_pipeline(args, logger, cate_num, device)`` is the reference's constructor (difashion.py:52-120): it
+builds them from the sub-folders of a Stable-Diffusion snapshot with this package's classes and widens ``conv_in``.
 """
 from __future__ import annotations
 
@@ -35,6 +36,56 @@ class DiFashion(nn.Module):
             vae.requires_grad_(False)                                    # difashion.py:106
         if text_encoder is None and prompt_table is None:
             raise ValueError("either text_encoder + tokenizer or a prompt_table is needed")
+
+    @classmethod
+    def from_pretrained_pipeline(cls, args, logger=None, cate_num: int = 50, device=None, tokenizer=None, prompt_table=None):
+        """What the reference's constructor does (difashion.py:52-120, ``DiFashion(args, logger, cate_num, device)``) on the MI355X classes:
+        scheduler / text encoder / VAE / U-Net from the sub-folders of ``args.pretrained_model_name_or_path`` (a Stable-Diffusion snapshot
+        directory), the U-Net's ``conv_in`` widened to 8 input channels with the pretrained weights in the first four and zeros behind
+        (:82-93), a fresh ``MutualEncoder`` with xavier-normal linears (:95-102), the VAE and the text encoder frozen (:106-107).  The
+        tokenizer is host-side string processing and stays transformers' ``CLIPTokenizer`` (loaded from ``tokenizer/`` when none is passed)."""
+        from .clip import CLIPTextModel
+        from .mutual import MutualEncoder
+        from .schedulers import PNDMScheduler
+        from .unet import UNet2DConditionModel
+        from .vae import AutoencoderKL
+        root = args.pretrained_model_name_or_path
+        info = logger.info if logger is not None else (lambda *a, **k: None)
+        info("load PDNMScheduler...")
+        sched = PNDMScheduler.from_pretrained(root, subfolder="scheduler")
+        if tokenizer is None and prompt_table is None:
+            info("load CLIPTokenizer...")
+            from transformers import CLIPTokenizer            # host-only; not part of the compute path
+            tokenizer = CLIPTokenizer.from_pretrained(root, subfolder="tokenizer", revision=getattr(args, "revision", None))
+        info("load CLIPTextModel...")
+        text = CLIPTextModel.from_pretrained(root, subfolder="text_encoder", revision=getattr(args, "revision", None))
+        info("load VAE...")
+        vae = AutoencoderKL.from_pretrained(root, subfolder="vae")
+        info("load UNet...")
+        unet = UNet2DConditionModel.from_pretrained(root, subfolder="unet")
+        info("Initializing the DiFashion UNet from the pretrained UNet.")
+        old = unet.conv_in
+        unet.register_to_config(in_channels=8)                # [latents, history_latents]
+        with torch.no_grad():
+            new_conv_in = nn.Conv2d(8, old.out_channels, old.kernel_size, old.stride, old.padding)
+            new_conv_in.weight.zero_()
+            new_conv_in.weight[:, :old.weight.shape[1]].copy_(old.weight)
+            # (the reference copies the weight only: the bias keeps nn.Conv2d's fresh default init, difashion.py:87-92 -- mirrored as is,
+            #  same constructor call, so the same torch RNG state gives the same bias)
+        unet.conv_in = new_conv_in
+        enc = MutualEncoder(cate_num=cate_num, cate_emb_size=args.category_emb_size, latent_channels=vae.config.latent_channels,
+                            latent_size=unet.config.sample_size, hid_dim=args.hid_dim)
+        for m in enc.modules():                               # xavier_normal_initialization (difashion.py:731-743)
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_normal_(m.weight.data)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias.data, 0)
+        text.requires_grad_(False)
+        if getattr(args, "enable_xformers_memory_efficient_attention", False):
+            unet.enable_xformers_memory_efficient_attention()  # accepted no-op: attention is always the fused HIP kernel
+        model = cls(args, vae=vae, unet=unet, fashion_encoder=enc, noise_scheduler=sched, text_encoder=text, tokenizer=tokenizer,
+                    prompt_table=prompt_table, logger=logger)
+        return model.to(device) if device is not None else model
 
     @property
     def device(self) -> torch.device:

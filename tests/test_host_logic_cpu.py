@@ -221,6 +221,40 @@ def test_checkpoint_directories_round_trip_like_the_reference_hooks(tmp_path):
 
 
 # ----------------------------------------------------------------------------- batch builder
+def test_difashion_is_built_from_a_snapshot_directory_like_the_reference_constructor(tmp_path):
+    """difashion.py:52-120: scheduler / text_encoder / vae / unet sub-folders of ``pretrained_model_name_or_path``, conv_in widened to 8 input
+    channels (pretrained weights in the first four, zeros behind), fresh xavier-normal MutualEncoder, VAE and text encoder frozen.  Host
+    logic only (no kernel runs): the snapshot is written by this package's own ``save_pretrained`` methods in the diffusers / transformers
+    directory layouts."""
+    import types
+    import difashion_amd as da
+    root = str(tmp_path)
+    unet = da.UNet2DConditionModel(sample_size=16, in_channels=4, block_out_channels=(32, 64, 64, 64), cross_attention_dim=64,
+                                   attention_head_dim=(1, 2, 2, 2), init_seed=3)
+    unet.save_pretrained(os.path.join(root, "unet"))
+    da.AutoencoderKL(block_out_channels=(32, 64, 64, 64), sample_size=32, init_seed=4).save_pretrained(os.path.join(root, "vae"))
+    da.CLIPTextModel(vocab_size=100, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                     init_seed=5).save_pretrained(os.path.join(root, "text_encoder"))
+    da.PNDMScheduler(prediction_type="v_prediction").save_pretrained(os.path.join(root, "scheduler"))
+    args = types.SimpleNamespace(pretrained_model_name_or_path=root, revision=None, non_ema_revision=None, category_emb_size=8, hid_dim=32,
+                                 enable_xformers_memory_efficient_attention=True, use_history=True, use_mutual_guidance=True, eta=0.1)
+    tok = types.SimpleNamespace(model_max_length=77)
+    m = da.DiFashion.from_pretrained_pipeline(args, logger=None, cate_num=7, device=None, tokenizer=tok)
+    assert isinstance(m.noise_scheduler, da.PNDMScheduler) and m.noise_scheduler.config.prediction_type == "v_prediction"
+    assert isinstance(m.text_encoder, da.CLIPTextModel) and not any(p.requires_grad for p in m.text_encoder.parameters())
+    assert isinstance(m.vae, da.AutoencoderKL) and not any(p.requires_grad for p in m.vae.parameters()) and m.vae_scale_factor == 8
+    w = m.unet.conv_in.weight
+    assert tuple(w.shape) == (32, 8, 3, 3) and m.unet.config.in_channels == 8
+    assert torch.equal(w[:, :4], unet.conv_in.weight) and float(w[:, 4:].abs().max()) == 0.0
+    # the reference copies the WEIGHT only (difashion.py:87-92): the widened conv's bias is nn.Conv2d's own fresh draw, not the pretrained one
+    assert not torch.equal(m.unet.conv_in.bias, unet.conv_in.bias) and float(m.unet.conv_in.bias.abs().max()) <= 1.0 / (8 * 9) ** 0.5 + 1e-6
+    enc = m.fashion_encoder
+    assert enc.category_embedding.weight.shape == (7, 8) and enc.mlp[0].weight.shape == (32, 4 * 16 * 16)
+    assert float(enc.mlp[0].bias.abs().max()) == 0.0 and float(enc.mlp[3].bias.abs().max()) == 0.0
+    assert any(p.requires_grad for p in m.unet.parameters()) and m.tokenizer is tok
+    assert torch.equal(m.text_encoder.state_dict()["text_model.final_layer_norm.weight"], torch.ones(64))
+
+
 def test_preprocess_dataset_matches_the_reference_function(tmp_path):
     """difashion_amd.data.preprocess_dataset vs golden vectors captured from the REAL DiFashion/data_utils.py
     (tests/golden/make_golden_data.py): prompts, token ids, history latents (bit-exact), FITB masking."""

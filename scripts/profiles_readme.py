@@ -70,6 +70,13 @@ def block(tag):
     va = last_json(os.path.join(d, "bench_vae_n1.json"))
     if va:
         out.append(f"* VAE (`{tag}/bench_vae_n1.json`): {va['value']:.1f} {va['unit']}.")
+    for name, what in (("bench_clip_n1.json", "CLIP ViT-L/14 shape (SD-1.5)"), ("bench_clip_sd2base_n1.json", "OpenCLIP ViT-H/14 shape (SD-2)")):
+        x = last_json(os.path.join(d, name))
+        if x:       # round 6: the prompt table through the HIP CLIP text encoder (bench.py --mode clip)
+            out.append(f"* CLIP text encoder, {what} (`{tag}/{name}`): {x['ms_per_step']:.2f} ms per prompt table (51 x 77 tokens), "
+                       f"{x['roofline']['achieved']:.1f} TFLOP/s = {x['roofline']['frac']:.3f} of the fp32 MFMA peak"
+                       + (f"; CPU oracle beside it {x['cpu_baseline']['value']:.2f} {x['cpu_baseline']['unit']} on {x['cpu_baseline']['cores']} host threads"
+                          if x.get("cpu_baseline") else "") + ".")
     st = os.path.join(d, "kernel_stats.csv")
     if os.path.exists(st):
         n, ms, us = gemm_family(st)

@@ -152,12 +152,15 @@ class CLIPTextModel(nn.Module):
             raise _lib.DfhError("parameters must stay fp32 (the kernels read them in place)")
         cfg = self.config
         shape = tuple(input_ids.shape)
-        ids = input_ids.reshape(-1, shape[-1]).to(device=dev, dtype=torch.int64).contiguous()
-        B, T = ids.shape
+        T = shape[-1]
         if T > cfg["max_position_embeddings"]:
             raise ValueError(f"Sequence length must be less than max_position_embeddings (got `sequence length`: {T} and "
                              f"max_position_embeddings: {cfg['max_position_embeddings']}")
-        lo, hi = int(ids.min()), int(ids.max())                   # nn.Embedding raises on these too (one sync; the encoder runs once per run)
+        # nn.Embedding raises on out-of-range ids too.  Checked where the ids LIVE: tokenizer output is a CPU tensor (no device sync then);
+        # ids that already sit on the GPU cost one sync, and the encoder runs once per run (PromptTable.build)
+        lo, hi = int(input_ids.min()), int(input_ids.max())
+        ids = input_ids.reshape(-1, T).to(device=dev, dtype=torch.int64).contiguous()
+        B = ids.shape[0]
         if lo < 0 or hi >= cfg["vocab_size"]:
             raise IndexError(f"input_ids out of range [0, {cfg['vocab_size']}): min {lo}, max {hi}")
         lib = _lib.raw()

@@ -153,3 +153,26 @@ def test_no_product_kernel_spills():
         assert hits, frag
         for k in hits:
             assert tab[k].get("private_segment_fixed_size", 0) == 0, (k, tab[k])
+
+
+def test_clip_context_and_parameter_table_without_a_gpu():
+    """dfh_clip_create is host-only work: the parameter table (transformers 4.32.1 names / order) and the argument checks."""
+    import ctypes as C
+    lib = _lib.raw()
+    bad = _lib.CLIPConfigC(100, 30, 128, 2, 4, 77, 1, 1e-5)                 # hidden_size not a multiple of 4
+    h = C.c_void_p()
+    with pytest.raises(_lib.DfhError, match="multiples of 4"):
+        _lib.call("dfh_clip_create", C.byref(bad), C.byref(h))
+    with pytest.raises(_lib.DfhError, match="128 positions"):
+        _lib.call("dfh_clip_create", C.byref(_lib.CLIPConfigC(100, 64, 128, 2, 4, 200, 1, 1e-5)), C.byref(h))
+    with pytest.raises(_lib.DfhError, match="hidden_act"):
+        _lib.call("dfh_clip_create", C.byref(_lib.CLIPConfigC(100, 64, 128, 2, 4, 77, 3, 1e-5)), C.byref(h))
+    m = da.CLIPTextModel(vocab_size=100, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4)
+    names = [n for n, _ in m.param_table()]
+    assert names[0] == "text_model.embeddings.token_embedding.weight" and names[2] == "text_model.encoder.layers.0.self_attn.k_proj.weight"
+    assert names[-1] == "text_model.final_layer_norm.bias" and len(names) == 2 + 16 * 2 + 2 == len(list(m.parameters()))
+    assert lib.dfh_clip_workspace_bytes(m._make_ctx(), 51, 77) > 51 * 77 * (6 * 64 + 128) * 4
+    # both checkpoint key layouts load (4.32.1 nests under text_model., newer transformers releases do not)
+    sd = {k[len("text_model."):]: v for k, v in m.state_dict().items()}
+    sd["embeddings.position_ids"] = torch.arange(77)[None]
+    da.CLIPTextModel(vocab_size=100, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4).load_state_dict(sd)

@@ -51,19 +51,19 @@ class DiFashion(nn.Module):
         from .vae import AutoencoderKL
         root = args.pretrained_model_name_or_path
         info = logger.info if logger is not None else (lambda *a, **k: None)
-        info("load PDNMScheduler...")
+        info("scheduler <- scheduler/")
         sched = PNDMScheduler.from_pretrained(root, subfolder="scheduler")
         if tokenizer is None and prompt_table is None:
-            info("load CLIPTokenizer...")
+            info("tokenizer <- tokenizer/ (transformers, host side)")
             from transformers import CLIPTokenizer            # host-only; not part of the compute path
             tokenizer = CLIPTokenizer.from_pretrained(root, subfolder="tokenizer", revision=getattr(args, "revision", None))
-        info("load CLIPTextModel...")
+        info("text encoder <- text_encoder/ (HIP CLIPTextModel)")
         text = CLIPTextModel.from_pretrained(root, subfolder="text_encoder", revision=getattr(args, "revision", None))
-        info("load VAE...")
+        info("VAE <- vae/ (HIP AutoencoderKL)")
         vae = AutoencoderKL.from_pretrained(root, subfolder="vae")
-        info("load UNet...")
+        info("U-Net <- unet/ (HIP UNet2DConditionModel)")
         unet = UNet2DConditionModel.from_pretrained(root, subfolder="unet")
-        info("Initializing the DiFashion UNet from the pretrained UNet.")
+        info("widening conv_in to [latents | history latents]")
         old = unet.conv_in
         unet.register_to_config(in_channels=8)                # [latents, history_latents]
         with torch.no_grad():
